@@ -1,0 +1,57 @@
+/*
+ * hipdeflate_params.h -- algorithm geometry shared by the HIP kernels
+ * (7bgzf_amd/csrc) and their CPU twin (oracle/hd_deflate_twin.c).
+ *
+ * The GPU encoder is NOT libdeflate: it is a wave64-native parse (64 input
+ * positions looked up at once, greedy resolution by ballot, bit packing by a
+ * wave prefix scan).  Its output is valid RFC 1951; it is byte-identical to
+ * the CPU twin, which restates the same algorithm serially.  Everything both
+ * sides must agree on lives here so that a change of geometry cannot make
+ * them drift apart silently.
+ *
+ * Level map (role of lib/libdeflate/deflate_compress.c:3874-3990 in the
+ * reference, where a level selects matchfinder + parser + Huffman mode):
+ *   0      stored blocks only          (store_deflate, lib/zlibutil.c:302)
+ *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like")
+ *   2..4   greedy parse, dynamic Huffman
+ *   5..9   lazy parse (one-chunk lookahead), dynamic Huffman (config 5,
+ *          "level-6-like")
+ */
+#ifndef HIPDEFLATE_PARAMS_H
+#define HIPDEFLATE_PARAMS_H
+
+#define HD_WAVE            64          /* positions parsed per step = lanes */
+#define HD_MIN_MATCH       4           /* hash covers 4 bytes               */
+#define HD_MAX_MATCH       258         /* RFC 1951 3.2.5                    */
+#define HD_PIECE           1024        /* window refill granule (64 x 16 B) */
+#define HD_LOOKAHEAD       384         /* >= 64 + 258 + 8, bytes past S     */
+
+/* level 1: static Huffman, streaming emit (no token buffer) */
+#define HD_L1_WIN_BITS     14          /* 16 KiB LDS ring window            */
+#define HD_L1_HASH_BITS    11          /* 2048 x u32 = 8 KiB LDS            */
+
+/* levels >= 2: dynamic Huffman, tokens buffered in a global scratch slab */
+#define HD_L2_WIN_BITS     15          /* 32 KiB ring: full DEFLATE window  */
+#define HD_L2_HASH_BITS    12
+
+#define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
+
+/* a DEFLATE block of the dynamic path ends after this many tokens */
+#define HD_DYN_MAX_TOKENS  (1u << 16)
+
+/* worst-case bits one parse step can emit with the static code:
+ * 64 tokens x (8+5 + 5+13 = 31 bits) */
+#define HD_STEP_MAX_BITS   (64 * 31)
+
+/* stored-block framing cost: 5 bytes per <=65535-byte block, at least one */
+#define HD_STORED_SIZE(n)  ((n) + 5u * ((n) == 0 ? 1u : (((n) + 65534u) / 65535u)))
+
+/* result codes of the inflate path = enum libdeflate_result
+ * (lib/libdeflate/libdeflate.h:193-208), which libdeflate_inflate
+ * (lib/zlibutil.c:194-204) hands straight back to the applet */
+#define HD_OK                  0
+#define HD_BAD_DATA            1
+#define HD_SHORT_OUTPUT        2
+#define HD_INSUFFICIENT_SPACE  3
+
+#endif

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REAL reference (oracle/_ref/libref.so,
+built by oracle/Makefile from /root/reference).  Run in the build container:
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+The outputs are DATA (inputs, reference outputs, verdicts), not source:
+
+* inflate_std_vects.json -- the 151 malformed DEFLATE streams the reference's
+  own test-suite holds (byte arrays of lib/isa-l/igzip/inflate_std_vects.h:4-803
+  and the expected ISAL_* code of :810-962), plus the verdict of each of the
+  three in-tree inflaters run here (libdeflate_inflate lib/zlibutil.c:194,
+  igzip_inflate lib/zlibutil_igzip.c:93, raw zlib inflate).
+* ref_streams.json -- raw-DEFLATE streams produced by every reference encoder
+  on small seeded inputs (libdeflate 0/1/6/9/12, zlib 1/6/9, slz 1, miniz 1,
+  store), with the SHA-256 of what they inflate to.  They cover stored, static,
+  dynamic, multi-block and 15-bit-code streams.
+* mutants.json -- bit-flip / truncation mutants of valid streams with the
+  verdict (and output hash on success) of libdeflate_inflate: the accept/reject
+  contract of the inflate path.
+* boundary.json -- known answers at the drop-in boundary: bgzf_compress
+  (bgzf_compress.c:39) return codes/sizes/header bytes, the EOF member,
+  zlibutil_buffer_code's RFC1950/1952 wrappers (lib/zlibutil.c:374-405),
+  store_deflate, crc32/adler32 values.
+"""
+import base64
+import ctypes
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hdtest  # noqa: E402
+
+REF_TREE = os.environ.get("HD_REFERENCE", "/root/reference")
+
+
+def b64(b):
+    return base64.b64encode(bytes(b)).decode()
+
+
+def zlib_raw_inflate(ref, data, cap):
+    """raw inflate(Z_FINISH) with the reference's zlib 1.3.1; returns (ok, out)."""
+
+    class ZS(ctypes.Structure):
+        _fields_ = [("next_in", ctypes.c_void_p), ("avail_in", ctypes.c_uint), ("total_in", ctypes.c_ulong),
+                    ("next_out", ctypes.c_void_p), ("avail_out", ctypes.c_uint), ("total_out", ctypes.c_ulong),
+                    ("msg", ctypes.c_char_p), ("state", ctypes.c_void_p), ("zalloc", ctypes.c_void_p),
+                    ("zfree", ctypes.c_void_p), ("opaque", ctypes.c_void_p), ("data_type", ctypes.c_int),
+                    ("adler", ctypes.c_ulong), ("reserved", ctypes.c_ulong)]
+
+    src = hdtest.as_u8(data)
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    z = ZS()
+    ref.inflateInit2_.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    assert ref.inflateInit2_(ctypes.byref(z), -15, b"1.3.1", ctypes.sizeof(ZS)) == 0
+    z.next_in = src.ctypes.data
+    z.avail_in = len(src)
+    z.next_out = dst.ctypes.data
+    z.avail_out = cap
+    r = ref.inflate(ctypes.byref(z), 4)  # Z_FINISH
+    out = bytes(dst[: z.total_out])
+    ref.inflateEnd(ctypes.byref(z))
+    return r == 1, out  # Z_STREAM_END
+
+
+ISAL_CODES = {"ISAL_DECOMP_OK": 0, "ISAL_END_INPUT": 1, "ISAL_OUT_OVERFLOW": 2, "ISAL_INVALID_BLOCK": -1,
+              "ISAL_INVALID_SYMBOL": -2, "ISAL_INVALID_LOOKBACK": -3}
+
+
+def isal_stateless(ref, data, cap):
+    """isal_inflate_stateless (lib/isa-l/igzip/igzip_inflate.c:2146) called directly, the
+    way igzip_rand_test.c:2538 drives it; struct inflate_state head fields per
+    lib/isa-l/include/igzip_lib.h:511-518."""
+    import struct
+    src = hdtest.as_u8(data)
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    st = (ctypes.c_uint8 * (1 << 18))()
+    ref.isal_inflate_init(st)
+    struct.pack_into("<QII", st, 0, dst.ctypes.data, cap, 0)
+    struct.pack_into("<Q", st, 16, src.ctypes.data)
+    struct.pack_into("<I", st, 32, len(src))
+    return ref.isal_inflate_stateless(st)
+
+
+def gen_std_vects(ref):
+    text = open(os.path.join(REF_TREE, "lib/isa-l/igzip/inflate_std_vects.h")).read()
+    arrays = {}
+    for m in re.finditer(r"uint8_t\s+(std_vect_\d+)\[\]\s*=\s*\{([^}]*)\}", text):
+        arrays[m.group(1)] = bytes(int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", m.group(2)))
+    table = re.findall(r"\{\s*(std_vect_\d+),\s*sizeof\(\1\),\s*(ISAL_\w+)\s*\}", text)
+    assert len(table) == 151 and len(arrays) == 151
+    out = []
+    for name, err in table:
+        v = arrays[name]
+        cap = 1 << 20
+        r_ld, _ = hdtest.call_dec(ref.libdeflate_inflate, v, cap)
+        r_ig, _ = hdtest.call_dec(ref.igzip_inflate, v, cap)
+        ok_z, _ = zlib_raw_inflate(ref, v, cap)
+        r_isal = isal_stateless(ref, v, cap)
+        assert r_isal == ISAL_CODES[err], (name, r_isal, err)
+        out.append({"name": name, "data": b64(v), "isal_expected": err, "isal_stateless": r_isal,
+                    "libdeflate": r_ld, "igzip_adapter": r_ig, "zlib_stream_end": ok_z})
+    json.dump(out, open(os.path.join(HERE, "inflate_std_vects.json"), "w"), indent=0)
+    print("inflate_std_vects.json:", len(out), "vectors; rejected by libdeflate:",
+          sum(1 for o in out if o["libdeflate"] != 0))
+
+
+ENCODERS = [("libdeflate", 0), ("libdeflate", 1), ("libdeflate", 6), ("libdeflate", 9), ("libdeflate", 12),
+            ("zlib", 1), ("zlib", 6), ("zlib", 9), ("slz", 1), ("miniz", 1), ("store", 0)]
+
+
+def ref_encode(ref, name, level, data):
+    if name == "slz":
+        ref.slz_initialize()
+    f = getattr(ref, name + "_deflate")
+    r, z = hdtest.call_enc(f, data, level, cap=len(data) * 2 + 4096)
+    assert r == 0, (name, level, r)
+    return z
+
+
+def gen_ref_streams(ref):
+    corpus = hdtest.corpus_small()
+    # keep the committed file small: each 64 KiB input only through the encoders
+    # that give it a distinct block structure (SURVEY.md section 4 "stream mix")
+    big = {"fastq_ff00": {("libdeflate", 1), ("libdeflate", 6), ("zlib", 6), ("slz", 1)},
+           "text_ff00": {("libdeflate", 6)}, "mixed": {("libdeflate", 12), ("zlib", 1)},
+           "zeros_64k": {("libdeflate", 1), ("zlib", 6), ("slz", 1)}}
+    out = []
+    for cname, data in corpus.items():
+        if cname == "empty":
+            encs = [e for e in ENCODERS if e[0] != "store"]  # store_deflate emits nothing for n == 0
+        else:
+            encs = ENCODERS
+        for name, level in encs:
+            if len(data) > 30000 and (name, level) not in big.get(cname, ()):
+                continue
+            z = ref_encode(ref, name, level, data)
+            r, o = hdtest.call_dec(ref.libdeflate_inflate, z, len(data))
+            assert r == 0 and o == data
+            out.append({"input": cname, "encoder": name, "level": level, "stream": b64(z),
+                        "out_len": len(data), "out_sha256": hdtest.sha(data)})
+    json.dump(out, open(os.path.join(HERE, "ref_streams.json"), "w"), indent=0)
+    print("ref_streams.json:", len(out), "streams,", sum(len(o["stream"]) for o in out) * 3 // 4, "bytes")
+
+
+def gen_mutants(ref):
+    rng = np.random.default_rng(2025)
+    s = hdtest.synth()
+    bases = []
+    for k, data in (("fastq", bytes(s.fastq_like(1500, seed=7))), ("text", bytes(s.text_like(1200, seed=8))),
+                    ("rep", b"abcdefgh" * 100 + bytes(200))):
+        for name, level in (("libdeflate", 1), ("libdeflate", 6), ("libdeflate", 12), ("zlib", 6), ("slz", 1)):
+            bases.append((k, name, level, data, ref_encode(ref, name, level, data)))
+    out = []
+    for k, name, level, data, z in bases:
+        for _ in range(40):
+            m = bytearray(z)
+            kind = int(rng.integers(0, 4))
+            if kind < 3:
+                for _ in range(kind + 1):
+                    bit = int(rng.integers(0, len(m) * 8))
+                    m[bit >> 3] ^= 1 << (bit & 7)
+            else:
+                m = m[: max(1, len(m) - int(rng.integers(1, 16)))]
+            cap = len(data) + 64
+            r, o = hdtest.call_dec(ref.libdeflate_inflate, bytes(m), cap)
+            r_ig, o_ig = hdtest.call_dec(ref.igzip_inflate, bytes(m), cap)
+            okz, oz = zlib_raw_inflate(ref, bytes(m), cap)
+            out.append({"base": "%s/%s%d" % (k, name, level), "stream": b64(m), "cap": cap, "libdeflate": r,
+                        "out_sha256": hdtest.sha(o) if r == 0 else None, "out_len": len(o) if r == 0 else None,
+                        "igzip_adapter": r_ig, "zlib_stream_end": okz})
+    json.dump(out, open(os.path.join(HERE, "mutants.json"), "w"), indent=0)
+    acc = sum(1 for o in out if o["libdeflate"] == 0)
+    print("mutants.json:", len(out), "mutants; accepted by libdeflate:", acc)
+
+
+def gen_boundary(ref):
+    s = hdtest.synth()
+    fq = bytes(s.fastq_like(0xff00))
+    res = {}
+    os.environ["BGZF_METHOD"] = "libdeflate1"
+    ref.bgzf_compress.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                  ctypes.c_size_t, ctypes.c_int]
+
+    def hook(data, cap):
+        src = hdtest.as_u8(data)
+        dst = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = ctypes.c_size_t(cap)
+        r = ref.bgzf_compress(dst.ctypes.data, ctypes.byref(n), src.ctypes.data if len(src) else None, len(src), -1)
+        return r, n.value, bytes(dst[: n.value]) if r == 0 else b""
+
+    r, n, m = hook(fq, 0x10000)
+    payload = m[18:-8]
+    r2, inflated = hdtest.call_dec(ref.libdeflate_inflate, payload, len(fq))
+    assert r == 0 and r2 == 0 and inflated == fq
+    res["hook_fastq_ff00"] = {"ret": r, "dlen": n, "header18": m[:18].hex(), "trailer8": m[-8:].hex(),
+                              "bsize_plus1": int.from_bytes(m[16:18], "little") + 1,
+                              "first_block_bfinal": payload[0] & 1, "first_block_btype": (payload[0] >> 1) & 3,
+                              "input_sha256": hdtest.sha(fq)}
+    r, n, m = hook(b"", 0x10000)
+    res["hook_eof"] = {"ret": r, "dlen": n, "member": m.hex()}
+    r, n, _ = hook(b"", 27)
+    res["hook_eof_cap27"] = {"ret": r}
+    r, n, _ = hook(fq[:100], 20)
+    res["hook_cap20"] = {"ret": r}
+    r, n, _ = hook(fq[:100], 25)
+    res["hook_cap25"] = {"ret": r}
+
+    # checksums
+    res["crc32"] = {k: ref.crc32(0, v, len(v)) & 0xffffffff for k, v in
+                    (("empty", b""), ("a", b"a"), ("123456789", b"123456789"), ("fastq_ff00", fq))}
+    ref.crc32_gzip_refl.restype = ctypes.c_uint32
+    res["crc32_gzip_refl"] = {k: ref.crc32_gzip_refl(0, v, ctypes.c_uint64(len(v))) for k, v in
+                              (("123456789", b"123456789"), ("fastq_ff00", fq))}
+    res["adler32"] = {k: ref.adler32(1, v, len(v)) & 0xffffffff for k, v in
+                      (("empty", b""), ("123456789", b"123456789"), ("fastq_ff00", fq))}
+
+    # store_deflate known answers (lib/zlibutil.c:302)
+    st = {}
+    for k, v in (("abc", b"abc"), ("n65535", bytes(65535)), ("n65536", bytes(65536)), ("n70000", fq + fq[:4720])):
+        r, z = hdtest.call_enc(ref.store_deflate, v, 0, cap=len(v) + 100)
+        st[k] = {"ret": r, "len": len(z), "sha256": hdtest.sha(z), "head5": z[:5].hex()}
+    r, z = hdtest.call_enc(ref.store_deflate, b"abc", 0, cap=7)
+    st["abc_cap7"] = {"ret": r}
+    res["store_deflate"] = st
+
+    # zlibutil_buffer_code wrappers around store_deflate (deterministic payload)
+    class ZB(ctypes.Structure):
+        _fields_ = [("dest", ctypes.c_void_p), ("destLen", ctypes.c_size_t), ("source", ctypes.c_void_p),
+                    ("sourceLen", ctypes.c_size_t), ("func", ctypes.c_void_p), ("encode", ctypes.c_int),
+                    ("level", ctypes.c_int), ("rfc1950", ctypes.c_int), ("rfc1952", ctypes.c_int),
+                    ("ret", ctypes.c_int)]
+
+    ref.zlibutil_buffer_allocate.restype = ctypes.POINTER(ZB)
+    ref.zlibutil_buffer_allocate.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    ref.zlibutil_buffer_code.restype = ctypes.POINTER(ZB)
+    ref.zlibutil_buffer_code.argtypes = [ctypes.POINTER(ZB)]
+    ref.zlibutil_buffer_free.argtypes = [ctypes.POINTER(ZB)]
+    wr = {}
+    data = b"hello hello hello wrapper"
+    for mode in ("rfc1950", "rfc1952"):
+        zb = ref.zlibutil_buffer_allocate(200, len(data))
+        ctypes.memmove(zb.contents.source, data, len(data))
+        zb.contents.func = ctypes.cast(ref.store_deflate, ctypes.c_void_p)
+        zb.contents.encode = 1
+        zb.contents.level = 0
+        setattr(zb.contents, mode, 1)
+        ref.zlibutil_buffer_code(zb)
+        out = ctypes.string_at(zb.contents.dest, zb.contents.destLen)
+        if mode == "rfc1952":
+            out = out[:4] + b"\0\0\0\0" + out[8:]  # MTIME = time(NULL): masked
+        wr[mode] = {"ret": zb.contents.ret, "bytes": out.hex(), "input": data.decode()}
+        ref.zlibutil_buffer_free(zb)
+    res["zlibutil_buffer_code_store"] = wr
+    json.dump(res, open(os.path.join(HERE, "boundary.json"), "w"), indent=1)
+    print("boundary.json:", json.dumps(res["hook_fastq_ff00"]))
+
+
+def main():
+    ref = hdtest.ref()
+    assert ref is not None, "build the reference first: make -C oracle ref"
+    gen_std_vects(ref)
+    gen_ref_streams(ref)
+    gen_mutants(ref)
+    gen_boundary(ref)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""Shared test plumbing: ctypes views of the oracle (checker), of the real
+reference library when it has been built (oracle/_ref/libref.so), and of the
+product's C-ABI (7bgzf_amd/libhipdeflate.so)."""
+import ctypes
+import hashlib
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def pkg():
+    return importlib.import_module("7bgzf_amd")
+
+
+def synth():
+    return importlib.import_module("7bgzf_amd.synth")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(0, dtype=np.uint8)
+
+
+_oracle = None
+
+
+def oracle():
+    """liboracle.so, built on demand (gcc, < 2 s)."""
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"], check=True)
+        lib = ctypes.CDLL(so)
+        lib.hdo_crc32.restype = ctypes.c_uint32
+        lib.hdo_crc32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+        lib.hdo_adler32.restype = ctypes.c_uint32
+        lib.hdo_adler32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+        lib.hdo_inflate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                    ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        lib.hdo_deflate_twin.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_int]
+        lib.hdo_store_deflate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                          ctypes.c_size_t]
+        for f in (lib.hdo_bgzf_frame, lib.hdo_migz_frame):
+            f.restype = ctypes.c_size_t
+            f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                          ctypes.c_uint32, ctypes.c_uint32]
+        lib.hdo_bgzf_eof.restype = ctypes.c_size_t
+        lib.hdo_bgzf_eof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        lib.hdo_read_gz_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
+        _oracle = lib
+    return _oracle
+
+
+def ref_path():
+    return os.path.join(ORACLE_DIR, "_ref", "libref.so")
+
+
+_ref = None
+
+
+def ref():
+    """The real reference (libdeflate 1.23, zlib 1.3.1, isa-l 2.31.1, slz, the
+    zlibutil adapters and bgzf_compress), or None when it has not been built."""
+    global _ref
+    if _ref is None and os.path.exists(ref_path()):
+        _ref = ctypes.CDLL(ref_path())
+    return _ref
+
+
+# ---- codec call helpers: all take/return bytes-like, mirror zlibutil_code_enc/_dec
+
+
+def call_enc(func, data, level, cap=None):
+    src = as_u8(data)
+    cap = (len(src) + len(src) // 2 + 1024) if cap is None else cap
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = ctypes.c_size_t(cap)
+    r = func(_ptr(dst), ctypes.byref(n), _ptr(src), ctypes.c_size_t(len(src)), ctypes.c_int(level))
+    return r, bytes(dst[: n.value]) if r == 0 else b""
+
+
+def call_dec(func, data, cap, extra_arg=False):
+    src = as_u8(data)
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = ctypes.c_size_t(cap)
+    if extra_arg:
+        r = func(_ptr(dst), ctypes.byref(n), _ptr(src), ctypes.c_size_t(len(src)), None)
+    else:
+        r = func(_ptr(dst), ctypes.byref(n), _ptr(src), ctypes.c_size_t(len(src)))
+    return r, bytes(dst[: n.value]) if r == 0 else b""
+
+
+def oracle_inflate(data, cap):
+    return call_dec(oracle().hdo_inflate, data, cap, extra_arg=True)
+
+
+def oracle_twin(data, level, cap=None):
+    return call_enc(oracle().hdo_deflate_twin, data, level, cap)
+
+
+def oracle_crc32(data):
+    a = as_u8(data)
+    return oracle().hdo_crc32(0, _ptr(a), len(a))
+
+
+def corpus_small():
+    """Named small inputs used across the CPU tests (all < 70 KB)."""
+    s = synth()
+    fq = s.fastq_like(70000)
+    tx = s.text_like(70000)
+    rnd = s.random_bytes(70000)
+    return {
+        "empty": b"",
+        "one": b"a",
+        "three": b"abc",
+        "four": b"abcd",
+        "short_rep": b"abcabcabcabcabcabcabc",
+        "zeros_1k": bytes(1000),
+        "zeros_64k": bytes(0xff00),
+        "run_a_300": b"a" * 300,
+        "period3_5k": b"xyz" * 1700,
+        "fastq_ff00": bytes(fq[:0xff00]),
+        "fastq_10000": bytes(fq[:0x10000]),
+        "fastq_777": bytes(fq[:777]),
+        "text_ff00": bytes(tx[:0xff00]),
+        "text_5000": bytes(tx[:5000]),
+        "random_ff00": bytes(rnd[:0xff00]),
+        "random_100": bytes(rnd[:100]),
+        "mixed": bytes(fq[:20000]) + bytes(rnd[:20000]) + bytes(20000) + bytes(tx[:5280]),
+        "bytes_0_255_x4": bytes(range(256)) * 4,
+    }

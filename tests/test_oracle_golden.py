@@ -1,0 +1,171 @@
+"""The oracle (oracle/*.c) against the committed golden vectors that were
+produced by the real reference (tests/golden/make_golden.py).  CPU only."""
+import base64
+import json
+import os
+
+import pytest
+
+import hdtest
+
+G = hdtest.GOLDEN
+
+
+def load(name):
+    return json.load(open(os.path.join(G, name)))
+
+
+def test_std_vects_all_rejected():
+    """lib/isa-l/igzip/inflate_std_vects.h: 151 malformed streams; the reference's
+    three inflaters reject every one and so must we."""
+    vects = load("inflate_std_vects.json")
+    assert len(vects) == 151
+    for v in vects:
+        # isal_inflate_stateless returns the listed ISAL_* code; libdeflate and zlib reject;
+        # only the igzip ADAPTER (lib/zlibutil_igzip.c:111) lets ISAL_END_INPUT through
+        assert v["isal_stateless"] != 0 and v["libdeflate"] != 0 and not v["zlib_stream_end"]
+        assert v["igzip_adapter"] != 0 or v["isal_expected"] == "ISAL_END_INPUT"
+        r, _ = hdtest.oracle_inflate(base64.b64decode(v["data"]), 1 << 20)
+        assert r != 0, v["name"]
+
+
+def test_ref_streams_inflate_bit_exact():
+    streams = load("ref_streams.json")
+    assert len(streams) > 100
+    kinds = set()
+    for s in streams:
+        z = base64.b64decode(s["stream"])
+        kinds.add((z[0] >> 1) & 3)
+        r, out = hdtest.oracle_inflate(z, s["out_len"])
+        assert r == 0, (s["input"], s["encoder"], s["level"])
+        assert len(out) == s["out_len"] and hdtest.sha(out) == s["out_sha256"], (s["input"], s["encoder"])
+        # trailing bytes after BFINAL are ignored (applet/7bgzf.c:328 passes payload+trailer)
+        r, out2 = hdtest.oracle_inflate(z + b"\x12\x34\x56\x78\x9a\xbc\xde\xf0", s["out_len"])
+        assert r == 0 and out2 == out
+    assert kinds == {0, 1, 2}  # stored, static and dynamic first blocks all present
+
+
+def test_ref_streams_capacity_semantics():
+    """libdeflate_inflate (lib/zlibutil.c:194-204): capacity larger than the data is
+    fine (actual size returned); capacity one byte short is INSUFFICIENT_SPACE (3)."""
+    for s in load("ref_streams.json"):
+        if s["out_len"] == 0 or s["out_len"] > 6000:
+            continue
+        z = base64.b64decode(s["stream"])
+        r, out = hdtest.oracle_inflate(z, s["out_len"] + 100)
+        assert r == 0 and len(out) == s["out_len"]
+        r, _ = hdtest.oracle_inflate(z, s["out_len"] - 1)
+        assert r == 3, (s["input"], s["encoder"], r)
+
+
+def test_mutants_verdicts_match_libdeflate():
+    muts = load("mutants.json")
+    acc = 0
+    for m in muts:
+        z = base64.b64decode(m["stream"])
+        r, out = hdtest.oracle_inflate(z, m["cap"])
+        assert (r == 0) == (m["libdeflate"] == 0), (m["base"], r, m["libdeflate"])
+        if r == 0:
+            acc += 1
+            assert len(out) == m["out_len"] and hdtest.sha(out) == m["out_sha256"], m["base"]
+        else:
+            assert r == m["libdeflate"], (m["base"], r, m["libdeflate"])
+    assert acc > 100
+
+
+def test_checksums():
+    b = load("boundary.json")
+    fq = bytes(hdtest.synth().fastq_like(0xff00))
+    inputs = {"empty": b"", "a": b"a", "123456789": b"123456789", "fastq_ff00": fq}
+    assert hdtest.sha(fq) == b["hook_fastq_ff00"]["input_sha256"]
+    o = hdtest.oracle()
+    for k, v in b["crc32"].items():
+        assert hdtest.oracle_crc32(inputs[k]) == v
+    for k, v in b["crc32_gzip_refl"].items():
+        assert hdtest.oracle_crc32(inputs[k]) == v
+    for k, v in b["adler32"].items():
+        a = hdtest.as_u8(inputs[k])
+        assert o.hdo_adler32(1, a.ctypes.data, len(a)) == v
+    assert hdtest.oracle_crc32(b"123456789") == 0xCBF43926
+
+
+def test_store_deflate_known_answers():
+    import ctypes
+    b = load("boundary.json")["store_deflate"]
+    fq = bytes(hdtest.synth().fastq_like(0xff00))
+    inputs = {"abc": b"abc", "n65535": bytes(65535), "n65536": bytes(65536), "n70000": fq + fq[:4720]}
+    o = hdtest.oracle()
+
+    def store(v, cap):
+        import numpy as np
+        src = hdtest.as_u8(v)
+        dst = np.zeros(cap, dtype=np.uint8)
+        n = ctypes.c_size_t(cap)
+        r = o.hdo_store_deflate(dst.ctypes.data, ctypes.byref(n), src.ctypes.data, len(src))
+        return r, bytes(dst[: n.value])
+
+    for k, v in inputs.items():
+        r, z = store(v, len(v) + 100)
+        assert r == b[k]["ret"] == 0 and len(z) == b[k]["len"] and hdtest.sha(z) == b[k]["sha256"]
+        assert z[:5].hex() == b[k]["head5"]
+    r, _ = store(b"abc", 7)
+    assert r == b["abc_cap7"]["ret"] != 0
+
+
+def test_bgzf_framing_known_answers():
+    import ctypes
+    import numpy as np
+    b = load("boundary.json")
+    o = hdtest.oracle()
+    dst = np.zeros(100, dtype=np.uint8)
+    assert o.hdo_bgzf_eof(dst.ctypes.data, 100) == 28
+    assert bytes(dst[:28]).hex() == b["hook_eof"]["member"]
+    assert o.hdo_bgzf_eof(dst.ctypes.data, 27) == 0 and b["hook_eof_cap27"]["ret"] == -1
+    # frame a payload of the hook's size: header/trailer bytes must be the reference's
+    h = b["hook_fastq_ff00"]
+    fq = hdtest.synth().fastq_like(0xff00)
+    plen = h["dlen"] - 26
+    payload = np.zeros(plen, dtype=np.uint8)
+    out = np.zeros(70000, dtype=np.uint8)
+    n = o.hdo_bgzf_frame(out.ctypes.data, 70000, payload.ctypes.data, plen, hdtest.oracle_crc32(fq), len(fq))
+    assert n == h["dlen"]
+    assert bytes(out[:18]).hex() == h["header18"] and bytes(out[n - 8:n]).hex() == h["trailer8"]
+    # BSIZE > 65535 cannot be framed (applet/7bgzf.c:256)
+    assert o.hdo_bgzf_frame(out.ctypes.data, 70000, payload.ctypes.data, 65536 - 25, 0, 0) == 0
+
+
+def test_gz_header_parser():
+    import ctypes
+    import numpy as np
+    o = hdtest.oracle()
+    buf = np.zeros(64, dtype=np.uint8)
+    o.hdo_bgzf_eof(buf.ctypes.data, 64)
+    eo, el, bl = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+    n = o.hdo_read_gz_header(buf.ctypes.data, 64, ctypes.byref(eo), ctypes.byref(el), ctypes.byref(bl))
+    assert (n, eo.value, el.value, bl.value) == (18, 12, 6, 28)
+    payload = np.zeros(5, dtype=np.uint8)
+    o.hdo_migz_frame(buf.ctypes.data, 64, payload.ctypes.data, 5, 0, 0)
+    n = o.hdo_read_gz_header(buf.ctypes.data, 64, ctypes.byref(eo), ctypes.byref(el), ctypes.byref(bl))
+    assert (n, el.value, bl.value) == (20, 8, 5 + 20 + 8)
+    buf[0] = 0x1e
+    assert o.hdo_read_gz_header(buf.ctypes.data, 64, ctypes.byref(eo), ctypes.byref(el), ctypes.byref(bl)) == 0
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_twin_roundtrip_and_bounds(level):
+    """Encoder parity is a property, not golden bytes: the twin's
+    output must inflate to the input, and never exceed the stored size."""
+    import zlib
+    for name, data in hdtest.corpus_small().items():
+        r, z = hdtest.oracle_twin(data, level)
+        assert r == 0, name
+        assert zlib.decompress(z, -15) == data, name
+        r2, out = hdtest.oracle_inflate(z, len(data))
+        assert r2 == 0 and out == data, name
+        stored = len(data) + 5 * max(1, -(-len(data) // 65535))
+        assert len(z) <= stored, name
+        # capacity exactly the result size succeeds, one byte less fails or falls back
+        r3, z3 = hdtest.oracle_twin(data, level, cap=len(z))
+        assert r3 == 0 and z3 == z, name
+        r4, z4 = hdtest.oracle_twin(data, level, cap=len(z) - 1)
+        assert r4 != 0, name
