@@ -1,0 +1,533 @@
+// hd_api.hip -- the C ABI of libhipdeflate.so (include/hipdeflate.h): context,
+// device/pinned pools, kernel launches, and the per-block zlibutil-style codecs.
+//
+// No CPU codec lives here: when no gfx950 device is usable every entry point
+// fails loudly (HD_E_NODEVICE + one line on stderr).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/hipdeflate.h"
+#include "hd_deflate_static.hpp"
+#include "hd_deflate_dynamic.hpp"
+#include "hd_inflate.hpp"
+#include "hd_compact.hpp"
+
+namespace {
+
+using hd::CrcTables;
+
+#define HD_CHECK(expr)                                                                         \
+	do {                                                                                   \
+		hipError_t e_ = (expr);                                                        \
+		if (e_ != hipSuccess) {                                                        \
+			fprintf(stderr, "hipdeflate: %s failed: %s (%s:%d)\n", #expr,          \
+				hipGetErrorString(e_), __FILE__, __LINE__);                    \
+			return HD_E_NODEVICE;                                                  \
+		}                                                                              \
+	} while (0)
+
+struct Buf {
+	void *p = nullptr;
+	size_t cap = 0;
+	bool pinned = false;
+	int reserve(size_t n)
+	{
+		if (n <= cap)
+			return 0;
+		release();
+		size_t want = n + n / 4 + 4096;
+		hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+		if (e != hipSuccess) {
+			p = nullptr;
+			cap = 0;
+			fprintf(stderr, "hipdeflate: %s of %zu bytes failed: %s\n", pinned ? "hipHostMalloc" : "hipMalloc",
+				want, hipGetErrorString(e));
+			return HD_E_NOMEM;
+		}
+		cap = want;
+		return 0;
+	}
+	void release()
+	{
+		if (p)
+			(void)(pinned ? hipHostFree(p) : hipFree(p));
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+struct Ctx {
+	bool ready = false;
+	int failed = 0;
+	int device = -1;
+	char desc[256] = "hipdeflate (not initialised)";
+	hipStream_t stream = nullptr;
+	CrcTables *d_ct = nullptr;
+	// host-pointer API pools (guarded by mu)
+	std::mutex mu;
+	Buf d_in, d_meta, d_slots, d_packed, d_scratch, d_scan;
+	Buf h_in{ nullptr, 0, true }, h_meta{ nullptr, 0, true }, h_out{ nullptr, 0, true };
+	// device-pointer API scratch (token slabs for the dynamic levels), guarded by mu_dev
+	std::mutex mu_dev;
+	Buf d_tok;
+	Buf d_tiles;
+};
+
+Ctx g;
+std::mutex g_init_mu;
+
+void build_crc_tables(CrcTables *t)
+{
+	const uint32_t poly = 0xEDB88320u;
+	for (uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i;
+		for (int k = 0; k < 8; k++)
+			c = (c >> 1) ^ (poly & (0u - (c & 1u)));
+		t->T[0][i] = c;
+	}
+	for (int k = 1; k < 4; k++)
+		for (uint32_t i = 0; i < 256; i++)
+			t->T[k][i] = (t->T[k - 1][i] >> 8) ^ t->T[0][t->T[k - 1][i] & 0xff];
+	// B[k][v]: state (v << 8k) after 1008 zero bytes
+	for (int k = 0; k < 4; k++)
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t s = i << (8 * k);
+			for (int z = 0; z < 1008; z++)
+				s = t->T[0][s & 0xff] ^ (s >> 8);
+			t->B[k][i] = s;
+		}
+	// K[q] = x^(128 q): appending 16 q zero bytes to the state 0x80000000 (= x^0)
+	uint32_t s = 0x80000000u;
+	for (int q = 0; q < 64; q++) {
+		t->K[q] = s;
+		for (int z = 0; z < 16; z++)
+			s = t->T[0][s & 0xff] ^ (s >> 8);
+	}
+}
+
+int ctx_init(int device)
+{
+	std::lock_guard<std::mutex> lk(g_init_mu);
+	if (g.ready)
+		return 0;
+	if (g.failed)
+		return g.failed;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev == 0) {
+		fprintf(stderr, "hipdeflate: no HIP device (%s); there is no CPU fallback\n",
+			e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+		return g.failed = HD_E_NODEVICE;
+	}
+	if (device < 0) {
+		const char *s = getenv("HIPDEFLATE_DEVICE");
+		if (!s || !*s)
+			s = getenv("LOCAL_RANK");
+		device = s && *s ? atoi(s) % ndev : 0;
+	}
+	if (device >= ndev)
+		device = device % ndev;
+	hipDeviceProp_t prop;
+	HD_CHECK(hipSetDevice(device));
+	HD_CHECK(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		fprintf(stderr, "hipdeflate: device %d is %s; this library holds gfx950 (MI355X) code only\n", device,
+			prop.gcnArchName);
+		return g.failed = HD_E_NODEVICE;
+	}
+	HD_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+	CrcTables *h = (CrcTables *)malloc(sizeof(CrcTables));
+	build_crc_tables(h);
+	HD_CHECK(hipMalloc((void **)&g.d_ct, sizeof(CrcTables)));
+	HD_CHECK(hipMemcpy(g.d_ct, h, sizeof(CrcTables), hipMemcpyHostToDevice));
+	free(h);
+	g.device = device;
+	snprintf(g.desc, sizeof(g.desc), "hipdeflate 0.1 on device %d: %s (%s), %d CUs, %.0f GiB", device, prop.name,
+		 prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+	g.ready = true;
+	return 0;
+}
+
+inline int ensure()
+{
+	return g.ready ? 0 : ctx_init(-1);
+}
+
+// the host-pointer entry points may be called from any thread; the device of
+// the calling thread must be ours
+inline int bind_device()
+{
+	HD_CHECK(hipSetDevice(g.device));
+	return 0;
+}
+
+int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
+{
+	if (a.nblocks == 0)
+		return 0;
+	if (level <= 1) {
+		hd::DeflateArgs b = a;
+		b.level = level;
+		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS>), dim3(a.nblocks), dim3(64), 0, st, b);
+	} else {
+		int r = hd::launch_deflate_dynamic(a, level, st);
+		if (r)
+			return r;
+	}
+	HD_CHECK(hipGetLastError());
+	return 0;
+}
+
+inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+} // namespace
+
+extern "C" {
+
+int hipdeflate_init(int device) { return ctx_init(device); }
+
+int hipdeflate_available(void) { return ensure(); }
+
+const char *hipdeflate_version(void) { return g.desc; }
+
+void hipdeflate_shutdown(void)
+{
+	std::lock_guard<std::mutex> lk(g_init_mu);
+	if (!g.ready)
+		return;
+	(void)hipSetDevice(g.device);
+	(void)hipStreamSynchronize(g.stream);
+	for (Buf *b : { &g.d_in, &g.d_meta, &g.d_slots, &g.d_packed, &g.d_scratch, &g.d_scan, &g.h_in, &g.h_meta,
+			&g.h_out, &g.d_tok, &g.d_tiles })
+		b->release();
+	(void)hipFree(g.d_ct);
+	(void)hipStreamDestroy(g.stream);
+	g.d_ct = nullptr;
+	g.stream = nullptr;
+	g.ready = false;
+}
+
+uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level)
+{
+	return hd::dynamic_scratch_bytes(nblocks, max_block, level);
+}
+
+/* ---- device-pointer API ---------------------------------------------------- */
+
+int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, int level,
+				 int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
+				 void *crc32, void *status, void *stream)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (frame < HD_FRAME_RAW || frame > HD_FRAME_MIGZ || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
+		return HD_E_ARG;
+	hd::DeflateArgs a;
+	a.in = (const uint8_t *)in;
+	a.in_off = (const uint64_t *)in_off;
+	a.in_len = (const uint32_t *)in_len;
+	a.nblocks = nblocks;
+	a.frame = frame;
+	a.level = level;
+	a.out = (uint8_t *)out;
+	a.out_stride = out_stride;
+	a.out_cap = out_cap;
+	a.out_len = (uint32_t *)out_len;
+	a.crc = (uint32_t *)crc32;
+	a.status = (int32_t *)status;
+	a.ct = g.d_ct;
+	a.scratch = nullptr;
+	if (level >= 2) {
+		// token slabs for the dynamic levels: library-owned, grow-only
+		std::lock_guard<std::mutex> lk(g.mu_dev);
+		const uint64_t need = hd::dynamic_scratch_bytes(nblocks, 0, level);
+		if (g.d_tok.cap < need) {
+			// a re-allocation must not pull the rug from under launches in flight
+			HD_CHECK(hipDeviceSynchronize());
+			if (g.d_tok.reserve(need))
+				return HD_E_NOMEM;
+		}
+		a.scratch = (uint8_t *)g.d_tok.p;
+	}
+	return launch_deflate(a, level, (hipStream_t)stream);
+}
+
+int hipdeflate_batch_inflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
+				 const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status,
+				 void *stream)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (!out_len)
+		return HD_E_ARG;
+	if (nblocks == 0)
+		return 0;
+	hd::InflateArgs a;
+	a.in = (const uint8_t *)in;
+	a.in_off = (const uint64_t *)in_off;
+	a.in_len = (const uint32_t *)in_len;
+	a.nblocks = nblocks;
+	a.out = (uint8_t *)out;
+	a.out_off = (const uint64_t *)out_off;
+	a.out_cap = (const uint32_t *)out_cap;
+	a.out_len = (uint32_t *)out_len;
+	a.crc = (uint32_t *)crc32;
+	a.status = (int32_t *)status;
+	a.ct = g.d_ct;
+	hipLaunchKernelGGL(hd::k_inflate, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, a);
+	HD_CHECK(hipGetLastError());
+	return 0;
+}
+
+int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t base, void *dst_off, void *total,
+			      void *stream)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (nblocks == 0) {
+		if (total)
+			HD_CHECK(hipMemsetAsync(total, 0, 8, (hipStream_t)stream));
+		return 0;
+	}
+	const uint32_t ntiles = (nblocks + hd::SCAN_TILE - 1) / hd::SCAN_TILE;
+	uint64_t *tiles;
+	{
+		std::lock_guard<std::mutex> lk(g.mu_dev);
+		if (g.d_tiles.cap < (size_t)ntiles * 8) {
+			HD_CHECK(hipDeviceSynchronize());
+			if (g.d_tiles.reserve((size_t)ntiles * 8))
+				return HD_E_NOMEM;
+		}
+		tiles = (uint64_t *)g.d_tiles.p;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(hd::k_scan_tile_sums, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)out_len, nblocks, tiles);
+	hipLaunchKernelGGL(hd::k_scan_tiles, dim3(1), dim3(256), 0, st, tiles, ntiles, base, (uint64_t *)total);
+	hipLaunchKernelGGL(hd::k_scan_finish, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)out_len, nblocks, tiles,
+			   (uint64_t *)dst_off);
+	HD_CHECK(hipGetLastError());
+	return 0;
+}
+
+int hipdeflate_compact_dev(const void *slots, uint64_t stride, const void *out_len, const void *dst_off,
+			   uint32_t nblocks, void *dst, void *stream)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (nblocks == 0)
+		return 0;
+	if ((stride & 3) || ((uintptr_t)slots & 3))
+		return HD_E_ARG;
+	hipLaunchKernelGGL(hd::k_compact, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)slots, stride,
+			   (const uint32_t *)out_len, (const uint64_t *)dst_off, nblocks, (uint8_t *)dst);
+	HD_CHECK(hipGetLastError());
+	return 0;
+}
+
+/* ---- host-pointer API ------------------------------------------------------ */
+
+int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
+			     int level, int frame, uint8_t *out, uint64_t out_stride, uint32_t out_cap,
+			     uint32_t *out_len, uint32_t *crc32, int32_t *status)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (nblocks == 0)
+		return 0;
+	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_MIGZ)
+		return HD_E_ARG;
+	std::lock_guard<std::mutex> lk(g.mu);
+	if ((r = bind_device()))
+		return r;
+
+	// pack the blocks 16-byte aligned into pinned memory (one H2D, aligned fast path)
+	size_t in_total = 0, max_len = 0;
+	for (uint32_t i = 0; i < nblocks; i++) {
+		in_total += up16(in_len[i]);
+		if (in_len[i] > max_len)
+			max_len = in_len[i];
+	}
+	const uint64_t cap_user = out_stride < out_cap ? out_stride : out_cap;
+	// device slot: what the user allows, but never more than any encoding needs
+	const size_t need = max_len + 5 * (max_len / 65535 + 1) + 32;
+	const size_t slot = up16(cap_user < need ? cap_user : need);
+	const size_t meta_bytes = (size_t)nblocks * (8 + 4 + 4 + 4 + 4 + 8);
+	if (g.h_in.reserve(in_total + 16) || g.h_meta.reserve(meta_bytes) || g.d_in.reserve(in_total + 16) ||
+	    g.d_meta.reserve(meta_bytes) || g.d_slots.reserve(slot * nblocks + 16) || g.d_scan.reserve(16))
+		return HD_E_NOMEM;
+	uint8_t *hin = (uint8_t *)g.h_in.p;
+	uint64_t *h_off = (uint64_t *)g.h_meta.p;
+	uint32_t *h_len = (uint32_t *)(h_off + nblocks);
+	size_t o = 0;
+	for (uint32_t i = 0; i < nblocks; i++) {
+		h_off[i] = o;
+		h_len[i] = in_len[i];
+		if (in_len[i])
+			memcpy(hin + o, in + in_off[i], in_len[i]);
+		o += up16(in_len[i]);
+	}
+	uint8_t *dm = (uint8_t *)g.d_meta.p;
+	uint64_t *d_off = (uint64_t *)dm;
+	uint32_t *d_len = (uint32_t *)(d_off + nblocks);
+	uint32_t *d_olen = d_len + nblocks;
+	uint32_t *d_crc = d_olen + nblocks;
+	int32_t *d_st = (int32_t *)(d_crc + nblocks);
+	uint64_t *d_doff = (uint64_t *)(d_st + nblocks);
+	HD_CHECK(hipMemcpyAsync(g.d_in.p, hin, in_total, hipMemcpyHostToDevice, g.stream));
+	HD_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)nblocks * 12, hipMemcpyHostToDevice, g.stream));
+	r = hipdeflate_batch_deflate_dev(g.d_in.p, d_off, d_len, nblocks, level, frame, g.d_slots.p, slot,
+					 (uint32_t)(cap_user < slot ? cap_user : slot), d_olen, d_crc, d_st, g.stream);
+	if (r)
+		return r;
+	// gather on the device so that only the compressed bytes cross PCIe
+	uint64_t *d_total = (uint64_t *)g.d_scan.p;
+	if ((r = hipdeflate_scan_sizes_dev(d_olen, nblocks, 0, d_doff, d_total, g.stream)))
+		return r;
+	if (g.d_packed.reserve(slot * nblocks + 16))
+		return HD_E_NOMEM;
+	if ((r = hipdeflate_compact_dev(g.d_slots.p, slot, d_olen, d_doff, nblocks, g.d_packed.p, g.stream)))
+		return r;
+	uint32_t *h_olen = (uint32_t *)g.h_meta.p;               // reuse: olen, crc, status
+	HD_CHECK(hipMemcpyAsync(h_olen, d_olen, (size_t)nblocks * 12, hipMemcpyDeviceToHost, g.stream));
+	uint64_t total = 0;
+	HD_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, g.stream));
+	HD_CHECK(hipStreamSynchronize(g.stream));
+	if (g.h_out.reserve(total + 16))
+		return HD_E_NOMEM;
+	HD_CHECK(hipMemcpyAsync(g.h_out.p, g.d_packed.p, total, hipMemcpyDeviceToHost, g.stream));
+	HD_CHECK(hipStreamSynchronize(g.stream));
+	const uint8_t *hp = (const uint8_t *)g.h_out.p;
+	const uint32_t *h_crc = h_olen + nblocks;
+	const int32_t *h_st = (const int32_t *)(h_crc + nblocks);
+	size_t po = 0;
+	for (uint32_t i = 0; i < nblocks; i++) {
+		out_len[i] = h_olen[i];
+		if (crc32)
+			crc32[i] = h_crc[i];
+		if (status)
+			status[i] = h_st[i];
+		memcpy(out + (uint64_t)i * out_stride, hp + po, h_olen[i]);
+		po += h_olen[i];
+	}
+	return 0;
+}
+
+int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
+			     uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+			     uint32_t *crc32, int32_t *status)
+{
+	int r = ensure();
+	if (r)
+		return r;
+	if (nblocks == 0)
+		return 0;
+	if (!in_off || !in_len || !out_off || !out_cap || !out_len)
+		return HD_E_ARG;
+	std::lock_guard<std::mutex> lk(g.mu);
+	if ((r = bind_device()))
+		return r;
+	size_t in_total = 0, out_total = 0;
+	for (uint32_t i = 0; i < nblocks; i++) {
+		in_total += up16(in_len[i]);
+		out_total += up16(out_cap[i]);
+	}
+	const size_t meta_bytes = (size_t)nblocks * (8 + 4 + 8 + 4 + 4 + 4 + 4);
+	if (g.h_in.reserve(in_total + 16) || g.h_meta.reserve(meta_bytes) || g.d_in.reserve(in_total + 16) ||
+	    g.d_meta.reserve(meta_bytes) || g.d_slots.reserve(out_total + 16) || g.h_out.reserve(out_total + 16))
+		return HD_E_NOMEM;
+	uint8_t *hin = (uint8_t *)g.h_in.p;
+	uint64_t *h_ioff = (uint64_t *)g.h_meta.p;
+	uint64_t *h_ooff = h_ioff + nblocks;
+	uint32_t *h_ilen = (uint32_t *)(h_ooff + nblocks);
+	uint32_t *h_ocap = h_ilen + nblocks;
+	size_t io = 0, oo = 0;
+	for (uint32_t i = 0; i < nblocks; i++) {
+		h_ioff[i] = io;
+		h_ooff[i] = oo;
+		h_ilen[i] = in_len[i];
+		h_ocap[i] = out_cap[i];
+		if (in_len[i])
+			memcpy(hin + io, in + in_off[i], in_len[i]);
+		io += up16(in_len[i]);
+		oo += up16(out_cap[i]);
+	}
+	uint8_t *dm = (uint8_t *)g.d_meta.p;
+	uint64_t *d_ioff = (uint64_t *)dm;
+	uint64_t *d_ooff = d_ioff + nblocks;
+	uint32_t *d_ilen = (uint32_t *)(d_ooff + nblocks);
+	uint32_t *d_ocap = d_ilen + nblocks;
+	uint32_t *d_olen = d_ocap + nblocks;
+	uint32_t *d_crc = d_olen + nblocks;
+	int32_t *d_st = (int32_t *)(d_crc + nblocks);
+	HD_CHECK(hipMemcpyAsync(g.d_in.p, hin, in_total, hipMemcpyHostToDevice, g.stream));
+	HD_CHECK(hipMemcpyAsync(dm, g.h_meta.p, (size_t)nblocks * 24, hipMemcpyHostToDevice, g.stream));
+	r = hipdeflate_batch_inflate_dev(g.d_in.p, d_ioff, d_ilen, nblocks, g.d_slots.p, d_ooff, d_ocap, d_olen,
+					 crc32 ? d_crc : nullptr, d_st, g.stream);
+	if (r)
+		return r;
+	uint32_t *h_olen = (uint32_t *)g.h_meta.p + 6 * (size_t)nblocks;     // past the 24 B/blk inputs
+	HD_CHECK(hipMemcpyAsync(h_olen, d_olen, (size_t)nblocks * 12, hipMemcpyDeviceToHost, g.stream));
+	HD_CHECK(hipMemcpyAsync(g.h_out.p, g.d_slots.p, out_total, hipMemcpyDeviceToHost, g.stream));
+	HD_CHECK(hipStreamSynchronize(g.stream));
+	const uint32_t *h_crc = h_olen + nblocks;
+	const int32_t *h_st = (const int32_t *)(h_crc + nblocks);
+	for (uint32_t i = 0; i < nblocks; i++) {
+		out_len[i] = h_olen[i];
+		if (crc32)
+			crc32[i] = h_crc[i];
+		if (status)
+			status[i] = h_st[i];
+		if (h_st[i] == 0 && h_olen[i])
+			memcpy(out + out_off[i], (const uint8_t *)g.h_out.p + h_ooff[i], h_olen[i]);
+	}
+	return 0;
+}
+
+/* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */
+
+int hip_deflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level)
+{
+	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xffffffffu - 65536u)
+		return HD_E_ARG;
+	uint64_t off = 0;
+	uint32_t len = (uint32_t)sourceLen, olen = 0;
+	int32_t st = 0;
+	const size_t cap = *destLen > 0xfffffff0u ? 0xfffffff0u : *destLen;
+	// the slot stride handed to the batch call only needs to cover `cap`
+	int r = hipdeflate_batch_deflate(source, &off, &len, 1, level, HD_FRAME_RAW, dest, up16(cap) ? up16(cap) : 16,
+					 (uint32_t)cap, &olen, nullptr, &st);
+	if (r)
+		return r;
+	if (st)
+		return 1; /* !Z_OK, as libdeflate_deflate (lib/zlibutil.c:189) */
+	*destLen = olen;
+	return 0;
+}
+
+int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)
+{
+	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xfffffff0u)
+		return HD_E_ARG;
+	uint64_t ioff = 0, ooff = 0;
+	uint32_t ilen = (uint32_t)sourceLen, olen = 0;
+	uint32_t ocap = *destLen > 0xfffffff0u ? 0xfffffff0u : (uint32_t)*destLen;
+	int32_t st = 0;
+	int r = hipdeflate_batch_inflate(source, &ioff, &ilen, 1, dest, &ooff, &ocap, &olen, nullptr, &st);
+	if (r)
+		return r;
+	if (st)
+		return st;
+	*destLen = olen;
+	return 0;
+}
+
+} // extern "C"

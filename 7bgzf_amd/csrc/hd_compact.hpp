@@ -1,0 +1,129 @@
+// hd_compact.hpp -- size prefix scan + member gather.
+//
+// Role: the in-order writer of applet/7bgzf.c:223-272 (join threads in order,
+// fwrite each member) becomes "exclusive prefix sum of the member sizes, then
+// every member copied to its final offset", all on the device.  With several
+// GPUs each rank adds its base (the all-gathered totals of the lower ranks,
+// SURVEY.md 8(e)) through the `base` argument.  HBM-bound byte copy.
+#pragma once
+#include "hd_device.hpp"
+
+namespace hd {
+
+constexpr uint32_t SCAN_TILE = 2048;     // elements per 256-thread workgroup
+
+// pass 1: per-tile sums
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t *len, uint32_t n, uint64_t *tile_sum)
+{
+	__shared__ uint64_t wsum[4];
+	const uint32_t t = threadIdx.x, tile = blockIdx.x;
+	uint64_t s = 0;
+	for (uint32_t i = tile * SCAN_TILE + t; i < n && i < (tile + 1) * SCAN_TILE; i += 256)
+		s += len[i];
+	for (int o = 32; o > 0; o >>= 1) {
+		s += ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)s, o, 64)) |
+		     ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)(s >> 32), o, 64) << 32);
+	}
+	if ((t & 63) == 0)
+		wsum[t >> 6] = s;
+	__syncthreads();
+	if (t == 0)
+		tile_sum[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: one workgroup turns tile sums into exclusive tile offsets (+ base)
+__global__ __launch_bounds__(256) void k_scan_tiles(uint64_t *tile_sum, uint32_t ntiles, uint64_t base, uint64_t *total)
+{
+	__shared__ uint64_t part[256];
+	const uint32_t t = threadIdx.x;
+	const uint32_t per = (ntiles + 255) / 256;
+	uint64_t s = 0;
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t i = t * per + k;
+		if (i < ntiles)
+			s += tile_sum[i];
+	}
+	part[t] = s;
+	__syncthreads();
+	if (t == 0) {
+		uint64_t run = base;
+		for (uint32_t k = 0; k < 256; k++) {
+			const uint64_t v = part[k];
+			part[k] = run;
+			run += v;
+		}
+		if (total)
+			*total = run - base;
+	}
+	__syncthreads();
+	uint64_t run = part[t];
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t i = t * per + k;
+		if (i < ntiles) {
+			const uint64_t v = tile_sum[i];
+			tile_sum[i] = run;
+			run += v;
+		}
+	}
+}
+
+// pass 3: exclusive scan inside each tile
+__global__ __launch_bounds__(256) void k_scan_finish(const uint32_t *len, uint32_t n, const uint64_t *tile_off, uint64_t *dst_off)
+{
+	__shared__ uint32_t wtot[4];
+	const uint32_t t = threadIdx.x, tile = blockIdx.x, lane = t & 63, w = t >> 6;
+	// thread t owns 8 consecutive elements
+	const uint32_t i0 = tile * SCAN_TILE + t * 8;
+	uint32_t v[8], s = 0;
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		v[k] = i0 + k < n ? len[i0 + k] : 0;
+		s += v[k];
+	}
+	const uint32_t incl = wave_incl_scan(s);
+	if (lane == 63)
+		wtot[w] = incl;
+	__syncthreads();
+	uint64_t run = tile_off[tile] + (incl - s);
+	for (uint32_t k = 0; k < w; k++)
+		run += wtot[k];
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		if (i0 + k < n)
+			dst_off[i0 + k] = run;
+		run += v[k];
+	}
+}
+
+// one wavefront per member: slots + i*stride (16-byte aligned) -> dst + dst_off[i]
+__global__ __launch_bounds__(64) void k_compact(const uint8_t *slots, uint64_t stride, const uint32_t *len,
+						const uint64_t *dst_off, uint32_t n, uint8_t *dst)
+{
+	const uint32_t i = blockIdx.x, lane = threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t L = len[i];
+	const uint8_t *s = slots + (uint64_t)i * stride;
+	uint8_t *d = dst + dst_off[i];
+	// head: bytes until d is dword aligned
+	uint32_t head = (uint32_t)((4 - ((uintptr_t)d & 3)) & 3);
+	if (head > L)
+		head = L;
+	if (lane < head)
+		d[lane] = s[lane];
+	const uint32_t body = (L - head) >> 2;           // whole destination dwords
+	const uint32_t *s32 = (const uint32_t *)s;       // source dwords (aligned)
+	uint32_t *d32 = (uint32_t *)(d + head);
+	for (uint32_t k = lane; k < body; k += 64) {
+		// destination dword k = source bytes [head + 4k, head + 4k + 4)
+		const uint32_t so = head + 4 * k;
+		const uint32_t lo = s32[so >> 2];
+		const uint32_t hi = (so & 3) ? s32[(so >> 2) + 1] : 0;
+		d32[k] = __builtin_amdgcn_alignbyte(hi, lo, so & 3);
+	}
+	const uint32_t done = head + 4 * body;
+	if (lane < L - done)
+		d[done + lane] = s[done + lane];
+}
+
+} // namespace hd

@@ -1,0 +1,361 @@
+// hd_deflate_static.hpp -- level 1: greedy LZ77 + static Huffman, one wavefront
+// per block, streaming bit emission (BASELINE config 2).
+//
+// Replaces, for BGZF_METHOD=hip1, what libdeflate_deflate (lib/zlibutil.c:179)
+// -> deflate_compress_fastest (lib/libdeflate/deflate_compress.c:2453-2524)
+// -> deflate_flush_block (:1707-2038) do per block on one CPU thread, and the
+// CRC-32 of the block (fcrc32, applet/7bgzf.c:269) and the BGZF/MiGz framing
+// (applet/7bgzf.c:263-272, applet/7migz.c:224-233) that the applet adds.
+//
+// The parse is wave64-native (oracle/hd_deflate_twin.c is its serial twin and
+// must produce the same bytes):
+//   lanes stand on 64 consecutive positions S..S+63; each hashes its 4 bytes,
+//   reads the candidate from the LDS hash table, then publishes itself with
+//   ds_max_u32; candidates are verified against the LDS ring window; a ballot
+//   gives the match-start mask, a scalar loop takes matches left to right and
+//   extends each one cooperatively (64 bytes per ballot); literal / match codes
+//   are placed with a DPP prefix scan of their bit lengths and OR-ed into an
+//   LDS staging ring that is flushed to HBM as whole dwords.
+//
+// HBM traffic per block: input read once (16 B/lane pieces), output written
+// once.  LDS per wave: ring 2^WIN_BITS + table 4*2^HASH_BITS + 512 B staging.
+#pragma once
+#include "hd_device.hpp"
+
+namespace hd {
+
+struct DeflateArgs {
+	const uint8_t *in;
+	const uint64_t *in_off;
+	const uint32_t *in_len;
+	uint32_t nblocks;
+	int frame;
+	int level;
+	uint8_t *out;
+	uint64_t out_stride;
+	uint32_t out_cap;
+	uint32_t *out_len;
+	uint32_t *crc;
+	int32_t *status;
+	const CrcTables *ct;
+	uint8_t *scratch;               // token slabs of the dynamic levels
+};
+
+__device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
+{
+	return frame == HD_FRAME_BGZF ? 18u : frame == HD_FRAME_MIGZ ? 20u : 0u;
+}
+
+// byte `o` of the container header; `sizefield` = BSIZE (u16) or compsize (u32)
+__device__ __forceinline__ uint32_t frame_hdr_byte(int frame, uint32_t o, uint32_t sizefield)
+{
+	// 1f 8b 08 04 | 00 00 00 00 | 00 ff XL 00 | S1 S2 SL 00 | size...
+	const uint32_t w0 = 0x04088b1fu, w1 = 0u;
+	const uint32_t w2 = frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u;
+	const uint32_t w3 = frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du;
+	uint32_t w = o < 4 ? w0 : o < 8 ? w1 : o < 12 ? w2 : o < 16 ? w3 : sizefield;
+	return (w >> (8 * (o & 3))) & 0xff;
+}
+
+// Stored-block form of the whole member, written from scratch (fallback when
+// the Huffman stream would not be smaller, deflate_compress.c:1820-1856; the
+// guarantee that a 0xff00-byte BGZF block always fits).
+__device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32_t b, const uint8_t *src, uint32_t n,
+						  uint32_t crc, uint32_t lane)
+{
+	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+	const uint32_t stored = HD_STORED_SIZE(n);
+	const uint32_t total = hdr + stored + trl;
+	uint64_t cap = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+	if (a.frame == HD_FRAME_BGZF && cap > 65536)
+		cap = 65536;
+	if (total > cap) {
+		if (lane == 0) {
+			a.out_len[b] = 0;
+			if (a.status) a.status[b] = 1;
+			if (a.crc) a.crc[b] = crc;
+		}
+		return;
+	}
+	const uint32_t sizefield = a.frame == HD_FRAME_BGZF ? total - 1 : stored;
+	const uint32_t nblk = n == 0 ? 1u : (n + 65534u) / 65535u;
+	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
+	for (uint32_t j = lane; j < (total + 3) / 4; j += 64) {
+		uint32_t w = 0;
+		for (uint32_t k = 0; k < 4; k++) {
+			uint32_t o = 4 * j + k, v = 0;
+			if (o < hdr) {
+				v = frame_hdr_byte(a.frame, o, sizefield);
+			} else if (o < hdr + stored) {
+				uint32_t q = (o - hdr) / 65540u, r = (o - hdr) - q * 65540u;
+				uint32_t left = n - q * 65535u;
+				uint32_t bl = left < 65535u ? left : 65535u;
+				if (r == 0) v = (q + 1 == nblk) ? 1u : 0u;
+				else if (r == 1) v = bl & 0xff;
+				else if (r == 2) v = bl >> 8;
+				else if (r == 3) v = ~bl & 0xff;
+				else if (r == 4) v = (~bl >> 8) & 0xff;
+				else v = src[q * 65535u + r - 5];
+			} else if (o < total) {
+				uint32_t t = o - hdr - stored;
+				v = ((t < 4 ? crc : n) >> (8 * (t & 3))) & 0xff;
+			}
+			w |= v << (8 * k);
+		}
+		dst32[j] = w;
+	}
+	if (lane == 0) {
+		a.out_len[b] = total;
+		if (a.status) a.status[b] = 0;
+		if (a.crc) a.crc[b] = crc;
+	}
+}
+
+// load the 16 bytes of slot (piece, lane); zero beyond n
+__device__ __forceinline__ uint4 load_slot(const uint8_t *src, uint32_t n, uint32_t piece, uint32_t lane, bool aligned)
+{
+	const uint32_t o = piece * HD_PIECE + lane * 16;
+	if (aligned && o + 16 <= n)
+		return *(const uint4 *)(src + o);
+	// ragged tail or unaligned source: byte loads, zero beyond n (static indices
+	// only -- a runtime-indexed array would live in scratch)
+	uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+	if (o < n) {
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++) {
+			w0 |= (o + k < n ? (uint32_t)src[o + k] : 0u) << (8 * k);
+			w1 |= (o + 4 + k < n ? (uint32_t)src[o + 4 + k] : 0u) << (8 * k);
+			w2 |= (o + 8 + k < n ? (uint32_t)src[o + 8 + k] : 0u) << (8 * k);
+			w3 |= (o + 12 + k < n ? (uint32_t)src[o + 12 + k] : 0u) << (8 * k);
+		}
+	}
+	return make_uint4(w0, w1, w2, w3);
+}
+
+template <int WIN_BITS, int HASH_BITS>
+__global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
+{
+	constexpr uint32_t W = 1u << WIN_BITS;
+	constexpr uint32_t W4M = W / 4 - 1;
+	constexpr uint32_t HS = 1u << HASH_BITS;
+	constexpr uint32_t STG = 128;
+
+	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4];
+	__shared__ __attribute__((aligned(16))) uint32_t table[HS];
+	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
+	const uint8_t *ring8 = (const uint8_t *)ring32;
+
+	const uint32_t lane = threadIdx.x;
+	const uint32_t b = blockIdx.x;
+	if (b >= a.nblocks)
+		return;
+	const uint8_t *src = a.in + a.in_off[b];
+	const uint32_t n = a.in_len[b];
+	const bool aligned = (((uintptr_t)src) & 15) == 0;
+	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
+	const CrcTables *ct = a.ct;
+
+	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+	uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+	if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
+		cap64 = 65536;
+	const uint32_t cap = (uint32_t)cap64;
+	const uint32_t stored = HD_STORED_SIZE(n);
+	// the static stream survives only while it stays strictly below the stored
+	// size and inside the slot (twin: deflate_static(), `limit`)
+	uint32_t limit = stored - 1;
+	bool use_static = a.level >= 1 && cap >= hdr + trl + 2;   // level 0: stored only
+	if (use_static && cap - hdr - trl < limit)
+		limit = cap - hdr - trl;
+
+	// ---- init LDS -------------------------------------------------------
+	for (uint32_t i = lane; i < HS / 4; i += 64)
+		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+	for (uint32_t i = lane; i < STG; i += 64)
+		stage[i] = 0;
+	if (lane < 4 && hdr)
+		stage[lane] = lane == 0 ? 0x04088b1fu : lane == 1 ? 0u
+			: lane == 2 ? (a.frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u)
+				    : (a.frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du);
+
+	CrcLanes crc;
+	crc.init(lane, n);
+	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
+	uint4 pre = load_slot(src, n, 0, lane, aligned);
+
+	uint32_t bitpos = 8 * hdr;           // absolute bit position in the slot
+	uint32_t flushed = 0;                // dwords already stored to HBM
+	const uint32_t paybase = 8 * hdr;
+
+	// emit one token per lane (nbits == 0: none) and flush completed dwords
+	auto emit = [&](uint32_t code, uint32_t nbits, uint32_t incl, uint32_t total) {
+		uint32_t bp = bitpos + incl - nbits;
+		if (nbits) {
+			uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
+			atomicOr(&stage[i], code << sh);
+			if (sh + nbits > 32)
+				atomicOr(&stage[(i + 1) & (STG - 1)], code >> (32 - sh));
+		}
+		bitpos += total;
+		uint32_t ndw = (bitpos >> 5) - flushed;
+		if (lane < ndw) {
+			uint32_t i = flushed + lane;
+			uint32_t v = stage[i & (STG - 1)];
+			stage[i & (STG - 1)] = 0;
+			dst32[i] = v;
+		}
+		flushed += ndw;
+	};
+
+	// BFINAL = 1, BTYPE = 01
+	{
+		emit(3u, lane == 0 ? 3u : 0u, 3u, 3u);
+	}
+
+	uint32_t S = 0;
+	while (S < n && use_static) {
+		// ---- refill the ring: one 1 KiB piece at a time ----------------
+		while (filled < n && filled < S + HD_LOOKAHEAD) {
+			const uint32_t piece = filled / HD_PIECE;
+			uint4 v = pre;
+			filled += HD_PIECE;
+			if (filled < n)
+				pre = load_slot(src, n, piece + 1, lane, aligned);
+			((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
+			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+		}
+		const uint32_t lo = filled > W ? filled - W : 0;
+		const uint32_t lanes = n - S < 64 ? n - S : 64;
+
+		// ---- 1. look up, 2. publish, 3. verify -------------------------
+		const uint32_t p = S + lane;
+		const bool can = p + HD_MIN_MATCH <= n;
+		uint32_t w0 = ring32[(p >> 2) & W4M], w1 = ring32[((p >> 2) + 1) & W4M];
+		const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+		const uint32_t h = (v * HD_HASH_MUL) >> (32 - HASH_BITS);
+		uint32_t c = 0;
+		if (can) {
+			c = table[h];
+			atomicMax(&table[h], p + 1);
+		}
+		bool ok = false;
+		uint32_t dist = 0;
+		if (can && c != 0 && c - 1 >= lo) {
+			const uint32_t cp = c - 1;
+			uint32_t c0 = ring32[(cp >> 2) & W4M], c1 = ring32[((cp >> 2) + 1) & W4M];
+			ok = __builtin_amdgcn_alignbyte(c1, c0, cp & 3) == v;
+			dist = p - cp;
+		}
+		uint64_t rem = __ballot(ok);
+
+		// ---- 4. greedy resolution, cooperative extension ---------------
+		uint64_t cover = 0;
+		uint32_t mylen = 0, E = 0;
+		while (rem) {
+			const uint32_t m = (uint32_t)__ffsll((unsigned long long)rem) - 1;
+			const uint32_t dm = readlane(dist, m);
+			const uint32_t pm = S + m;
+			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+			uint32_t len = HD_MIN_MATCH;
+			for (;;) {
+				const uint32_t idx = len + lane;
+				bool diff = true;
+				if (idx < maxlen)
+					diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
+				const uint64_t nq = __ballot(diff);
+				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
+				len += k;
+				if (k < 64)
+					break;
+			}
+			if (lane == m)
+				mylen = len;
+			E = m + len;
+			const uint64_t upto = E >= 64 ? ~0ull : ((1ull << E) - 1);
+			cover |= upto & ~((1ull << m) - 1);
+			rem &= ~upto;
+		}
+		const bool is_match = mylen != 0;
+		const bool is_lit = lane < lanes && !((cover >> lane) & 1);
+
+		// ---- 5. codes ---------------------------------------------------
+		uint32_t code = 0, nbits = 0;
+		if (is_match) {
+			uint32_t ls, leb, lev, ds, deb, dev;
+			len_slot(mylen, ls, leb, lev);
+			off_slot(dist, ds, deb, dev);
+			// litlen symbols 257..279: 7 bits (sym-256); 280..287: 8 bits 0xC0+(sym-280)
+			uint32_t lc, ln;
+			if (ls < 23) { lc = __brev(ls + 1) >> 25; ln = 7; }
+			else         { lc = __brev(0xC0 + (ls - 23)) >> 24; ln = 8; }
+			code = lc | (lev << ln);
+			nbits = ln + leb;
+			code |= (__brev(ds) >> 27) << nbits;
+			nbits += 5;
+			code |= dev << nbits;
+			nbits += deb;
+		} else if (is_lit) {
+			const uint32_t byte = v & 0xff;
+			if (byte < 144) { code = __brev(0x30 + byte) >> 24; nbits = 8; }
+			else            { code = __brev(0x190 + (byte - 144)) >> 23; nbits = 9; }
+		}
+		const uint32_t incl = wave_incl_scan(nbits);
+		const uint32_t total = readlane(incl, 63);
+		if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit) {
+			use_static = false;
+			break;
+		}
+		emit(code, nbits, incl, total);
+		S += E > lanes ? E : lanes;
+	}
+
+	// the CRC needs every piece, also when the static stream was abandoned
+	while (filled < n) {
+		const uint32_t piece = filled / HD_PIECE;
+		uint4 v = pre;
+		filled += HD_PIECE;
+		if (filled < n)
+			pre = load_slot(src, n, piece + 1, lane, aligned);
+		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+	}
+	const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
+
+	if (use_static && (uint64_t)(bitpos - paybase) + 7 > 8ull * limit)
+		use_static = false;
+	if (!use_static) {
+		write_stored_member(a, b, src, n, crcv, lane);
+		return;
+	}
+
+	// end-of-block (7 zero bits), pad to a byte, then CRC32 + ISIZE as 4 x 16 bits
+	bitpos += 7;
+	bitpos = (bitpos + 7) & ~7u;
+	const uint32_t paylen = (bitpos - paybase) >> 3;
+	if (trl) {
+		uint32_t code = 0, nb = 0;
+		if (lane < 4) {
+			code = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
+			nb = 16;
+		}
+		const uint32_t incl = wave_incl_scan(nb);
+		emit(code, nb, incl, 64);
+	}
+	// final flush: the last partial dword
+	{
+		const uint32_t ndw = ((bitpos + 31) >> 5) - flushed;
+		if (lane < ndw)
+			dst32[flushed + lane] = stage[(flushed + lane) & (STG - 1)];
+	}
+	if (lane == 0) {
+		const uint32_t total = hdr + paylen + trl;
+		if (a.frame == HD_FRAME_BGZF)
+			*(uint16_t *)((uint8_t *)dst32 + 16) = (uint16_t)(total - 1);
+		else if (a.frame == HD_FRAME_MIGZ)
+			dst32[4] = paylen;
+		a.out_len[b] = total;
+		if (a.status) a.status[b] = 0;
+		if (a.crc) a.crc[b] = crcv;
+	}
+}
+
+} // namespace hd

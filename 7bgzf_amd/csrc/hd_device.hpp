@@ -1,0 +1,150 @@
+// hd_device.hpp -- wave64 primitives shared by the gfx950 kernels.
+//
+// Everything here assumes ONE wavefront of 64 lanes per block of work
+// (north_star: "one wavefront per block").  No 32-wide idiom anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hipdeflate_params.h"
+
+namespace hd {
+
+// CRC-32 folding tables, built once on the host (hd_api.hip) and kept in HBM;
+// 8.25 KiB, L1/L2 resident on every CU.
+//   T[k][v] : slicing-by-4 tables of the reflected IEEE polynomial
+//   B[k][v] : "append 1008 zero bytes" to the state byte v << 8k
+//   K[q]    : x^(128 q) mod P, q = 0..63, for the final per-lane alignment
+struct CrcTables {
+	uint32_t T[4][256];
+	uint32_t B[4][256];
+	uint32_t K[64];
+};
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{
+	// lanes whose DPP source is masked off or out of the row read 0
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// inclusive prefix sum over the 64 lanes: 7 DPP adds, no LDS
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
+{
+	uint32_t v = x;
+	v += dpp0<0x111, 0xf, 0xf>(x);   // row_shr:1
+	v += dpp0<0x112, 0xf, 0xf>(x);   // row_shr:2
+	v += dpp0<0x113, 0xf, 0xf>(x);   // row_shr:3
+	v += dpp0<0x114, 0xf, 0xe>(v);   // row_shr:4, banks 1-3
+	v += dpp0<0x118, 0xf, 0xc>(v);   // row_shr:8, banks 2-3
+	v += dpp0<0x142, 0xa, 0xf>(v);   // row_bcast:15 -> rows 1,3
+	v += dpp0<0x143, 0xc, 0xf>(v);   // row_bcast:31 -> rows 2,3
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_xor_reduce(uint32_t v)
+{
+	for (int o = 32; o > 0; o >>= 1)
+		v ^= (uint32_t)__shfl_xor((int)v, o, 64);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l)
+{
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// ---- CRC-32 ---------------------------------------------------------------
+__device__ __forceinline__ uint32_t crc_step4(const CrcTables *ct, uint32_t s, uint32_t d)
+{
+	s ^= d;
+	return ct->T[3][s & 0xff] ^ ct->T[2][(s >> 8) & 0xff] ^ ct->T[1][(s >> 16) & 0xff] ^ ct->T[0][s >> 24];
+}
+
+__device__ __forceinline__ uint32_t crc_skip1008(const CrcTables *ct, uint32_t s)
+{
+	return ct->B[0][s & 0xff] ^ ct->B[1][(s >> 8) & 0xff] ^ ct->B[2][(s >> 16) & 0xff] ^ ct->B[3][s >> 24];
+}
+
+__device__ __forceinline__ uint32_t crc_byte(const CrcTables *ct, uint32_t s, uint32_t b)
+{
+	return ct->T[0][(s ^ b) & 0xff] ^ (s >> 8);
+}
+
+// a(x) * b(x) mod P, reflected representation (bit 31 = x^0)
+__device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+	uint32_t p = 0;
+#pragma unroll 4
+	for (int i = 0; i < 32; i++) {
+		p ^= b & (0u - ((a >> (31 - i)) & 1u));
+		b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+	}
+	return p;
+}
+
+// Per-lane strided CRC accumulator.  The input is consumed in 1 KiB pieces;
+// lane l owns the 16-byte slot j = 64 k + l of piece k.  fold() is called once
+// per piece with that slot's bytes, finish() aligns and combines the 64 lanes.
+struct CrcLanes {
+	uint32_t s;
+	__device__ __forceinline__ void init(uint32_t lane, uint32_t n)
+	{
+		s = (lane == 0 && n >= 16) ? 0xffffffffu : 0u;
+	}
+	__device__ __forceinline__ void fold(const CrcTables *ct, uint32_t piece, bool full, uint4 v)
+	{
+		if (full) {
+			uint32_t t = piece ? crc_skip1008(ct, s) : s;
+			t = crc_step4(ct, t, v.x);
+			t = crc_step4(ct, t, v.y);
+			t = crc_step4(ct, t, v.z);
+			s = crc_step4(ct, t, v.w);
+		}
+	}
+	// tail = the < 16 bytes after the last full slot
+	__device__ __forceinline__ uint32_t finish(const CrcTables *ct, uint32_t lane, uint32_t n,
+						    const uint8_t *tail)
+	{
+		uint32_t n16 = n >> 4;
+		uint32_t acc = 0;
+		if (lane < n16) {
+			uint32_t jl = lane + 64u * ((n16 - 1 - lane) >> 6);
+			acc = gf_mul(ct->K[n16 - 1 - jl], s);
+		}
+		acc = wave_xor_reduce(acc);
+		if (n16 == 0)
+			acc = 0xffffffffu;
+		for (uint32_t i = n16 << 4; i < n; i++)
+			acc = crc_byte(ct, acc, tail[i - (n16 << 4)]);
+		return ~acc;
+	}
+};
+
+// ---- RFC 1951 3.2.5 slot arithmetic ----------------------------------------
+// length 3..258 -> symbol - 257, extra bit count, extra value
+__device__ __forceinline__ void len_slot(uint32_t len, uint32_t &sym, uint32_t &eb, uint32_t &ev)
+{
+	uint32_t l = len - 3;
+	uint32_t e = (l < 8) ? 0 : (29 - __clz(l));          // ilog2(l) - 2
+	sym = (l < 8) ? l : (4 + 4 * e + ((l >> e) & 3));
+	eb = e;
+	ev = l & ((1u << e) - 1);
+	if (l == 255) { sym = 28; eb = 0; ev = 0; }
+}
+
+// offset 1..32768 -> symbol, extra bit count, extra value
+__device__ __forceinline__ void off_slot(uint32_t off, uint32_t &sym, uint32_t &eb, uint32_t &ev)
+{
+	uint32_t d = off - 1;
+	uint32_t e = (d < 4) ? 0 : (30 - __clz(d));          // ilog2(d) - 1
+	sym = (d < 4) ? d : (2 * e + 2 + ((d >> e) & 1));
+	eb = e;
+	ev = d & ((1u << e) - 1);
+}
+
+} // namespace hd

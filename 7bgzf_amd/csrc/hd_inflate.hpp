@@ -1,0 +1,505 @@
+// hd_inflate.hpp -- raw-DEFLATE decoder, one wavefront per stream
+// (BASELINE config 3: BGZF decode, bit-exact vs the reference).
+//
+// Replaces, for the hip backend, libdeflate_inflate (lib/zlibutil.c:194-204) ->
+// libdeflate_deflate_decompress (lib/libdeflate/decompress_template.h:44-772,
+// table build lib/libdeflate/deflate_decompress.c:722-1004), i.e. what
+// zlibutil_auto_inflate does per block in applet/7bgzf.c:330.  Accept/reject
+// behaviour and result codes follow libdeflate (oracle/hd_inflate.c lists the
+// rules with their file:line); the structure does not:
+//
+//   * the compressed stream is pulled in 256-byte coalesced pieces (one dword
+//     per lane); the bit buffer lives in SGPRs and is refilled with v_readlane,
+//     so the symbol loop never waits on memory;
+//   * Huffman tables are built by all 64 lanes (ballot ranks per code length)
+//     into LDS: 2^10-entry litlen and 2^8-entry offset tables; longer codewords
+//     take a canonical bit-serial slow path instead of subtables;
+//   * output goes through an LDS ring; finished 1 KiB pieces leave as 16 B per
+//     lane stores; a match copy is 64 bytes per step across the lanes, from the
+//     ring when the source is near, from HBM (already flushed) when it is far.
+#pragma once
+#include "hd_device.hpp"
+
+namespace hd {
+
+struct InflateArgs {
+	const uint8_t *in;
+	const uint64_t *in_off;
+	const uint32_t *in_len;
+	uint32_t nblocks;
+	uint8_t *out;
+	const uint64_t *out_off;
+	const uint32_t *out_cap;
+	uint32_t *out_len;
+	uint32_t *crc;
+	int32_t *status;
+	const CrcTables *ct;
+};
+
+constexpr uint32_t INF_LT_BITS = 10;     // litlen direct table
+constexpr uint32_t INF_DT_BITS = 8;      // offset direct table
+constexpr uint32_t INF_RING    = 8192;   // LDS output ring
+constexpr uint32_t INF_NEAR    = INF_RING - 258 - 64; // dist <= this: source is in the ring
+
+// table entry: [31:16] value (literal / length base / offset base)
+//              [9:8] kind  [7:4] extra-bit count  [3:0] codeword length
+constexpr uint32_t K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SLOW = 3;
+
+// order in which the precode lengths are stored (RFC 1951 3.2.7;
+// decompress_template.h:91-93)
+__constant__ uint8_t k_precode_perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+__device__ __forceinline__ uint32_t litlen_entry(uint32_t sym, uint32_t len)
+{
+	if (sym < 256)
+		return (sym << 16) | (K_LIT << 8) | len;
+	if (sym == 256)
+		return (K_EOB << 8) | len;
+	// lengths: deflate_decompress.c:563-577 (286, 287 decode as 258)
+	uint32_t s = sym - 257, base, eb;
+	if (s < 8) { base = 3 + s; eb = 0; }
+	else if (s >= 28) { base = 258; eb = 0; }
+	else { eb = (s >> 2) - 1; base = 3 + ((4 + (s & 3)) << eb); }
+	return (base << 16) | (K_LEN << 8) | (eb << 4) | len;
+}
+
+__device__ __forceinline__ uint32_t offset_entry(uint32_t sym, uint32_t len)
+{
+	// deflate_decompress.c:612-627 (30, 31 decode as 24577 + 13 bits)
+	uint32_t base, eb;
+	if (sym < 4) { base = 1 + sym; eb = 0; }
+	else if (sym >= 30) { base = 24577; eb = 13; }
+	else { eb = (sym >> 1) - 1; base = 1 + ((2 + (sym & 1)) << eb); }
+	return (base << 16) | (eb << 4) | len;
+}
+
+struct InfLds {
+	uint32_t lit[1u << INF_LT_BITS];
+	uint32_t off[1u << INF_DT_BITS];
+	uint32_t pre[128];
+	uint16_t lit_sorted[288];
+	uint16_t off_sorted[32];
+	uint16_t lit_count[16], off_count[16];
+	uint8_t pre_lens[32];
+	uint8_t cl[288 + 32 + 138 + 6];           // + worst-case RLE overrun (decompress_template.h:171)
+	__attribute__((aligned(16))) uint8_t ring[INF_RING];
+};
+
+// Build one decode table from code lengths (all 64 lanes).  Returns false for
+// what build_decode_table() rejects (deflate_decompress.c:799-853).
+//   nsyms <= 288; tbits = direct table bits; kind 0 litlen / 1 offset / 2 precode
+template <int KIND>
+__device__ __forceinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
+					      uint16_t *sorted, uint16_t *count_out, uint32_t lane)
+{
+	// per-length counts and canonical first codes (uniform)
+	uint32_t count[16], first[16], offs[16];
+#pragma unroll
+	for (int l = 0; l < 16; l++)
+		count[l] = 0;
+	for (uint32_t base = 0; base < nsyms; base += 64) {
+		const uint32_t s = base + lane;
+		const uint32_t len = s < nsyms ? lens[s] : 0;
+#pragma unroll
+		for (int l = 1; l < 16; l++)
+			count[l] += __popcll(__ballot(len == (uint32_t)l));
+	}
+	uint32_t used = 0, code = 0, o = 0, maxlen = 0;
+#pragma unroll
+	for (int l = 1; l < 16; l++) {
+		code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
+		first[l] = code;
+		offs[l] = o;
+		o += count[l];
+		used += count[l] << (15 - l);
+		if (count[l])
+			maxlen = l;
+	}
+	if (count_out) {
+		uint32_t mine = 0;
+#pragma unroll
+		for (int l = 1; l < 16; l++)
+			mine = lane == (uint32_t)l ? count[l] : mine;
+		if (lane < 16)
+			count_out[lane] = (uint16_t)mine;
+	}
+	if (used > (1u << 15))
+		return false;                     // overfull
+	bool degenerate = false;
+	if (used < (1u << 15)) {                  // incomplete
+		if (used != 0 && !(count[1] == 1 && maxlen == 1))
+			return false;
+		degenerate = true;
+	}
+	// rank of every symbol inside its length class, in symbol order
+	uint32_t run[16];
+#pragma unroll
+	for (int l = 0; l < 16; l++)
+		run[l] = 0;
+	uint32_t one_sym = 0;                 // the symbol owning the single 1-bit codeword, if any
+	for (uint32_t base = 0; base < nsyms; base += 64) {
+		const uint32_t s = base + lane;
+		const uint32_t len = s < nsyms ? lens[s] : 0;
+		uint32_t rank = 0, fc = 0, of = 0;
+#pragma unroll
+		for (int l = 1; l < 16; l++) {
+			const uint64_t m = __ballot(len == (uint32_t)l);
+			if (len == (uint32_t)l) {
+				rank = run[l] + __popcll(m & ((1ull << lane) - 1));
+				fc = first[l];
+				of = offs[l];
+			}
+			if (l == 1 && m)
+				one_sym = base + (uint32_t)__ffsll((unsigned long long)m) - 1;
+			run[l] += __popcll(m);
+		}
+		if (len) {
+			sorted[of + rank] = (uint16_t)s;
+			const uint32_t cw = fc + rank;              // MSB-first codeword
+			const uint32_t rev = __brev(cw) >> (32 - len);
+			if (!degenerate) {
+				if (len <= tbits) {
+					const uint32_t e = KIND == 0 ? litlen_entry(s, len)
+							 : KIND == 1 ? offset_entry(s, len)
+								     : ((s << 16) | len);
+					for (uint32_t i = rev; i < (1u << tbits); i += 1u << len)
+						table[i] = e;
+				} else {
+					table[rev & ((1u << tbits) - 1)] = K_SLOW << 8;
+				}
+			}
+		}
+	}
+	if (degenerate) {
+		// empty code -> symbol 0; single 1-bit codeword -> that symbol, for both
+		// bit values (deflate_decompress.c:816-849)
+		const uint32_t sym = used ? one_sym : 0;
+		const uint32_t e = KIND == 0 ? litlen_entry(sym, 1) : KIND == 1 ? offset_entry(sym, 1) : ((sym << 16) | 1);
+		for (uint32_t i = lane; i < (1u << tbits); i += 64)
+			table[i] = e;
+	}
+	return true;
+}
+
+// bit-serial canonical decode for codewords longer than the direct table
+__device__ __forceinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted,
+						 uint32_t &len_out)
+{
+	uint32_t code = 0, first = 0, index = 0;
+	for (uint32_t l = 1; l <= 15; l++) {
+		code |= (uint32_t)(bb >> (l - 1)) & 1;
+		const uint32_t cnt = uniform(count[l]);
+		if (code - first < cnt) {
+			len_out = l;
+			return uniform(sorted[index + (code - first)]);
+		}
+		index += cnt;
+		first = (first + cnt) << 1;
+		code <<= 1;
+	}
+	len_out = 15;
+	return 0;
+}
+
+__global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
+{
+	__shared__ InfLds L;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t b = blockIdx.x;
+	if (b >= a.nblocks)
+		return;
+	const uint8_t *src = a.in + a.in_off[b];
+	const uint32_t n = a.in_len[b];
+	uint8_t *dst = a.out + a.out_off[b];
+	const uint32_t cap = a.out_cap[b];
+	const CrcTables *ct = a.ct;
+	const bool want_crc = a.crc != nullptr;
+	const bool dst_aligned = (((uintptr_t)dst) & 15) == 0;
+
+	// ---- compressed input: 256-byte pieces, one dword per lane -----------
+	const uint32_t mis = (uint32_t)((uintptr_t)src & 3);
+	const uint32_t *src32 = (const uint32_t *)(src - mis);
+	const uint32_t nbytes_al = mis + n;                  // valid bytes from src32
+	auto load_piece = [&](uint32_t piece) -> uint32_t {
+		const uint32_t d = piece * 64 + lane;
+		uint32_t w = 0;
+		if (d * 4 < nbytes_al) {
+			w = src32[d];
+			const uint32_t valid = nbytes_al - d * 4;    // bytes of this dword inside the stream
+			if (valid < 4)
+				w &= (1u << (8 * valid)) - 1;
+		}
+		return w;
+	};
+	uint32_t cur_piece = 0;
+	uint32_t cw = load_piece(0), cw_next = load_piece(1);
+	uint32_t dw = 0;                 // next dword index to feed the bit buffer
+	uint64_t bb = 0;                 // bit buffer (uniform)
+	uint32_t bc = 0;                 // valid bits in bb
+
+	auto next_dword = [&]() -> uint32_t {
+		const uint32_t piece = dw >> 6;
+		if (piece != cur_piece) {        // uniform branch: step to the next piece
+			cw = cw_next;
+			cur_piece = piece;
+			cw_next = load_piece(piece + 1);
+		}
+		const uint32_t w = readlane(cw, dw & 63);
+		dw++;
+		return w;
+	};
+	auto refill = [&]() {
+		if (bc <= 32) {
+			bb |= (uint64_t)next_dword() << bc;
+			bc += 32;
+		}
+	};
+	auto consumed_bits = [&]() -> int64_t { return (int64_t)dw * 32 - bc - 8 * (int64_t)mis; };
+	auto seek_byte = [&](uint32_t byteoff) {       // restart the bit reader at src + byteoff
+		const uint32_t o = mis + byteoff;
+		dw = o >> 2;
+		const uint32_t piece = dw >> 6;
+		if (piece != cur_piece) {
+			cur_piece = piece;
+			cw = load_piece(piece);
+			cw_next = load_piece(piece + 1);
+		}
+		bb = 0;
+		bc = 0;
+		refill();
+		bb >>= 8 * (o & 3);
+		bc -= 8 * (o & 3);
+	};
+	// skip the mis-alignment bytes
+	refill();
+	bb >>= 8 * mis;
+	bc -= 8 * mis;
+
+	// ---- output ring + flush ---------------------------------------------
+	uint32_t pos = 0, flushed = 0;
+	CrcLanes crc;
+	crc.init(lane, 0xffffffffu);          // length unknown yet; lane 0 seeds, fixed in finish
+	auto flush_pieces = [&]() {
+		while (pos - flushed >= HD_PIECE) {
+			const uint4 v = *(const uint4 *)&L.ring[(flushed & (INF_RING - 1)) + 16 * lane];
+			if (dst_aligned) {
+				*(uint4 *)(dst + flushed + 16 * lane) = v;
+			} else {
+				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+				for (uint32_t k = 0; k < 16; k++)
+					dst[flushed + 16 * lane + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+			}
+			if (want_crc)
+				crc.fold(ct, flushed / HD_PIECE, true, v);
+			flushed += HD_PIECE;
+		}
+	};
+
+	int32_t st = HD_OK;
+	bool static_loaded = false;
+
+	for (;;) {
+		refill();
+		const uint32_t bfinal = (uint32_t)bb & 1;
+		const uint32_t btype = ((uint32_t)bb >> 1) & 3;
+		bb >>= 3;
+		bc -= 3;
+
+		if (btype == 0) {
+			// ---- stored: decompress_template.h:234-279 -------------------
+			int64_t cbits = (consumed_bits() + 7) & ~(int64_t)7;
+			if (cbits > 8 * (int64_t)n) { st = HD_BAD_DATA; break; }
+			uint32_t ip = (uint32_t)(cbits >> 3);
+			if (n - ip < 4) { st = HD_BAD_DATA; break; }
+			seek_byte(ip);
+			refill();
+			const uint32_t len = (uint32_t)bb & 0xffff, nlen = ((uint32_t)bb >> 16) & 0xffff;
+			ip += 4;
+			if (len != (~nlen & 0xffff)) { st = HD_BAD_DATA; break; }
+			if (len > cap - pos) { st = HD_INSUFFICIENT_SPACE; break; }
+			if (len > n - ip) { st = HD_BAD_DATA; break; }
+			for (uint32_t done = 0; done < len;) {
+				const uint32_t step = len - done < 64 ? len - done : 64;
+				if (lane < step)
+					L.ring[(pos + lane) & (INF_RING - 1)] = src[ip + done + lane];
+				pos += step;
+				done += step;
+				if (pos - flushed >= HD_PIECE)
+					flush_pieces();
+			}
+			seek_byte(ip + len);
+		} else if (btype == 3) {
+			st = HD_BAD_DATA;
+			break;
+		} else {
+			uint32_t nlit = 288, noff = 32;
+			if (btype == 2) {
+				// ---- dynamic header: decompress_template.h:101-232 -------
+				refill();
+				nlit = 257 + ((uint32_t)bb & 31);
+				noff = 1 + (((uint32_t)bb >> 5) & 31);
+				const uint32_t npre = 4 + (((uint32_t)bb >> 10) & 15);
+				bb >>= 14;
+				bc -= 14;
+				if (lane < 19)
+					L.pre_lens[lane] = 0;
+				for (uint32_t i = 0; i < npre; i++) {
+					refill();
+					if (lane == 0)
+						L.pre_lens[k_precode_perm[i]] = (uint8_t)((uint32_t)bb & 7);
+					bb >>= 3;
+					bc -= 3;
+				}
+				if (!build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, lane)) { st = HD_BAD_DATA; break; }
+				uint8_t *cl = L.cl;
+				uint32_t i = 0, prev = 0;
+				bool bad = false;
+				while (i < nlit + noff) {
+					refill();
+					if (consumed_bits() > 8 * (int64_t)n + 64) { bad = true; break; }
+					const uint32_t e = uniform(L.pre[(uint32_t)bb & 127]);
+					const uint32_t cl_len = e & 15, s = e >> 16;
+					bb >>= cl_len;
+					bc -= cl_len;
+					if (s < 16) {
+						if (lane == 0)
+							cl[i] = (uint8_t)s;
+						prev = s;
+						i++;
+						continue;
+					}
+					uint32_t rep, val = 0;
+					if (s == 16) {
+						if (i == 0) { bad = true; break; }
+						rep = 3 + ((uint32_t)bb & 3);
+						bb >>= 2; bc -= 2;
+						val = prev;
+					} else if (s == 17) {
+						rep = 3 + ((uint32_t)bb & 7);
+						bb >>= 3; bc -= 3;
+						prev = 0;
+					} else {
+						rep = 11 + ((uint32_t)bb & 127);
+						bb >>= 7; bc -= 7;
+						prev = 0;
+					}
+					for (uint32_t k = lane; k < rep; k += 64)
+						cl[i + k] = (uint8_t)val;
+					i += rep;
+				}
+				if (bad || i != nlit + noff) { st = HD_BAD_DATA; break; }
+				static_loaded = false;
+				if (!build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, lane) ||
+				    !build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, lane)) {
+					st = HD_BAD_DATA;
+					break;
+				}
+			} else if (!static_loaded) {
+				// ---- static code: decompress_template.h:297-330 ----------
+				uint8_t *cl = L.cl;
+				for (uint32_t s = lane; s < 320; s += 64)
+					cl[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+				build_table<1>(cl + 288, 32, L.off, INF_DT_BITS, L.off_sorted, L.off_count, lane);
+				build_table<0>(cl, 288, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, lane);
+				static_loaded = true;
+			}
+
+			// ---- symbol loop ----------------------------------------------
+			for (;;) {
+				refill();
+				if (consumed_bits() > 8 * (int64_t)n + 64) { st = HD_BAD_DATA; break; }
+				uint32_t e = uniform(L.lit[(uint32_t)bb & ((1u << INF_LT_BITS) - 1)]);
+				if (((e >> 8) & 3) == K_SLOW) {
+					uint32_t l;
+					const uint32_t s = slow_decode(bb, L.lit_count, L.lit_sorted, l);
+					e = litlen_entry(s, l);
+				}
+				const uint32_t clen = e & 15;
+				bb >>= clen;
+				bc -= clen;
+				const uint32_t kind = (e >> 8) & 3;
+				if (kind == K_LIT) {
+					if (pos == cap) { st = HD_INSUFFICIENT_SPACE; break; }
+					if (lane == 0)
+						L.ring[pos & (INF_RING - 1)] = (uint8_t)(e >> 16);
+					pos++;
+					if (pos - flushed >= HD_PIECE)
+						flush_pieces();
+					continue;
+				}
+				if (kind == K_EOB)
+					break;
+				const uint32_t eb = (e >> 4) & 15;
+				const uint32_t length = (e >> 16) + ((uint32_t)bb & ((1u << eb) - 1));
+				bb >>= eb;
+				bc -= eb;
+				if (length > cap - pos) { st = HD_INSUFFICIENT_SPACE; break; }
+				refill();
+				uint32_t d = uniform(L.off[(uint32_t)bb & ((1u << INF_DT_BITS) - 1)]);
+				if (((d >> 8) & 3) == K_SLOW) {
+					uint32_t l;
+					const uint32_t s = slow_decode(bb, L.off_count, L.off_sorted, l);
+					d = offset_entry(s, l);
+				}
+				const uint32_t dlen = d & 15, deb = (d >> 4) & 15;
+				bb >>= dlen;
+				bc -= dlen;
+				const uint32_t offset = (d >> 16) + ((uint32_t)bb & ((1u << deb) - 1));
+				bb >>= deb;
+				bc -= deb;
+				if (offset > pos) { st = HD_BAD_DATA; break; }
+
+				// ---- match copy, 64 bytes per step ------------------------
+				if (offset <= INF_NEAR) {
+					for (uint32_t i = lane; i < length; i += 64) {
+						const uint32_t r = offset < length ? i % offset : i;
+						const uint8_t v = L.ring[(pos - offset + r) & (INF_RING - 1)];
+						L.ring[(pos + i) & (INF_RING - 1)] = v;
+					}
+				} else {
+					// source was flushed long ago: make our own stores visible
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					for (uint32_t i = lane; i < length; i += 64)
+						L.ring[(pos + i) & (INF_RING - 1)] = dst[pos - offset + i];
+				}
+				pos += length;
+				if (pos - flushed >= HD_PIECE)
+					flush_pieces();
+			}
+			if (st != HD_OK)
+				break;
+		}
+		if (bfinal)
+			break;
+		if (consumed_bits() > 8 * (int64_t)n + 64) { st = HD_BAD_DATA; break; }
+	}
+	if (st == HD_OK && consumed_bits() > 8 * (int64_t)n)
+		st = HD_BAD_DATA;
+
+	uint32_t crcv = 0;
+	if (st == HD_OK) {
+		// tail: bytes [flushed, pos) leave the ring byte-wise
+		for (uint32_t i = flushed + lane; i < pos; i += 64)
+			dst[i] = L.ring[i & (INF_RING - 1)];
+		if (want_crc) {
+			// full 16-byte slots of the tail piece, then the < 16 byte remainder
+			const uint32_t piece = flushed / HD_PIECE;
+			const uint32_t o = flushed + 16 * lane;
+			const bool full = o + 16 <= pos;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (full)
+				v = *(const uint4 *)&L.ring[o & (INF_RING - 1)];
+			if (pos < 16)
+				crc.s = 0;                       // no full slot at all: finish() reseeds
+			crc.fold(ct, piece, full, v);
+			crcv = crc.finish(ct, lane, pos, &L.ring[(pos & ~15u) & (INF_RING - 1)]);
+		}
+	}
+	if (lane == 0) {
+		a.out_len[b] = st == HD_OK ? pos : 0;
+		if (a.status) a.status[b] = st;
+		if (a.crc) a.crc[b] = crcv;
+	}
+}
+
+} // namespace hd

@@ -1,0 +1,138 @@
+// hd_selftest.hip -- device self-test of the wave primitives every kernel leans
+// on (DPP prefix scan, strided CRC folding, slot arithmetic).  Run by
+// hipdeflate_selftest(); tests/test_gpu_selftest.py calls it on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/hipdeflate.h"
+#include "hd_device.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(64) void k_selftest_scan(const uint32_t *x, uint32_t *incl)
+{
+	incl[blockIdx.x * 64 + threadIdx.x] = hd::wave_incl_scan(x[blockIdx.x * 64 + threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void k_selftest_slots(uint32_t *out)
+{
+	// out[len]   = packed (sym, eb, ev) for len 3..258; out[512 + i] for a sweep of offsets
+	for (uint32_t len = 3 + threadIdx.x; len <= 258; len += 64) {
+		uint32_t s, eb, ev;
+		hd::len_slot(len, s, eb, ev);
+		out[len] = (s << 16) | (eb << 8) | ev;
+	}
+	for (uint32_t i = threadIdx.x; i < 32768; i += 64) {
+		uint32_t s, eb, ev;
+		hd::off_slot(i + 1, s, eb, ev);
+		out[512 + i] = (s << 24) | (eb << 16) | ev;
+	}
+}
+
+} // namespace
+
+extern "C" int hipdeflate_selftest(void)
+{
+	int r = hipdeflate_available();
+	if (r)
+		return r;
+	int fails = 0;
+	// ---- scan -------------------------------------------------------------
+	{
+		const int nb = 8;
+		uint32_t hx[nb * 64], hi[nb * 64];
+		uint32_t seed = 12345;
+		for (int i = 0; i < nb * 64; i++) {
+			seed = seed * 1664525u + 1013904223u;
+			hx[i] = i < 64 ? 31 : i < 128 ? (i & 1) : (seed >> 27);
+		}
+		uint32_t *dx, *di;
+		if (hipMalloc((void **)&dx, sizeof(hx)) != hipSuccess || hipMalloc((void **)&di, sizeof(hi)) != hipSuccess)
+			return HD_E_NOMEM;
+		(void)hipMemcpy(dx, hx, sizeof(hx), hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(k_selftest_scan, dim3(nb), dim3(64), 0, 0, dx, di);
+		(void)hipMemcpy(hi, di, sizeof(hi), hipMemcpyDeviceToHost);
+		for (int b = 0; b < nb; b++) {
+			uint32_t run = 0;
+			for (int l = 0; l < 64; l++) {
+				run += hx[b * 64 + l];
+				if (hi[b * 64 + l] != run) {
+					if (fails < 5)
+						fprintf(stderr, "hipdeflate selftest: scan[%d][%d] = %u, want %u\n", b, l,
+							hi[b * 64 + l], run);
+					fails++;
+				}
+			}
+		}
+		(void)hipFree(dx);
+		(void)hipFree(di);
+	}
+	// ---- slot arithmetic vs RFC 1951 3.2.5 tables ---------------------------
+	{
+		static const uint16_t lbase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
+						    67, 83, 99, 115, 131, 163, 195, 227, 258 };
+		static const uint8_t lext[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
+						  4, 4, 4, 4, 5, 5, 5, 5, 0 };
+		static const uint16_t obase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513,
+						    769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+		static const uint8_t oext[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8,
+						  9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+		const size_t n = 512 + 32768;
+		uint32_t *d, *h = (uint32_t *)malloc(n * 4);
+		if (hipMalloc((void **)&d, n * 4) != hipSuccess)
+			return HD_E_NOMEM;
+		hipLaunchKernelGGL(k_selftest_slots, dim3(1), dim3(64), 0, 0, d);
+		(void)hipMemcpy(h, d, n * 4, hipMemcpyDeviceToHost);
+		for (uint32_t len = 3; len <= 258; len++) {
+			uint32_t s = h[len] >> 16, eb = (h[len] >> 8) & 0xff, ev = h[len] & 0xff;
+			// 258 is symbol 285 (index 28), never 284 + extra 31
+			if (s > 28 || lext[s] != eb || lbase[s] + ev != len || ev >= (1u << eb) + (eb == 0) ||
+			    (len == 258 && s != 28))
+				fails++;
+		}
+		for (uint32_t i = 0; i < 32768; i++) {
+			uint32_t s = h[512 + i] >> 24, eb = (h[512 + i] >> 16) & 0xff, ev = h[512 + i] & 0xffff;
+			if (s > 29 || oext[s] != eb || obase[s] + ev != i + 1 || (eb && ev >= (1u << eb)))
+				fails++;
+		}
+		if (fails)
+			fprintf(stderr, "hipdeflate selftest: slot arithmetic failures so far: %d\n", fails);
+		free(h);
+		(void)hipFree(d);
+	}
+	// ---- CRC folding: through the public inflate/deflate entry points -------
+	{
+		// stored level-0 members of assorted sizes carry the kernel's CRC-32;
+		// compare with a bitwise CRC computed here
+		const uint32_t sizes[] = { 0, 1, 15, 16, 17, 1023, 1024, 1025, 4096 + 7, 65280, 65536, 70001 };
+		for (uint32_t n : sizes) {
+			uint8_t *src = (uint8_t *)malloc(n + 1), *dst = (uint8_t *)malloc(n + 1024);
+			uint32_t seed = n * 2654435761u + 1;
+			for (uint32_t i = 0; i < n; i++) {
+				seed = seed * 1664525u + 1013904223u;
+				src[i] = seed >> 24;
+			}
+			uint32_t c = 0xffffffffu;
+			for (uint32_t i = 0; i < n; i++) {
+				c ^= src[i];
+				for (int k = 0; k < 8; k++)
+					c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+			}
+			c = ~c;
+			uint64_t off = 0;
+			uint32_t len = n, olen = 0, crc = 0;
+			int32_t st = -1;
+			int rr = hipdeflate_batch_deflate(src, &off, &len, 1, 0, HD_FRAME_RAW, dst, (n + 1024) & ~15u, n + 1000,
+							  &olen, &crc, &st);
+			if (rr || st || crc != c) {
+				fprintf(stderr, "hipdeflate selftest: crc n=%u got %08x want %08x (rc %d st %d)\n", n, crc, c,
+					rr, st);
+				fails++;
+			}
+			free(src);
+			free(dst);
+		}
+	}
+	return fails ? 1 : 0;
+}

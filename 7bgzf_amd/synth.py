@@ -7,7 +7,8 @@ these generators.  They are deterministic functions of (seed, size).
   seeded random ACGT "genome" with 1 % substitutions, header
   ``@SRR000001.<i> <i>/1``, 150 quality symbols from a 26-character skewed
   alphabet.  libdeflate 1.23 level 1 compresses it to 0.274, level 6 to 0.259
-  (0xff00-byte blocks; measured with oracle/_ref/libref.so).
+  (0xff00-byte blocks; measured in the build container with the reference's own
+  libdeflate 1.23).
 * ``text_like``   -- config 5: Zipf-distributed words over a 50k vocabulary with
   wiki-ish markup (zlib-6 ratio ~0.33-0.36).
 * ``random_bytes`` -- config 1 stand-in for /dev/urandom (incompressible).

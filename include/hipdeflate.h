@@ -1,0 +1,149 @@
+/*
+ * hipdeflate.h -- C ABI of libhipdeflate.so: the MI355X (gfx950) block-parallel
+ * DEFLATE engine that sits behind 7bgzf's codec boundary as BGZF_METHOD=hip.
+ *
+ * Plain C: pointers and sizes only.  Every entry point names the reference
+ * interface it replaces or extends (paths relative to cielavenir/7bgzf):
+ *
+ *   hip_deflate / hip_inflate      = one more backend pair with the
+ *       zlibutil_code_enc / zlibutil_code_dec signatures, lib/zlibutil.h:46-47,
+ *       next to libdeflate_deflate / libdeflate_inflate (lib/zlibutil.h:101-114,
+ *       lib/zlibutil.c:179-204).  DEFLATE_HIP extends the enum at
+ *       lib/zlibutil.h:13-26.
+ *   bgzf_compress                  = the LD_PRELOAD hook, bgzf_compress.c:39,
+ *       with BGZF_METHOD=hip<level> added to its method table (:53-113).
+ *   hipdeflate_batch_*             = the batch-shaped form of the per-block
+ *       loop of applet/7bgzf.c:159-277 / applet/7migz.c:130-244 (encode) and
+ *       applet/7bgzf.c:306-360 (decode): thousands of independent blocks per
+ *       call instead of one pthread per block.  No reference counterpart
+ *       exists; INTEGRATION.md shows the loop rewritten on top of them.
+ *
+ * Return convention everywhere: 0 = success, non-zero = failure, as the
+ * reference's codecs (applet/7bgzf.c:228-254,350-353 only print the value).
+ * There is NO CPU fallback: without a usable gfx950 device every entry point
+ * fails (HD_E_NODEVICE) and says so on stderr.
+ */
+#ifndef HIPDEFLATE_H
+#define HIPDEFLATE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* value to add after DEFLATE_KZIP in lib/zlibutil.h:13-26 */
+#define DEFLATE_HIP 11
+
+/* library error codes (positive; never collide with the 0..3 inflate codes) */
+#define HD_E_NODEVICE  100   /* no HIP device / not gfx950 / runtime error     */
+#define HD_E_ARG       101   /* bad argument (alignment, sizes)                 */
+#define HD_E_NOMEM     102   /* device or pinned allocation failed              */
+
+/* container framing the encode kernel writes around each payload */
+#define HD_FRAME_RAW   0     /* raw DEFLATE only (what a zlibutil codec returns) */
+#define HD_FRAME_BGZF  1     /* applet/7bgzf.c:263-272: 18 B header, CRC32, ISIZE */
+#define HD_FRAME_MIGZ  2     /* applet/7migz.c:224-233: 20 B header, CRC32, ISIZE */
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Select the device (-1: HIPDEFLATE_DEVICE env, else LOCAL_RANK env, else 0) and
+ * create the context.  Idempotent; every other entry point calls it lazily. */
+int  hipdeflate_init(int device);
+void hipdeflate_shutdown(void);
+/* 0 if a usable device is present and the kernels loaded, else HD_E_NODEVICE */
+int  hipdeflate_available(void);
+/* human-readable build/device description, never NULL */
+const char *hipdeflate_version(void);
+
+/* ---- per-block codecs: drop-in zlibutil backends ------------------------ */
+
+/* zlibutil_code_enc (lib/zlibutil.h:47).  *destLen in = capacity, out = bytes.
+ * Output is raw DEFLATE ending in a BFINAL block.  level as
+ * include/hipdeflate_params.h.  Re-entrant and thread-safe. */
+int hip_deflate(unsigned char *dest, size_t *destLen,
+		const unsigned char *source, size_t sourceLen, int level);
+
+/* zlibutil_code_dec (lib/zlibutil.h:46).  Stops at BFINAL, ignores trailing
+ * source bytes (applet/7bgzf.c:328 passes payload + 8-byte trailer).  Returns
+ * enum libdeflate_result values 0/1/3 like libdeflate_inflate
+ * (lib/zlibutil.c:194-204). */
+int hip_inflate(unsigned char *dest, size_t *destLen,
+		const unsigned char *source, size_t sourceLen);
+
+/* ---- batch API, host buffers ------------------------------------------- */
+
+/* Compress nblocks independent blocks.  Block i is in[in_off[i] .. +in_len[i]).
+ * Its output (framed as `frame` says) is written to out + i*out_stride, at most
+ * min(out_stride, out_cap) bytes; out_len[i] = bytes written, crc32[i] = CRC-32
+ * of the block's INPUT (fcrc32, applet/7bgzf.c:269), status[i] = 0 or 1 (does
+ * not fit).  crc32/status may be NULL.  out_stride must be a multiple of 16.
+ * Returns 0 if the batch ran (look at status[] per block), else HD_E_*. */
+int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off,
+			     const uint32_t *in_len, uint32_t nblocks,
+			     int level, int frame,
+			     uint8_t *out, uint64_t out_stride, uint32_t out_cap,
+			     uint32_t *out_len, uint32_t *crc32, int32_t *status);
+
+/* Decompress nblocks independent raw-DEFLATE streams.  Stream i is
+ * in[in_off[i] .. +in_len[i]) (trailing bytes allowed), its output goes to
+ * out + out_off[i], capacity out_cap[i]; out_len[i] = bytes produced,
+ * crc32[i] = CRC-32 of the OUTPUT (may be NULL), status[i] = 0/1/3 as
+ * hip_inflate. */
+int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off,
+			     const uint32_t *in_len, uint32_t nblocks,
+			     uint8_t *out, const uint64_t *out_off,
+			     const uint32_t *out_cap,
+			     uint32_t *out_len, uint32_t *crc32, int32_t *status);
+
+/* ---- batch API, device-resident buffers --------------------------------- */
+/* Same contracts, every pointer is a DEVICE address (hipMalloc'd, or a torch
+ * CUDA tensor's data_ptr()); `stream` is a hipStream_t (NULL = default stream).
+ * Asynchronous: returns after enqueueing.  `in` and `out` bases must be
+ * 16-byte aligned; fastest when every in_off[i] is too (0xff00 and 0x10000 are). */
+int hipdeflate_batch_deflate_dev(const void *in, const void *in_off,
+				 const void *in_len, uint32_t nblocks,
+				 int level, int frame,
+				 void *out, uint64_t out_stride, uint32_t out_cap,
+				 void *out_len, void *crc32, void *status,
+				 void *stream);
+int hipdeflate_batch_inflate_dev(const void *in, const void *in_off,
+				 const void *in_len, uint32_t nblocks,
+				 void *out, const void *out_off, const void *out_cap,
+				 void *out_len, void *crc32, void *status,
+				 void *stream);
+
+/* Gather the variable-length members produced by batch_deflate_dev into one
+ * contiguous stream: member i (out_len[i] bytes at slots + i*stride) goes to
+ * dst + dst_off[i], where dst_off is the exclusive prefix sum of out_len (plus
+ * this rank's base when the stream is sharded across GPUs -- SURVEY.md 8(e)).
+ * dst_off is computed on the device by hipdeflate_scan_sizes_dev. */
+int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks,
+			      uint64_t base, void *dst_off, void *total,
+			      void *stream);
+int hipdeflate_compact_dev(const void *slots, uint64_t stride,
+			   const void *out_len, const void *dst_off,
+			   uint32_t nblocks, void *dst, void *stream);
+
+/* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level<=1);
+ * the library keeps its own grow-only scratch, this is informational */
+uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level);
+
+/* ---- LD_PRELOAD hook ----------------------------------------------------- */
+/* Same signature and return values as bgzf_compress.c:39: 0 ok; -1 if
+ * *dlen < 26 (28 for the EOF block) or no coder; 1 on codec error.  slen == 0
+ * yields the canned 28-byte EOF block.  BGZF_METHOD=hip<level> (default level
+ * 1) is the only method this library serves; any other BGZF_METHOD value makes
+ * the call fail with -1 ("coder missing"), it never falls back to a CPU codec.
+ * Calls from concurrent htslib worker threads are micro-batched into one
+ * launch (HIPDEFLATE_BATCH_US, default 200 us window). */
+int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
+
+/* device self-test of the wave primitives (scan, CRC folding); 0 = pass */
+int hipdeflate_selftest(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

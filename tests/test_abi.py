@@ -1,0 +1,126 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every
+symbol include/hipdeflate.h declares, and refuses to work without a GPU instead of
+silently falling back to a CPU codec."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import hdtest
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = hdtest.pkg()
+    if not os.path.exists(p.LIB_PATH):
+        subprocess.run(["make", "-s", "-C", os.path.join(hdtest.ROOT, "7bgzf_amd", "csrc")], check=True)
+    return p
+
+
+def declared_functions():
+    text = open(os.path.join(hdtest.ROOT, "include", "hipdeflate.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hip_\w+|hipdeflate_\w+|bgzf_compress)\s*\(", text)))
+
+
+def test_exports_match_header(pkg):
+    names = declared_functions()
+    assert len(names) >= 15
+    assert sorted(pkg.EXPORTS) == names
+    lib = pkg.lib()
+    for n in names:
+        assert getattr(lib, n) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if " T " in l)
+    for n in names:
+        assert n in exported, n
+
+
+def test_no_oracle_or_reference_in_product(pkg):
+    """The product must not link or embed the oracle / the reference."""
+    out = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED.*\[(.*)\]", out)          # direct dependencies only
+    assert needed and all(not n.startswith(("liboracle", "libref", "libdeflate", "libz.")) for n in needed), needed
+    src_dir = os.path.join(hdtest.ROOT, "7bgzf_amd")
+    for root, _, files in os.walk(src_dir):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".hpp")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "liboracle" not in text and "hd_oracle.h" not in text and "libref.so" not in text, f
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: covered by the gpu tests")
+def test_fails_loudly_without_gpu(pkg):
+    assert pkg.available() is False
+    r, z = pkg.hip_deflate(b"hello hello hello hello")
+    assert r == pkg.HD_E_NODEVICE and z == b""
+    r, z = pkg.hip_inflate(b"\x03\x00", 10)
+    assert r == pkg.HD_E_NODEVICE
+    with pytest.raises(pkg.HipDeflateError):
+        pkg.bgzf_compress_bytes(b"abc")
+
+
+def test_hook_constants_without_gpu(pkg):
+    """slen == 0 -> canned EOF member; too-small capacity -> -1 (bgzf_compress.c:40-51)."""
+    import json
+    b = json.load(open(os.path.join(hdtest.GOLDEN, "boundary.json")))
+    r, m = pkg.bgzf_compress_hook(b"", 0x10000)
+    assert r == b["hook_eof"]["ret"] == 0 and m.hex() == b["hook_eof"]["member"] and m == pkg.BGZF_EOF
+    r, _ = pkg.bgzf_compress_hook(b"", 27)
+    assert r == b["hook_eof_cap27"]["ret"] == -1
+
+
+def test_zlibutil_mirror_wrappers(pkg):
+    """hd_zlibutil_buffer_code with a CPU-side stand-in codec (the store_deflate layout
+    is irrelevant here: the wrappers only add bytes around whatever func returns) must
+    produce the reference's RFC1950 / RFC1952 bytes (lib/zlibutil.c:374-405)."""
+    import json
+    b = json.load(open(os.path.join(hdtest.GOLDEN, "boundary.json")))["zlibutil_buffer_code_store"]
+    lib = pkg.lib()
+
+    class ZB(ctypes.Structure):
+        _fields_ = [("dest", ctypes.c_void_p), ("destLen", ctypes.c_size_t), ("source", ctypes.c_void_p),
+                    ("sourceLen", ctypes.c_size_t), ("func", ctypes.c_void_p), ("encode", ctypes.c_int),
+                    ("level", ctypes.c_int), ("rfc1950", ctypes.c_int), ("rfc1952", ctypes.c_int),
+                    ("ret", ctypes.c_int)]
+
+    lib.hd_zlibutil_buffer_allocate.restype = ctypes.POINTER(ZB)
+    lib.hd_zlibutil_buffer_allocate.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    lib.hd_zlibutil_buffer_code.restype = ctypes.POINTER(ZB)
+    lib.hd_zlibutil_buffer_code.argtypes = [ctypes.POINTER(ZB)]
+    lib.hd_zlibutil_buffer_free.argtypes = [ctypes.POINTER(ZB)]
+    ENC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                           ctypes.c_size_t, ctypes.c_int)
+
+    def stored_codec(dest, dest_len, source, source_len, level):
+        data = ctypes.string_at(source, source_len)
+        n = len(data)
+        z = bytes([1, n & 0xff, n >> 8, ~n & 0xff, (~n >> 8) & 0xff]) + data
+        ctypes.memmove(dest, z, len(z))
+        dest_len[0] = len(z)
+        return 0
+
+    cb = ENC(stored_codec)
+    for mode in ("rfc1950", "rfc1952"):
+        data = b[mode]["input"].encode()
+        zb = lib.hd_zlibutil_buffer_allocate(200, len(data))
+        ctypes.memmove(zb.contents.source, data, len(data))
+        zb.contents.func = ctypes.cast(cb, ctypes.c_void_p)
+        zb.contents.encode = 1
+        setattr(zb.contents, mode, 1)
+        ret = lib.hd_zlibutil_buffer_code(zb)
+        assert ctypes.addressof(ret.contents) == ctypes.addressof(zb.contents)  # returns its argument
+        out = ctypes.string_at(zb.contents.dest, zb.contents.destLen)
+        if mode == "rfc1952":
+            out = out[:4] + b"\0\0\0\0" + out[8:]
+        assert zb.contents.ret == b[mode]["ret"] == 0 and out.hex() == b[mode]["bytes"], mode
+        lib.hd_zlibutil_buffer_free(zb)
+    # host checksums used by those wrappers
+    lib.hd_crc32.restype = ctypes.c_uint32
+    lib.hd_adler32.restype = ctypes.c_uint32
+    v = b"123456789" * 1000
+    assert lib.hd_crc32(0, v, len(v)) == hdtest.oracle_crc32(v)
+    a = hdtest.as_u8(v)
+    assert lib.hd_adler32(1, v, len(v)) == hdtest.oracle().hdo_adler32(1, a.ctypes.data, len(a))

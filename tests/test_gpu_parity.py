@@ -1,0 +1,324 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the
+C ABI of libhipdeflate.so; the oracle (oracle/*.c) and the committed golden vectors
+are the checkers.  /root/reference is NOT needed here.
+
+Bars: bit-exact everywhere (integer/byte work, no tolerance):
+  * encode: kernel bytes == CPU twin bytes; oracle-inflate(kernel bytes) == input;
+    container bytes == oracle framing; CRC32 == oracle CRC32
+  * decode: kernel output == golden SHA-256 for every reference-encoded stream;
+    accept/reject verdicts == libdeflate's on mutants and on the 151 malformed vectors
+"""
+import base64
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import hdtest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = hdtest.pkg()
+    assert os.path.exists(p.LIB_PATH), "libhipdeflate.so missing: run __graft_entry__.build()"
+    assert p.available(), "no usable MI355X: the HIP path must be the one that runs"
+    return p
+
+
+def load(name):
+    return json.load(open(os.path.join(hdtest.GOLDEN, name)))
+
+
+def test_selftest(pkg):
+    assert pkg.lib().hipdeflate_selftest() == 0
+    assert "gfx950" in pkg.version()
+
+
+# ---- encode ----------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("level", [0, 1, 3, 6, 9])
+def test_encode_matches_twin_small_corpus(pkg, level):
+    corpus = hdtest.corpus_small()
+    names = list(corpus)
+    blob = b"".join(corpus[k] + bytes(-len(corpus[k]) % 16) for k in names)
+    offs, lens, o = [], [], 0
+    for k in names:
+        offs.append(o)
+        lens.append(len(corpus[k]))
+        o += len(corpus[k]) + (-len(corpus[k]) % 16)
+    members, crc, st = pkg.batch_deflate(blob, offs, lens, level, pkg.FRAME_RAW)
+    for i, k in enumerate(names):
+        data = corpus[k]
+        assert st[i] == 0, k
+        r, twin = hdtest.oracle_twin(data, level)
+        assert r == 0 and members[i] == twin, (k, level, len(members[i]), len(twin))
+        assert zlib.decompress(members[i], -15) == data, k
+        r, back = hdtest.oracle_inflate(members[i], len(data))
+        assert r == 0 and back == data, k
+        assert int(crc[i]) == hdtest.oracle_crc32(data), k
+
+
+def test_encode_unaligned_offsets_and_ragged_lengths(pkg):
+    s = hdtest.synth()
+    data = bytes(s.fastq_like(300000, seed=3))
+    rng = np.random.default_rng(8)
+    offs, lens = [], []
+    o = 1
+    while o < len(data) - 70000 and len(offs) < 40:
+        ln = int(rng.integers(0, 66000))
+        offs.append(o)
+        lens.append(ln)
+        o += int(rng.integers(1, 9000))
+    members, crc, st = pkg.batch_deflate(data, offs, lens, 1, pkg.FRAME_RAW)
+    for i in range(len(offs)):
+        chunk = data[offs[i]:offs[i] + lens[i]]
+        r, twin = hdtest.oracle_twin(chunk, 1)
+        assert st[i] == 0 and members[i] == twin, (i, offs[i], lens[i])
+        assert int(crc[i]) == hdtest.oracle_crc32(chunk)
+
+
+@pytest.mark.parametrize("frame", ["bgzf", "migz"])
+def test_container_bytes_match_reference_framing(pkg, frame):
+    """Bytes outside the payload (header, BSIZE/compsize, CRC32, ISIZE) are the
+    reference's (applet/7bgzf.c:263-272, applet/7migz.c:224-233)."""
+    import ctypes
+    o = hdtest.oracle()
+    s = hdtest.synth()
+    fr = pkg.FRAME_BGZF if frame == "bgzf" else pkg.FRAME_MIGZ
+    inputs = [bytes(s.fastq_like(0xff00)), bytes(s.random_bytes(0xff00)), b"", b"x", bytes(s.text_like(12345))]
+    if frame == "migz":
+        inputs.append(bytes(s.text_like(300000)))
+    blob = b"".join(x + bytes(-len(x) % 16) for x in inputs)
+    offs, lens, p = [], [], 0
+    for x in inputs:
+        offs.append(p)
+        lens.append(len(x))
+        p += len(x) + (-len(x) % 16)
+    slot = 65536 if frame == "bgzf" else ((max(lens) + 200 + 15) & ~15)
+    members, crc, st = pkg.batch_deflate(blob, offs, lens, 1, fr, slot=slot)
+    hdr = 18 if frame == "bgzf" else 20
+    for i, x in enumerate(inputs):
+        assert st[i] == 0
+        m = members[i]
+        r, twin = hdtest.oracle_twin(x, 1, cap=slot - hdr - 8)
+        assert r == 0
+        want = np.zeros(len(twin) + 64, dtype=np.uint8)
+        tw = hdtest.as_u8(twin)
+        f = o.hdo_bgzf_frame if frame == "bgzf" else o.hdo_migz_frame
+        n = f(want.ctypes.data, len(want), tw.ctypes.data, len(tw), hdtest.oracle_crc32(x), len(x))
+        assert n == len(m) and bytes(want[:n]) == m, (frame, i)
+    if frame == "bgzf":
+        # golden header bytes observed on the reference hook (same constant fields)
+        b = load("boundary.json")["hook_fastq_ff00"]
+        assert members[0][:16].hex() == b["header18"][:32]
+        assert members[0][-8:].hex() == b["trailer8"]          # CRC32 + ISIZE of the same input
+
+
+def test_encode_capacity_errors(pkg):
+    data = bytes(hdtest.synth().random_bytes(5000))
+    r, z = pkg.hip_deflate(data, 1, cap=5005)           # stored form fits exactly
+    assert r == 0 and len(z) == 5005
+    r, _ = pkg.hip_deflate(data, 1, cap=5004)
+    assert r != 0
+    text = bytes(hdtest.synth().text_like(5000))
+    r, z = pkg.hip_deflate(text, 1)
+    rt, twin = hdtest.oracle_twin(text, 1)
+    assert r == 0 and z == twin
+    r2, z2 = pkg.hip_deflate(text, 1, cap=len(z))
+    assert r2 == 0 and z2 == z
+    r3, _ = pkg.hip_deflate(text, 1, cap=len(z) - 1)
+    rt3, _ = hdtest.oracle_twin(text, 1, cap=len(z) - 1)
+    assert (r3 != 0) == (rt3 != 0)
+
+
+# ---- decode ----------------------------------------------------------------------
+
+
+def test_inflate_reference_streams_bit_exact(pkg):
+    streams = load("ref_streams.json")
+    zs = [base64.b64decode(s["stream"]) + b"\xaa" * 8 for s in streams]     # + "trailer" bytes
+    caps = [s["out_len"] for s in streams]
+    outs, crc, st = pkg.batch_inflate(zs, caps)
+    for i, s in enumerate(streams):
+        assert st[i] == 0, (s["input"], s["encoder"], s["level"], int(st[i]))
+        assert len(outs[i]) == s["out_len"] and hdtest.sha(outs[i]) == s["out_sha256"], (s["input"], s["encoder"])
+        assert int(crc[i]) == zlib.crc32(outs[i])
+    # unaligned source / destination: per-block entry point with odd slices
+    for s in streams[:40]:
+        z = base64.b64decode(s["stream"])
+        r, out = pkg.hip_inflate(z, s["out_len"] + 7)
+        assert r == 0 and hdtest.sha(out) == s["out_sha256"]
+        r, _ = pkg.hip_inflate(z, max(s["out_len"] - 1, 0))
+        if s["out_len"]:
+            assert r == 3
+
+
+def test_inflate_malformed_vectors_rejected(pkg):
+    vects = load("inflate_std_vects.json")
+    zs = [base64.b64decode(v["data"]) for v in vects]
+    outs, _, st = pkg.batch_inflate(zs, [1 << 16] * len(zs))
+    assert len(zs) == 151 and all(int(x) != 0 for x in st)
+    for i, v in enumerate(vects):
+        ro, _ = hdtest.oracle_inflate(zs[i], 1 << 16)
+        assert (int(st[i]) != 0) == (ro != 0)
+
+
+def test_inflate_mutants_verdicts(pkg):
+    muts = load("mutants.json")
+    zs = [base64.b64decode(m["stream"]) for m in muts]
+    caps = [m["cap"] for m in muts]
+    outs, _, st = pkg.batch_inflate(zs, caps)
+    acc = 0
+    for i, m in enumerate(muts):
+        assert (int(st[i]) == 0) == (m["libdeflate"] == 0), (m["base"], int(st[i]), m["libdeflate"])
+        ro, oo = hdtest.oracle_inflate(zs[i], caps[i])
+        assert int(st[i]) == ro, (m["base"], int(st[i]), ro)         # same code as the oracle
+        if st[i] == 0:
+            acc += 1
+            assert hdtest.sha(outs[i]) == m["out_sha256"]
+    assert acc > 100
+
+
+def test_inflate_fuzz_against_oracle(pkg):
+    """2000 fresh mutants of twin-/zlib-encoded streams: kernel verdict and bytes ==
+    oracle (which is itself pinned to libdeflate by tests/test_oracle_*.py)."""
+    rng = np.random.default_rng(4242)
+    s = hdtest.synth()
+    bases = []
+    for data in (bytes(s.fastq_like(5000, seed=21)), bytes(s.text_like(4000, seed=22)), b"abc" * 900 + bytes(500)):
+        bases.append((data, hdtest.oracle_twin(data, 1)[1]))
+        for lvl in (1, 6, 9):
+            c = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+            bases.append((data, c.compress(data) + c.flush()))
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+        bases.append((data, c.compress(data) + c.flush()))
+    zs, caps = [], []
+    for k in range(2000):
+        data, z = bases[k % len(bases)]
+        m = bytearray(z)
+        kind = int(rng.integers(0, 5))
+        if kind < 3:
+            for _ in range(kind + 1):
+                bit = int(rng.integers(0, len(m) * 8))
+                m[bit >> 3] ^= 1 << (bit & 7)
+        elif kind == 3:
+            m = m[: max(1, len(m) - int(rng.integers(1, 20)))]
+        else:
+            m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        zs.append(bytes(m))
+        caps.append(len(data) + int(rng.integers(0, 3)) * 100)
+    outs, _, st = pkg.batch_inflate(zs, caps)
+    for i in range(len(zs)):
+        ro, oo = hdtest.oracle_inflate(zs[i], caps[i])
+        assert int(st[i]) == ro, (i, int(st[i]), ro)
+        if ro == 0:
+            assert outs[i] == oo
+
+
+# ---- whole containers, the hook, the device-resident path ---------------------------
+
+
+@pytest.mark.parametrize("level", [1, 6])
+def test_bgzf_roundtrip_and_zlib_interop(pkg, level):
+    import gzip
+    data = bytes(hdtest.synth().fastq_like(3 * 1024 * 1024 + 77))
+    blob = pkg.bgzf_compress_bytes(data, level)
+    assert gzip.decompress(blob) == data                          # multi-member gzip interop
+    assert pkg.bgzf_decompress_bytes(blob) == data
+    tbl = pkg.bgzf_scan(blob)
+    assert len(tbl) == -(-len(data) // 0xff00) + 1 and tbl[-1][2] == 0
+    # every member <= 64 KiB (BSIZE is a u16)
+    assert max(ln + 18 for _, ln, _ in tbl) <= 65536
+
+
+def test_bgzf_incompressible_fits(pkg):
+    """0xff00 random bytes must still make a legal member (stored fallback),
+    SURVEY.md section 5 'failure detection'."""
+    data = bytes(hdtest.synth().random_bytes(4 * 0xff00))
+    blob = pkg.bgzf_compress_bytes(data, 1)
+    tbl = pkg.bgzf_scan(blob)
+    assert all(ln + 18 == 0xff00 + 5 + 26 for _, ln, _ in tbl[:-1])
+    assert pkg.bgzf_decompress_bytes(blob) == data
+
+
+def test_hook(pkg):
+    import threading
+    os.environ["BGZF_METHOD"] = "hip1"
+    os.environ["HIPDEFLATE_BATCH_US"] = "2000"
+    data = bytes(hdtest.synth().fastq_like(16 * 0xff00))
+    blocks = [data[i:i + 0xff00] for i in range(0, len(data), 0xff00)]
+    res = [None] * len(blocks)
+
+    def work(i):
+        res[i] = pkg.bgzf_compress_hook(blocks[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(blocks))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, (r, m) in enumerate(res):
+        assert r == 0
+        assert m[:16] == bytes.fromhex("1f8b08040000000000ff060042430200")
+        assert int.from_bytes(m[16:18], "little") == len(m) - 1
+        r2, twin = hdtest.oracle_twin(blocks[i], 1, cap=65536 - 26)
+        assert m[18:-8] == twin
+        assert int.from_bytes(m[-8:-4], "little") == hdtest.oracle_crc32(blocks[i])
+        assert int.from_bytes(m[-4:], "little") == len(blocks[i])
+    assert pkg.bgzf_compress_hook(blocks[0], cap=20)[0] == -1     # bgzf_compress.c:116
+    r, m = pkg.bgzf_compress_hook(b"")
+    assert r == 0 and m == pkg.BGZF_EOF
+
+
+def test_device_resident_pipeline_properties(pkg):
+    """256 MiB resident in HBM: encode -> size scan -> compact -> decode, checked by
+    size-independent properties: decode(encode(x)) == x on the device, per-block CRC32
+    of the encoder == per-block CRC32 of the decoder, scan total == sum of sizes,
+    and 64 sampled members == CPU twin."""
+    import importlib
+    import torch
+    dev = importlib.import_module("7bgzf_amd.device")
+    s = hdtest.synth()
+    tile = torch.from_numpy(s.fastq_like(32 << 20)).cuda()
+    data = tile.repeat(8)
+    total = data.numel()
+    off, ln = dev.block_table(total, 0xff00)
+    nb = off.numel()
+    enc = dev.DeviceDeflate(nb)
+    enc.run(data, off, ln, level=1, frame=pkg.FRAME_BGZF)
+    enc.scan()
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().sum()) == 0
+    sizes = enc.out_len.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert int(enc.total.item()) == int(sizes.sum())
+    assert np.array_equal(enc.dst_off.cpu().numpy(), np.concatenate([[0], np.cumsum(sizes)[:-1]]))
+    packed = torch.empty(int(enc.total.item()) + 16, dtype=torch.uint8, device="cuda")
+    enc.compact(packed)
+    # decode from the packed stream: payload of member i = [dst_off+18, +size-18)
+    in_off = enc.dst_off + 18
+    in_len = (enc.out_len - 18).to(torch.int32)
+    out = torch.zeros_like(data)
+    out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    st = torch.ones(nb, dtype=torch.int32, device="cuda")
+    dev.device_inflate(packed, in_off, in_len, out, off, ln, out_len, crc, st)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0
+    assert torch.equal(out_len, ln) and torch.equal(out, data)
+    assert torch.equal(crc, enc.crc)
+    # sampled members against the CPU twin and the trailer fields
+    host = packed.cpu().numpy()
+    hdata = data.cpu().numpy()
+    doff = enc.dst_off.cpu().numpy()
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, nb, 64):
+        m = bytes(host[doff[i]: doff[i] + sizes[i]])
+        chunk = bytes(hdata[int(off[i]): int(off[i]) + int(ln[i])])
+        r, twin = hdtest.oracle_twin(chunk, 1, cap=65536 - 26)
+        assert m[18:-8] == twin
+        assert int.from_bytes(m[-8:-4], "little") == zlib.crc32(chunk)
