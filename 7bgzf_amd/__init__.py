@@ -45,6 +45,32 @@ EXPORTS = [
 ]
 
 
+def _link_hip_runtime():
+    """A process must hold exactly ONE HIP runtime.  PyTorch's wheel bundles its own
+    libamdhip64.so; libhipdeflate.so's RPATH looks in 7bgzf_amd/hiprt/ first, so point
+    that at torch's copy (same inode => the loader shares the instance whichever of
+    the two is loaded first).  See 7bgzf_amd/csrc/Makefile, target `hiprt`."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    link = os.path.join(HERE, "hiprt", "libamdhip64.so.7")
+    target = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            target = cand
+    try:
+        if target is None:
+            if os.path.islink(link) or os.path.exists(link):
+                os.remove(link)
+        elif not (os.path.islink(link) and os.readlink(link) == target):
+            os.makedirs(os.path.dirname(link), exist_ok=True)
+            if os.path.islink(link) or os.path.exists(link):
+                os.remove(link)
+            os.symlink(target, link)
+    except OSError:
+        pass
+
+
 def lib():
     """Load libhipdeflate.so (built by ``__graft_entry__.build()``); loud if absent."""
     global _lib
@@ -54,6 +80,7 @@ def lib():
         raise HipDeflateError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C 7bgzf_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    _link_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     L.hipdeflate_version.restype = ctypes.c_char_p
     L.hipdeflate_scratch_bytes.restype = ctypes.c_uint64
