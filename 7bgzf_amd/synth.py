@@ -23,8 +23,8 @@ def fastq_like(nbytes, seed=1234, genome_len=5_000_000, first_record=1):
     rng = np.random.default_rng(seed)
     genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, genome_len)]
     read_len = 150
-    # one record is ~ 2*150 + header(~30) + 5 bytes
-    nrec = nbytes // 330 + 2
+    # one record is 2*150 + 4 + header (17..40 bytes): never fewer than 321 bytes
+    nrec = nbytes // 321 + 2
     pos = rng.integers(0, genome_len - read_len, nrec)
     reads = genome[pos[:, None] + np.arange(read_len)[None, :]]
     sub = rng.random((nrec, read_len)) < 0.01
@@ -49,7 +49,9 @@ def fastq_like(nbytes, seed=1234, genome_len=5_000_000, first_record=1):
         total += len(rec)
         if total >= nbytes:
             break
-    return np.frombuffer(b"".join(parts)[:nbytes], dtype=np.uint8).copy()
+    blob = b"".join(parts)
+    assert len(blob) >= nbytes
+    return np.frombuffer(blob[:nbytes], dtype=np.uint8).copy()
 
 
 def text_like(nbytes, seed=4321, vocab=50_000):
@@ -76,7 +78,10 @@ def text_like(nbytes, seed=4321, vocab=50_000):
         total += len(wbytes) + 1
         if total >= nbytes + 16:
             break
-    return np.frombuffer(b" ".join(out)[:nbytes], dtype=np.uint8).copy()
+    blob = b" ".join(out)
+    while len(blob) < nbytes:              # Zipf tail shorter than planned: pad with more of the same
+        blob += b" " + blob[: nbytes - len(blob)]
+    return np.frombuffer(blob[:nbytes], dtype=np.uint8).copy()
 
 
 def random_bytes(nbytes, seed=99):

@@ -149,12 +149,14 @@ def main():
     # ---- synthetic input: a seeded FASTQ-like tile replicated to G GiB in HBM ---------
     tile_bytes = args.tile_mib << 20
     tile_np = synth.fastq_like(tile_bytes, seed=1234 + rank, first_record=1 + rank * 10_000_000)
+    assert len(tile_np) == tile_bytes
     total = int(args.gib * (1 << 30))
     reps = max(1, total // tile_bytes)
     total = reps * tile_bytes
     tile = torch.from_numpy(tile_np).cuda()
     data = tile.repeat(reps)
     del tile
+    assert data.numel() == total
     off, ln = dev.block_table(total, BLOCK)
     nb = off.numel()
 
