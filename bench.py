@@ -111,7 +111,7 @@ def cpu_baseline(tile, level, mode, sample_budget_s=16.0):
     work(0, 64, res)
     per_block = res[0][1] / 64
     one_core = BLOCK / per_block / 1e9
-    threads = min(ncores, 32)
+    threads = min(ncores, 16)          # a one-GPU box owns 16 host cores
     n_iter = max(16, int(sample_budget_s / per_block / threads))
     res = [None] * threads
     th = [threading.Thread(target=work, args=(i, n_iter, res)) for i in range(threads)]
