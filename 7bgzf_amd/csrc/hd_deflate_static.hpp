@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t S = 0;
 	while (S < n && use_static) {
 		// ---- refill the ring: one 1 KiB piece at a time ----------------
-		while (filled < n && filled < S + HD_LOOKAHEAD) {
+		if (filled < n && filled < S + HD_LOOKAHEAD) {   // one piece per step is always enough (advance <= 322)
 			const uint32_t piece = filled / HD_PIECE;
 			uint4 v = pre;
 			filled += HD_PIECE;
@@ -227,77 +227,94 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t lo = filled > W ? filled - W : 0;
 		const uint32_t lanes = n - S < 64 ? n - S : 64;
 
-		// ---- 1. look up, 2. publish, 3. verify -------------------------
+		// ---- 1. look up, 2. publish, 3. verify + first 8 bytes of length --
+		// every lane holds its own 8 bytes [p, p+8) and, if it has a candidate,
+		// the candidate's 8 bytes: match lengths up to 8 come out of one XOR,
+		// in parallel for all 64 positions (DNA-like data averages ~12 matches
+		// of ~5 bytes per step; a per-match serial extension would dominate)
 		const uint32_t p = S + lane;
 		const bool can = p + HD_MIN_MATCH <= n;
-		uint32_t w0 = ring32[(p >> 2) & W4M], w1 = ring32[((p >> 2) + 1) & W4M];
+		const uint32_t pi = p >> 2;
+		const uint32_t w0 = ring32[pi & W4M], w1 = ring32[(pi + 1) & W4M], w2 = ring32[(pi + 2) & W4M];
 		const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+		const uint32_t vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const uint32_t h = (v * HD_HASH_MUL) >> (32 - HASH_BITS);
 		uint32_t c = 0;
 		if (can) {
 			c = table[h];
 			atomicMax(&table[h], p + 1);
 		}
-		bool ok = false;
-		uint32_t dist = 0;
-		if (can && c != 0 && c - 1 >= lo) {
-			const uint32_t cp = c - 1;
-			uint32_t c0 = ring32[(cp >> 2) & W4M], c1 = ring32[((cp >> 2) + 1) & W4M];
-			ok = __builtin_amdgcn_alignbyte(c1, c0, cp & 3) == v;
-			dist = p - cp;
-		}
+		const uint32_t cp = c - 1;
+		const uint32_t ci = cp >> 2;
+		const uint32_t c0 = ring32[ci & W4M], c1 = ring32[(ci + 1) & W4M], c2 = ring32[(ci + 2) & W4M];
+		const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, cp & 3);
+		const uint32_t cvh = __builtin_amdgcn_alignbyte(c2, c1, cp & 3);
+		const bool ok = can && c != 0 && cp >= lo && cv == v;
+		const uint32_t dist = ok ? p - cp : 1u;
+		const uint32_t x = cvh ^ vh;
+		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
+		const uint32_t room = n - p;                  // >= 4 where ok
+		uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
 		uint64_t rem = __ballot(ok);
 
-		// ---- 4. greedy resolution, cooperative extension ---------------
-		uint64_t cover = 0;
-		uint32_t mylen = 0, E = 0;
+		// ---- 4. greedy resolution: a scalar walk over the candidate mask --
+		uint64_t starts = 0;
+		uint32_t E = 0;
 		while (rem) {
 			const uint32_t m = (uint32_t)__ffsll((unsigned long long)rem) - 1;
-			const uint32_t dm = readlane(dist, m);
-			const uint32_t pm = S + m;
-			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
-			uint32_t len = HD_MIN_MATCH;
-			for (;;) {
-				const uint32_t idx = len + lane;
-				bool diff = true;
-				if (idx < maxlen)
-					diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
-				const uint64_t nq = __ballot(diff);
-				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
-				len += k;
-				if (k < 64)
-					break;
+			uint32_t len = readlane(mylen, m);
+			if (len == 8) {
+				// the parallel compare ran out of bytes: extend this one
+				// cooperatively, 64 bytes per ballot
+				const uint32_t dm = readlane(dist, m);
+				const uint32_t pm = S + m;
+				const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+				for (;;) {
+					const uint32_t idx = len + lane;
+					bool diff = true;
+					if (idx < maxlen)
+						diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
+					const uint64_t nq = __ballot(diff);
+					const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
+					len += k;
+					if (k < 64)
+						break;
+				}
+				if (lane == m)
+					mylen = len;
 			}
-			if (lane == m)
-				mylen = len;
+			starts |= 1ull << m;
 			E = m + len;
-			const uint64_t upto = E >= 64 ? ~0ull : ((1ull << E) - 1);
-			cover |= upto & ~((1ull << m) - 1);
-			rem &= ~upto;
+			rem = E >= 64 ? 0 : (rem >> E) << E;
 		}
-		const bool is_match = mylen != 0;
-		const bool is_lit = lane < lanes && !((cover >> lane) & 1);
+		// coverage: the nearest start at or before this lane, and its length
+		const uint64_t sb = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+		const uint32_t ms = 63 - (uint32_t)__clzll((long long)(sb | 1ull));  // sb == 0 -> lane 0 (harmless)
+		const uint32_t lenms = (uint32_t)__shfl((int)mylen, (int)ms, 64);
+		const bool covered = sb != 0 && lane < ms + lenms;
+		const bool is_match = (starts >> lane) & 1;
+		const bool is_lit = lane < lanes && !covered;
 
-		// ---- 5. codes ---------------------------------------------------
-		uint32_t code = 0, nbits = 0;
-		if (is_match) {
+		// ---- 5. codes (straight-line: both forms computed, one selected) ---
+		uint32_t code, nbits;
+		{
 			uint32_t ls, leb, lev, ds, deb, dev;
 			len_slot(mylen, ls, leb, lev);
 			off_slot(dist, ds, deb, dev);
 			// litlen symbols 257..279: 7 bits (sym-256); 280..287: 8 bits 0xC0+(sym-280)
-			uint32_t lc, ln;
-			if (ls < 23) { lc = __brev(ls + 1) >> 25; ln = 7; }
-			else         { lc = __brev(0xC0 + (ls - 23)) >> 24; ln = 8; }
-			code = lc | (lev << ln);
-			nbits = ln + leb;
-			code |= (__brev(ds) >> 27) << nbits;
-			nbits += 5;
-			code |= dev << nbits;
-			nbits += deb;
-		} else if (is_lit) {
+			const uint32_t lc = ls < 23 ? __brev(ls + 1) >> 25 : __brev(0xC0 + (ls - 23)) >> 24;
+			const uint32_t ln7 = ls < 23 ? 7u : 8u;
+			uint32_t mc = lc | (lev << ln7);
+			uint32_t mn = ln7 + leb;
+			mc |= (__brev(ds) >> 27) << mn;
+			mn += 5;
+			mc |= dev << mn;
+			mn += deb;
 			const uint32_t byte = v & 0xff;
-			if (byte < 144) { code = __brev(0x30 + byte) >> 24; nbits = 8; }
-			else            { code = __brev(0x190 + (byte - 144)) >> 23; nbits = 9; }
+			const uint32_t lcode = byte < 144 ? __brev(0x30 + byte) >> 24 : __brev(0x190 + (byte - 144)) >> 23;
+			const uint32_t lbits = byte < 144 ? 8u : 9u;
+			code = is_match ? mc : lcode;
+			nbits = is_match ? mn : (is_lit ? lbits : 0u);
 		}
 		const uint32_t incl = wave_incl_scan(nbits);
 		const uint32_t total = readlane(incl, 63);
