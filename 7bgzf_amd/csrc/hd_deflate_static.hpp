@@ -213,17 +213,23 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	}
 
 	uint32_t S = 0;
+	// Two-level loop: the outer one brings in one 1 KiB piece (already in flight
+	// in `pre` since the previous outer iteration) and issues the next load; the
+	// inner one parses while the ring holds HD_LOOKAHEAD bytes past S.  Keeping
+	// `pre` untouched inside the inner loop matters: a loop-carried copy of it
+	// would put an s_waitcnt vmcnt(0) -- i.e. a wait for the previous step's
+	// output store to reach L2 -- into every step.
 	while (S < n && use_static) {
-		// ---- refill the ring: one 1 KiB piece at a time ----------------
-		if (filled < n && filled < S + HD_LOOKAHEAD) {   // one piece per step is always enough (advance <= 322)
+		if (filled < n && filled < S + HD_LOOKAHEAD) {
 			const uint32_t piece = filled / HD_PIECE;
-			uint4 v = pre;
+			const uint4 v = pre;
 			filled += HD_PIECE;
 			if (filled < n)
 				pre = load_slot(src, n, piece + 1, lane, aligned);
 			((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
 			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 		}
+	  while (S < n && (filled >= n || filled >= S + HD_LOOKAHEAD)) {
 		const uint32_t lo = filled > W ? filled - W : 0;
 		const uint32_t lanes = n - S < 64 ? n - S : 64;
 
@@ -255,20 +261,38 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
 		const uint32_t room = n - p;                  // >= 4 where ok
 		uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
-		uint64_t rem = __ballot(ok);
 
-		// ---- 4. greedy resolution: a scalar walk over the candidate mask --
-		uint64_t starts = 0;
+		// ---- 4. greedy resolution as a wave prefix scan ---------------------
+		// The greedy parse is a little automaton walking the lanes: its state
+		// r = "lanes still covered by the current match"; a lane with r == 0
+		// starts a token and sets r = len - 1 (0 for a literal), otherwise
+		// r -= 1.  Each lane's transition f_l : {0..7} -> {0..7} is eight bytes;
+		// composing two of them is two v_perm_b32 table lookups, so the state
+		// entering every lane comes out of a 6-stage DPP scan -- no per-match
+		// serial loop (DNA-like data has ~12 matches per 64 bytes).  Matches
+		// whose first 8 bytes all agree ("capped") are rare; when the scan
+		// takes one it is extended cooperatively and the scan is redone for
+		// the lanes behind it.
+		const bool capped = ok && eqb == 4 && room > 8;
+		uint32_t base = 0;                 // lanes < base are settled (covered)
+		uint64_t starts = 0;               // settled token starts
 		uint32_t E = 0;
-		while (rem) {
-			const uint32_t m = (uint32_t)__ffsll((unsigned long long)rem) - 1;
-			uint32_t len = readlane(mylen, m);
-			if (len == 8) {
-				// the parallel compare ran out of bytes: extend this one
-				// cooperatively, 64 bytes per ballot
+		for (;;) {
+			const uint32_t a = (ok && lane >= base) ? (mylen < 8 ? mylen : 8u) - 1 : 0u;
+			const Fn8 w = fn8_scan(fn8_make(lane >= base, a));
+			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1
+			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138 /* wave_shr:1 */,
+										   0xf, 0xf, false);
+			const bool st = sin == 0 && lane >= base;
+			const uint64_t stm = __ballot(st);
+			uint64_t cm = __ballot(st && capped && mylen == 8);
+			bool redo = false;
+			while (cm) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
 				const uint32_t dm = readlane(dist, m);
 				const uint32_t pm = S + m;
 				const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+				uint32_t len = 8;
 				for (;;) {
 					const uint32_t idx = len + lane;
 					bool diff = true;
@@ -280,20 +304,34 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					if (k < 64)
 						break;
 				}
-				if (lane == m)
-					mylen = len;
+				if (len > 8) {
+					if (lane == m)
+						mylen = len;
+					// everything the scan decided up to and including m stands;
+					// the lanes under the longer match are covered
+					starts |= stm & ((2ull << m) - 1);
+					base = m + len;
+					redo = true;
+					break;
+				}
+				cm &= cm - 1;
 			}
-			starts |= 1ull << m;
-			E = m + len;
-			rem = E >= 64 ? 0 : (rem >> E) << E;
+			if (!redo) {
+				starts |= stm;
+				// coverage left over after lane 63 = state after the last lane
+				E = 64 + (readlane(w.lo, 63) & 0xff);
+				break;
+			}
+			if (base >= 64) {
+				E = base;
+				break;
+			}
 		}
-		// coverage: the nearest start at or before this lane, and its length
-		const uint64_t sb = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
-		const uint32_t ms = 63 - (uint32_t)__clzll((long long)(sb | 1ull));  // sb == 0 -> lane 0 (harmless)
-		const uint32_t lenms = (uint32_t)__shfl((int)mylen, (int)ms, 64);
-		const bool covered = sb != 0 && lane < ms + lenms;
-		const bool is_match = (starts >> lane) & 1;
-		const bool is_lit = lane < lanes && !covered;
+		const bool is_start = (starts >> lane) & 1;
+		const bool is_match = is_start && ok;
+		const bool is_lit = is_start && !ok && lane < lanes;
+		if (lanes < 64)
+			E = 0;                          // tail step: matches are clipped to n, advance = lanes
 
 		// ---- 5. codes (straight-line: both forms computed, one selected) ---
 		uint32_t code, nbits;
@@ -324,6 +362,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		}
 		emit(code, nbits, incl, total);
 		S += E > lanes ? E : lanes;
+	  }
 	}
 
 	// the CRC needs every piece, also when the static stream was abandoned

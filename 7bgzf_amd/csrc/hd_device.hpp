@@ -41,6 +41,55 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 	return v;
 }
 
+// ---- greedy-parse automaton scan -------------------------------------------
+// A lane's transition is f(r) = r - 1 for r = 1..7 and f(0) = a (a = len - 1 of
+// the token that would start here, 0 for a literal): eight bytes
+// {a,0,1,2 | 3,4,5,6}.  (g o f)(r) = g[f(r)] is a byte-table lookup, i.e.
+// v_perm_b32 with g as the 8-byte table {S0 = g.hi, S1 = g.lo} and f's bytes as
+// selectors (selector 0..3 -> S1 bytes, 4..7 -> S0 bytes).
+struct Fn8 {
+	uint32_t lo, hi;
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Fn8 fn8_dpp(Fn8 v)
+{
+	// lanes without a source keep the identity map {0,1,2,3 | 4,5,6,7}
+	Fn8 r;
+	r.lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.lo, CTRL, ROW_MASK, 0xf, false);
+	r.hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.hi, CTRL, ROW_MASK, 0xf, false);
+	return r;
+}
+
+// apply `first`, then `then`
+__device__ __forceinline__ Fn8 fn8_compose(Fn8 then, Fn8 first)
+{
+	Fn8 r;
+	r.lo = __builtin_amdgcn_perm(then.hi, then.lo, first.lo);
+	r.hi = __builtin_amdgcn_perm(then.hi, then.lo, first.hi);
+	return r;
+}
+
+// inclusive scan: result at lane l = f_l o ... o f_0
+__device__ __forceinline__ Fn8 fn8_scan(Fn8 w)
+{
+	w = fn8_compose(w, fn8_dpp<0x111, 0xf>(w));   // row_shr:1
+	w = fn8_compose(w, fn8_dpp<0x112, 0xf>(w));   // row_shr:2
+	w = fn8_compose(w, fn8_dpp<0x114, 0xf>(w));   // row_shr:4
+	w = fn8_compose(w, fn8_dpp<0x118, 0xf>(w));   // row_shr:8
+	w = fn8_compose(w, fn8_dpp<0x142, 0xa>(w));   // row_bcast:15 -> rows 1,3
+	w = fn8_compose(w, fn8_dpp<0x143, 0xc>(w));   // row_bcast:31 -> rows 2,3
+	return w;
+}
+
+__device__ __forceinline__ Fn8 fn8_make(bool live, uint32_t a)
+{
+	Fn8 f;
+	f.lo = live ? (0x02010000u | a) : 0x03020100u;   // not live: identity
+	f.hi = live ? 0x06050403u : 0x07060504u;
+	return f;
+}
+
 __device__ __forceinline__ uint32_t wave_xor_reduce(uint32_t v)
 {
 	for (int o = 32; o > 0; o >>= 1)
