@@ -138,7 +138,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
 	constexpr uint32_t HS = 1u << HASH_BITS;
-	constexpr uint32_t STG = 128;
+	constexpr uint32_t STG = 256;            // staging ring, dwords
+	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 
 	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4];
 	__shared__ __attribute__((aligned(16))) uint32_t table[HS];
@@ -187,80 +188,91 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t flushed = 0;                // dwords already stored to HBM
 	const uint32_t paybase = 8 * hdr;
 
-	// emit one token per lane (nbits == 0: none) and flush completed dwords
-	auto emit = [&](uint32_t code, uint32_t nbits, uint32_t incl, uint32_t total) {
-		uint32_t bp = bitpos + incl - nbits;
+	// OR one token per lane (nbits == 0: none) into the staging ring
+	auto put = [&](uint32_t code, uint32_t nbits, uint32_t incl, uint32_t total) {
+		const uint32_t bp = bitpos + incl - nbits;
 		if (nbits) {
-			uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
+			const uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
 			atomicOr(&stage[i], code << sh);
 			if (sh + nbits > 32)
 				atomicOr(&stage[(i + 1) & (STG - 1)], code >> (32 - sh));
 		}
 		bitpos += total;
-		uint32_t ndw = (bitpos >> 5) - flushed;
-		if (lane < ndw) {
-			uint32_t i = flushed + lane;
-			uint32_t v = stage[i & (STG - 1)];
-			stage[i & (STG - 1)] = 0;
-			dst32[i] = v;
-		}
-		flushed += ndw;
 	};
-
-	// BFINAL = 1, BTYPE = 01
-	{
-		emit(3u, lane == 0 ? 3u : 0u, 3u, 3u);
-	}
-
-	uint32_t S = 0;
-	// Two-level loop: the outer one brings in one 1 KiB piece (already in flight
-	// in `pre` since the previous outer iteration) and issues the next load; the
-	// inner one parses while the ring holds HD_LOOKAHEAD bytes past S.  Keeping
-	// `pre` untouched inside the inner loop matters: a loop-carried copy of it
-	// would put an s_waitcnt vmcnt(0) -- i.e. a wait for the previous step's
-	// output store to reach L2 -- into every step.
-	while (S < n && use_static) {
-		if (filled < n && filled < S + HD_LOOKAHEAD) {
-			const uint32_t piece = filled / HD_PIECE;
-			const uint4 v = pre;
-			filled += HD_PIECE;
-			if (filled < n)
-				pre = load_slot(src, n, piece + 1, lane, aligned);
-			((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
-			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+	// whenever 128 whole dwords are ready they leave as one 8-byte-per-lane store
+	auto flush_ready = [&]() {
+		if ((bitpos >> 5) - flushed >= FLUSH_DW) {
+			const uint32_t i = (flushed & (STG - 1)) + 2 * lane;   // flushed is a multiple of 128
+			const uint2 v = *(const uint2 *)&stage[i];
+			*(uint2 *)&stage[i] = make_uint2(0, 0);
+			*(uint2 *)&dst32[flushed + 2 * lane] = v;
+			flushed += FLUSH_DW;
 		}
-	  while (S < n && (filled >= n || filled >= S + HD_LOOKAHEAD)) {
-		const uint32_t lo = filled > W ? filled - W : 0;
-		const uint32_t lanes = n - S < 64 ? n - S : 64;
-
-		// ---- 1. look up, 2. publish, 3. verify + first 8 bytes of length --
-		// every lane holds its own 8 bytes [p, p+8) and, if it has a candidate,
-		// the candidate's 8 bytes: match lengths up to 8 come out of one XOR,
-		// in parallel for all 64 positions (DNA-like data averages ~12 matches
-		// of ~5 bytes per step; a per-match serial extension would dominate)
-		const uint32_t p = S + lane;
-		const bool can = p + HD_MIN_MATCH <= n;
+	};
+	auto fill_piece = [&]() {
+		const uint32_t piece = filled / HD_PIECE;
+		const uint4 v = pre;
+		filled += HD_PIECE;
+		if (filled < n)
+			pre = load_slot(src, n, piece + 1, lane, aligned);
+		((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
+		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+	};
+	// own 8 bytes at S_ + lane, hash, table lookup, publish: the front half of a
+	// step, issued one step ahead so that its LDS latency hides behind the
+	// previous step's scan / code / emit arithmetic
+	uint32_t v = 0, vh = 0, c = 0;
+	auto fetch = [&](uint32_t S_) {
+		const uint32_t p = S_ + lane;
 		const uint32_t pi = p >> 2;
 		const uint32_t w0 = ring32[pi & W4M], w1 = ring32[(pi + 1) & W4M], w2 = ring32[(pi + 2) & W4M];
-		const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
-		const uint32_t vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
+		v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+		vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const uint32_t h = (v * HD_HASH_MUL) >> (32 - HASH_BITS);
-		uint32_t c = 0;
-		if (can) {
+		c = 0;
+		if (p + HD_MIN_MATCH <= n) {
 			c = table[h];
 			atomicMax(&table[h], p + 1);
 		}
-		const uint32_t cp = c - 1;
+	};
+
+	// BFINAL = 1, BTYPE = 01
+	put(3u, lane == 0 ? 3u : 0u, 3u, 3u);
+
+	if (use_static && n) {
+		fill_piece();
+		fetch(0);
+	}
+	uint32_t carry = 0;                  // leading positions covered by the last match
+	for (uint32_t S = 0; S < n && use_static; S += 64) {
+		if (filled < n && filled < S + HD_LOOKAHEAD)
+			fill_piece();
+		const uint32_t lo = filled > W ? filled - W : 0;
+		const uint32_t lanes = n - S < 64 ? n - S : 64;
+
+		// ---- 3. verify the candidate + first 8 bytes of its length ---------
+		const uint32_t p = S + lane;
+		const bool can = p + HD_MIN_MATCH <= n;
+		const uint32_t cv0 = v, cvh0 = vh, cp = c - 1;
 		const uint32_t ci = cp >> 2;
 		const uint32_t c0 = ring32[ci & W4M], c1 = ring32[(ci + 1) & W4M], c2 = ring32[(ci + 2) & W4M];
+		const bool had = can && c != 0 && cp >= lo;
+		// ---- 1./2. of the NEXT step, in flight while this one computes -----
+		if (S + 64 < n)
+			fetch(S + 64);
 		const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, cp & 3);
 		const uint32_t cvh = __builtin_amdgcn_alignbyte(c2, c1, cp & 3);
-		const bool ok = can && c != 0 && cp >= lo && cv == v;
+		const bool ok = had && cv == cv0;
 		const uint32_t dist = ok ? p - cp : 1u;
-		const uint32_t x = cvh ^ vh;
+		const uint32_t x = cvh ^ cvh0;
 		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
 		const uint32_t room = n - p;                  // >= 4 where ok
 		uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
+
+		if (carry >= lanes) {                // the whole step lies inside the last match
+			carry -= lanes;
+			continue;
+		}
 
 		// ---- 4. greedy resolution as a wave prefix scan ---------------------
 		// The greedy parse is a little automaton walking the lanes: its state
@@ -274,64 +286,62 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// takes one it is extended cooperatively and the scan is redone for
 		// the lanes behind it.
 		const bool capped = ok && eqb == 4 && room > 8;
-		uint32_t base = 0;                 // lanes < base are settled (covered)
-		uint64_t starts = 0;               // settled token starts
-		uint32_t E = 0;
-		for (;;) {
-			const uint32_t a = (ok && lane >= base) ? (mylen < 8 ? mylen : 8u) - 1 : 0u;
-			const Fn8 w = fn8_scan(fn8_make(lane >= base, a));
+		const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;   // token length as the scan sees it
+		uint64_t starts;
+		{
+			const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1));
 			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1
 			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138 /* wave_shr:1 */,
 										   0xf, 0xf, false);
-			const bool st = sin == 0 && lane >= base;
-			const uint64_t stm = __ballot(st);
-			uint64_t cm = __ballot(st && capped && mylen == 8);
-			bool redo = false;
-			while (cm) {
-				const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
-				const uint32_t dm = readlane(dist, m);
-				const uint32_t pm = S + m;
-				const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
-				uint32_t len = 8;
-				for (;;) {
-					const uint32_t idx = len + lane;
-					bool diff = true;
-					if (idx < maxlen)
-						diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
-					const uint64_t nq = __ballot(diff);
-					const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
-					len += k;
-					if (k < 64)
-						break;
-				}
-				if (len > 8) {
-					if (lane == m)
-						mylen = len;
-					// everything the scan decided up to and including m stands;
-					// the lanes under the longer match are covered
-					starts |= stm & ((2ull << m) - 1);
-					base = m + len;
-					redo = true;
-					break;
-				}
-				cm &= cm - 1;
-			}
-			if (!redo) {
-				starts |= stm;
-				// coverage left over after lane 63 = state after the last lane
-				E = 64 + (readlane(w.lo, 63) & 0xff);
-				break;
-			}
-			if (base >= 64) {
-				E = base;
-				break;
-			}
+			starts = __ballot(sin == 0 && lane >= carry);
 		}
+		// Capped matches the scan took: extend each (left to right) to its true
+		// length, drop the token starts it now covers, and re-thread the chain
+		// behind it.  Two parses that start a token on the same lane coincide
+		// from there on, so the walk stops at the first old start it lands on
+		// (a few hops) instead of re-scanning the wave.
+		const uint64_t capmask = __ballot(capped);
+		uint64_t cm = starts & capmask;
+		while (cm) {
+			const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
+			const uint32_t dm = readlane(dist, m);
+			const uint32_t pm = S + m;
+			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+			uint32_t len = 8;
+			for (;;) {
+				const uint32_t idx = len + lane;
+				bool diff = true;
+				if (idx < maxlen)
+					diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
+				const uint64_t nq = __ballot(diff);
+				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
+				len += k;
+				if (k < 64)
+					break;
+			}
+			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
+			if (len > 8) {
+				if (lane == m)
+					mylen = len;
+				const uint32_t q = m + len;                   // first lane behind the match
+				uint64_t fresh = 0;
+				uint32_t x = q;
+				while (x < 64 && !((starts >> x) & 1)) {
+					fresh |= 1ull << x;
+					x += readlane(jump8, x);
+				}
+				const uint64_t below_x = x >= 64 ? ~0ull : ((1ull << x) - 1);
+				starts = (starts & (upto_m | ~below_x)) | fresh;
+			}
+			cm = starts & capmask & ~upto_m;
+		}
+		// coverage behind the last token of the step
+		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
+		const uint32_t E = last + (readlane(ok ? mylen : 1u, last));
 		const bool is_start = (starts >> lane) & 1;
 		const bool is_match = is_start && ok;
 		const bool is_lit = is_start && !ok && lane < lanes;
-		if (lanes < 64)
-			E = 0;                          // tail step: matches are clipped to n, advance = lanes
+		carry = (lanes == 64 && E > 64) ? E - 64 : 0;   // tail step: matches are clipped to n
 
 		// ---- 5. codes (straight-line: both forms computed, one selected) ---
 		uint32_t code, nbits;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			mn += 5;
 			mc |= dev << mn;
 			mn += deb;
-			const uint32_t byte = v & 0xff;
+			const uint32_t byte = cv0 & 0xff;
 			const uint32_t lcode = byte < 144 ? __brev(0x30 + byte) >> 24 : __brev(0x190 + (byte - 144)) >> 23;
 			const uint32_t lbits = byte < 144 ? 8u : 9u;
 			code = is_match ? mc : lcode;
@@ -360,19 +370,18 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			use_static = false;
 			break;
 		}
-		emit(code, nbits, incl, total);
-		S += E > lanes ? E : lanes;
-	  }
+		put(code, nbits, incl, total);
+		flush_ready();
 	}
 
 	// the CRC needs every piece, also when the static stream was abandoned
 	while (filled < n) {
 		const uint32_t piece = filled / HD_PIECE;
-		uint4 v = pre;
+		const uint4 pv = pre;
 		filled += HD_PIECE;
 		if (filled < n)
 			pre = load_slot(src, n, piece + 1, lane, aligned);
-		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
 	}
 	const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 
@@ -388,20 +397,17 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	bitpos = (bitpos + 7) & ~7u;
 	const uint32_t paylen = (bitpos - paybase) >> 3;
 	if (trl) {
-		uint32_t code = 0, nb = 0;
+		uint32_t tcode = 0, nb = 0;
 		if (lane < 4) {
-			code = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
+			tcode = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
 			nb = 16;
 		}
 		const uint32_t incl = wave_incl_scan(nb);
-		emit(code, nb, incl, 64);
+		put(tcode, nb, incl, 64);
 	}
-	// final flush: the last partial dword
-	{
-		const uint32_t ndw = ((bitpos + 31) >> 5) - flushed;
-		if (lane < ndw)
-			dst32[flushed + lane] = stage[(flushed + lane) & (STG - 1)];
-	}
+	// final flush: everything left, including the last partial dword (< 256 dwords)
+	for (uint32_t i = flushed + lane; i < ((bitpos + 31) >> 5); i += 64)
+		dst32[i] = stage[i & (STG - 1)];
 	if (lane == 0) {
 		const uint32_t total = hdr + paylen + trl;
 		if (a.frame == HD_FRAME_BGZF)

@@ -18,16 +18,19 @@
  *   length/offset slot tables (:237-318)                -> len_slot()/off_slot()
  *
  * The algorithm (one "step" = what one wavefront does at once):
- *   S = first unparsed position.  Lanes l = 0..63 stand on p = S + l.
+ *   Steps stand on fixed 64-byte strides: S = 0, 64, 128, ...  Lanes l = 0..63
+ *   stand on p = S + l; `carry` = how many leading positions the previous
+ *   steps' last match still covers (it may cover whole steps).
  *   1. every lane with 4 bytes left hashes in[p..p+4) and reads the table
  *      entry (latest earlier position with that hash, from PREVIOUS steps only),
- *   2. then every such lane publishes p: table[h] = max(table[h], p + 1),
+ *   2. then every such lane -- covered or not -- publishes p:
+ *      table[h] = max(table[h], p + 1),
  *   3. a lane is a match start candidate iff its entry is inside the window and
  *      the 4 bytes there are equal,
- *   4. greedy resolution left to right: the first candidate at or after the
- *      cursor E is taken, extended to its full length (<= 258, <= n - p), and
- *      E jumps past it; lanes not covered by a taken match are literals,
- *   5. tokens are emitted in position order; S advances by max(E, lanes).
+ *   4. greedy resolution left to right from lane `carry`: the first candidate at
+ *      or after the cursor E is taken, extended to its full length (<= 258,
+ *      <= n - p), and E jumps past it; lanes not covered are literals,
+ *   5. tokens are emitted in position order; carry = max(E - 64, 0).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -120,7 +123,7 @@ typedef struct {
 
 typedef struct {
 	unsigned lanes;           /* positions covered by lanes this step */
-	unsigned advance;         /* bytes consumed (>= lanes) */
+	unsigned carry_out;       /* lanes of the NEXT step the last match covers */
 	uint8_t  is_match[HD_WAVE];
 	uint8_t  is_lit[HD_WAVE];
 	uint16_t len[HD_WAVE];
@@ -132,7 +135,7 @@ static uint32_t load32(const uint8_t *p)
 	return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, step_t *st)
+static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry, step_t *st)
 {
 	uint32_t cand[HD_WAVE];
 	uint8_t ok[HD_WAVE];
@@ -173,7 +176,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, step_t *
 		ok[l] = 1;
 		st->dist[l] = (uint32_t)(p - c);
 	}
-	unsigned E = 0;                                 /* 4. greedy */
+	unsigned E = carry;                             /* 4. greedy */
 	for (unsigned l = 0; l < lanes; l++) {
 		if (l < E || !ok[l])
 			continue;
@@ -186,7 +189,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, step_t *
 		st->len[l] = (uint16_t)len;
 		E = l + len;
 	}
-	E = 0;
+	E = carry;
 	for (unsigned l = 0; l < lanes; l++) {
 		if (st->is_match[l])
 			E = l + st->len[l];
@@ -194,7 +197,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, step_t *
 			st->is_lit[l] = 1;
 	}
 	st->lanes = lanes;
-	st->advance = E > lanes ? E : lanes;
+	st->carry_out = E > lanes ? E - lanes : 0;   /* E >= carry always */
 }
 
 /* ---- level 1: greedy + static Huffman, streaming ------------------------ */
@@ -216,8 +219,10 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 
 	bw_put(&w, 1, 1);       /* BFINAL */
 	bw_put(&w, 1, 2);       /* BTYPE = 01 */
-	for (size_t S = 0; S < n && use_static; S += st.advance) {
-		parse_step(&mf, in, n, S, &st);
+	unsigned carry = 0;
+	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
+		parse_step(&mf, in, n, S, carry, &st);
+		carry = st.carry_out;
 		/* the kernel knows the step's bit count (wave prefix sum) before it
 		 * writes anything; once the stream plus the end-of-block code can no
 		 * longer fit in `limit` bytes it abandons the static stream for good */
