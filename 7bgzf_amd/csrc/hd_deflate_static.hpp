@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 
 	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4];
-	__shared__ __attribute__((aligned(16))) uint32_t table[HS];
+	__shared__ __attribute__((aligned(16))) uint16_t table[HS];   // (position + 1) mod 2^16, 0 = empty
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		limit = cap - hdr - trl;
 
 	// ---- init LDS -------------------------------------------------------
-	for (uint32_t i = lane; i < HS / 4; i += 64)
+	for (uint32_t i = lane; i < HS / 8; i += 64)
 		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
 	for (uint32_t i = lane; i < STG; i += 64)
 		stage[i] = 0;
@@ -218,30 +218,75 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
 		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 	};
-	// own 8 bytes at S_ + lane, hash, table lookup, publish: the front half of a
-	// step, issued one step ahead so that its LDS latency hides behind the
-	// previous step's scan / code / emit arithmetic
-	uint32_t v = 0, vh = 0, c = 0;
-	auto fetch = [&](uint32_t S_) {
+	// ---- the front of the pipeline -------------------------------------------
+	// A step is split in three stages that run one iteration apart, so that no
+	// LDS round trip is waited for where it is issued:
+	//   fetch(k+2)  own 8 bytes at S + lane, hash, table lookup, publish
+	//   probe(k+1)  the three ring dwords under the candidate found by fetch
+	//   compute(k)  verify, scan, codes, emit
+	// The table holds (position + 1) mod 2^16 in 16 bits (0 = empty): half the
+	// LDS of 32-bit entries, which buys occupancy.  Several lanes of a step may
+	// publish to one slot; the hardware picks an arbitrary winner, so the
+	// losers with a LARGER position write again until the slot holds the
+	// maximum -- the order-independent result the CPU twin computes.
+	struct Fetched {
+		uint32_t v, vh, c;           // own bytes [p,p+4), [p+4,p+8); candidate position + 1 (0 = none)
+	};
+	auto fetch = [&](uint32_t S_) -> Fetched {
+		Fetched f;
 		const uint32_t p = S_ + lane;
 		const uint32_t pi = p >> 2;
 		const uint32_t w0 = ring32[pi & W4M], w1 = ring32[(pi + 1) & W4M], w2 = ring32[(pi + 2) & W4M];
-		v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
-		vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
-		const uint32_t h = (v * HD_HASH_MUL) >> (32 - HASH_BITS);
-		c = 0;
-		if (p + HD_MIN_MATCH <= n) {
-			c = table[h];
-			atomicMax(&table[h], p + 1);
+		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
+		const uint32_t h = (f.v * HD_HASH_MUL) >> (32 - HASH_BITS);
+		f.c = 0;
+		const bool can = p + HD_MIN_MATCH <= n;
+		const uint16_t mine = (uint16_t)(p + 1);
+		if (can) {
+			const uint32_t e = table[h];
+			// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
+			const uint32_t back = (p + 1 - e) & 0xffffu;     // 0: an entry exactly 2^16 back, i.e. stale
+			f.c = (e && back) ? p + 1 - back : 0u;
+			table[h] = mine;
 		}
+		// settle publish conflicts inside this step (positions differ by < 64)
+		for (;;) {
+			bool again = false;
+			if (can) {
+				const uint16_t now = table[h];
+				again = (uint16_t)(mine - now) - 1u < 0x7fffu;      // mine > now (mod 2^16)
+				if (again)
+					table[h] = mine;
+			}
+			if (!__ballot(again))
+				break;
+		}
+		return f;
+	};
+	struct Probed {
+		uint32_t c0, c1, c2;
+	};
+	auto probe = [&](uint32_t c) -> Probed {
+		Probed q;
+		const uint32_t ci = (c - 1) >> 2;
+		q.c0 = ring32[ci & W4M];
+		q.c1 = ring32[(ci + 1) & W4M];
+		q.c2 = ring32[(ci + 2) & W4M];
+		return q;
 	};
 
 	// BFINAL = 1, BTYPE = 01
 	put(3u, lane == 0 ? 3u : 0u, 3u, 3u);
 
+	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
+	Probed q0 = { 0, 0, 0 };
 	if (use_static && n) {
 		fill_piece();
-		fetch(0);
+		f0 = fetch(0);
+		q0 = probe(f0.c);
+		if (n > 64)
+			f1 = fetch(64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
 	for (uint32_t S = 0; S < n && use_static; S += 64) {
@@ -250,18 +295,22 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t lo = filled > W ? filled - W : 0;
 		const uint32_t lanes = n - S < 64 ? n - S : 64;
 
+		// stage 2 of step k+1 and stage 1 of step k+2 go out first
+		const Fetched fc = f0;
+		const Probed qc = q0;
+		f0 = f1;
+		if (S + 64 < n)
+			q0 = probe(f1.c);
+		if (S + 128 < n)
+			f1 = fetch(S + 128);
+
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
 		const uint32_t p = S + lane;
 		const bool can = p + HD_MIN_MATCH <= n;
-		const uint32_t cv0 = v, cvh0 = vh, cp = c - 1;
-		const uint32_t ci = cp >> 2;
-		const uint32_t c0 = ring32[ci & W4M], c1 = ring32[(ci + 1) & W4M], c2 = ring32[(ci + 2) & W4M];
-		const bool had = can && c != 0 && cp >= lo;
-		// ---- 1./2. of the NEXT step, in flight while this one computes -----
-		if (S + 64 < n)
-			fetch(S + 64);
-		const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, cp & 3);
-		const uint32_t cvh = __builtin_amdgcn_alignbyte(c2, c1, cp & 3);
+		const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
+		const bool had = can && fc.c != 0 && cp >= lo;
+		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
+		const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
 		const bool ok = had && cv == cv0;
 		const uint32_t dist = ok ? p - cp : 1u;
 		const uint32_t x = cvh ^ cvh0;

@@ -115,7 +115,7 @@ static void put_static_match(bw_t *w, unsigned len, unsigned off)
 
 /* ---- one parse step ---------------------------------------------------- */
 typedef struct {
-	uint32_t *table;      /* 1 << hash_bits entries, value = position + 1 */
+	uint16_t *table;      /* 1 << hash_bits entries: (position + 1) mod 2^16, 0 = empty */
 	unsigned hash_bits;
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
@@ -154,15 +154,19 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 		if (p + HD_MIN_MATCH > n)
 			continue;
 		uint32_t v = load32(in + p);
-		cand[l] = mf->table[(v * HD_HASH_MUL) >> (32 - mf->hash_bits)];
+		uint32_t e = mf->table[(v * HD_HASH_MUL) >> (32 - mf->hash_bits)];
+		/* the latest p' < p with p' + 1 == e (mod 2^16); for inputs <= 64 KiB
+		 * that is simply e */
+		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
+		cand[l] = (e && back) ? (uint32_t)(p + 1 - back) : 0;
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 2. publish */
 		size_t p = S + l;
 		if (p + HD_MIN_MATCH > n)
 			continue;
-		uint32_t *e = &mf->table[(load32(in + p) * HD_HASH_MUL) >> (32 - mf->hash_bits)];
-		if (*e < p + 1)
-			*e = (uint32_t)(p + 1);
+		/* the kernel's lanes race for the slot and re-write until the largest
+		 * position of the step holds it: within a step the last lane wins */
+		mf->table[(load32(in + p) * HD_HASH_MUL) >> (32 - mf->hash_bits)] = (uint16_t)(p + 1);
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 3. verify */
 		size_t p = S + l;
@@ -211,7 +215,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 4), hash_bits, 1u << win_bits, 0 };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
