@@ -27,7 +27,7 @@
 #define HD_LOOKAHEAD       384         /* >= 64 + 258 + 8, bytes past S     */
 
 /* level 1: static Huffman, streaming emit (no token buffer) */
-#define HD_L1_WIN_BITS     13          /* 8 KiB LDS ring window              */
+#define HD_L1_WIN_BITS     12          /* 4 KiB LDS ring window (occupancy)  */
 #define HD_L1_HASH_BITS    11          /* 2048 x u32 = 8 KiB LDS            */
 
 /* levels >= 2: dynamic Huffman, tokens buffered in a global scratch slab */
