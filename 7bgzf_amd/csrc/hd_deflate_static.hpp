@@ -141,8 +141,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t STG = 256;            // staging ring, dwords
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 
-	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4];
-	__shared__ __attribute__((aligned(16))) uint16_t table[HS];   // (position + 1) mod 2^16, 0 = empty
+	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
+	// unaligned 8-byte read never wrap
+	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
+	// (position + 1) mod 2^16, 0 = empty; slot HS is a dump for lanes with nothing to publish
+	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		limit = cap - hdr - trl;
 
 	// ---- init LDS -------------------------------------------------------
-	for (uint32_t i = lane; i < HS / 8; i += 64)
+	for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
 		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
 	for (uint32_t i = lane; i < STG; i += 64)
 		stage[i] = 0;
@@ -215,7 +218,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		filled += HD_PIECE;
 		if (filled < n)
 			pre = load_slot(src, n, piece + 1, lane, aligned);
-		((uint4 *)ring32)[((piece * HD_PIECE) & (W - 1)) / 16 + lane] = v;
+		const uint32_t ro = (piece * HD_PIECE) & (W - 1);
+		((uint4 *)ring32)[ro / 16 + lane] = v;
+		if (ro == 0 && lane == 0)
+			((uint4 *)ring32)[W / 16] = v;          // mirror of ring bytes [0,16)
 		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 	};
 	// ---- the front of the pipeline -------------------------------------------
@@ -235,32 +241,26 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	auto fetch = [&](uint32_t S_) -> Fetched {
 		Fetched f;
 		const uint32_t p = S_ + lane;
-		const uint32_t pi = p >> 2;
-		const uint32_t w0 = ring32[pi & W4M], w1 = ring32[(pi + 1) & W4M], w2 = ring32[(pi + 2) & W4M];
+		const uint32_t *w = &ring32[(p >> 2) & W4M];
+		const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
 		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
-		const uint32_t h = (f.v * HD_HASH_MUL) >> (32 - HASH_BITS);
-		f.c = 0;
 		const bool can = p + HD_MIN_MATCH <= n;
+		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
 		const uint16_t mine = (uint16_t)(p + 1);
-		if (can) {
-			const uint32_t e = table[h];
-			// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
-			const uint32_t back = (p + 1 - e) & 0xffffu;     // 0: an entry exactly 2^16 back, i.e. stale
-			f.c = (e && back) ? p + 1 - back : 0u;
-			table[h] = mine;
-		}
+		const uint32_t e = table[h];
+		table[h] = mine;
+		// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
+		const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
+		f.c = (can && e && back) ? p + 1 - back : 0u;
 		// settle publish conflicts inside this step (positions differ by < 64)
 		for (;;) {
-			bool again = false;
-			if (can) {
-				const uint16_t now = table[h];
-				again = (uint16_t)(mine - now) - 1u < 0x7fffu;      // mine > now (mod 2^16)
-				if (again)
-					table[h] = mine;
-			}
+			const uint16_t now = table[h];
+			const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;   // mine > now (mod 2^16)
 			if (!__ballot(again))
 				break;
+			if (again)
+				table[h] = mine;
 		}
 		return f;
 	};
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	};
 	auto probe = [&](uint32_t c) -> Probed {
 		Probed q;
-		const uint32_t ci = (c - 1) >> 2;
-		q.c0 = ring32[ci & W4M];
-		q.c1 = ring32[(ci + 1) & W4M];
-		q.c2 = ring32[(ci + 2) & W4M];
+		const uint32_t *w = &ring32[((c - 1) >> 2) & W4M];
+		q.c0 = w[0];
+		q.c1 = w[1];
+		q.c2 = w[2];
 		return q;
 	};
 
@@ -285,8 +285,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		fill_piece();
 		f0 = fetch(0);
 		q0 = probe(f0.c);
-		if (n > 64)
-			f1 = fetch(64);
+		f1 = fetch(64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
 	for (uint32_t S = 0; S < n && use_static; S += 64) {
@@ -299,10 +298,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const Fetched fc = f0;
 		const Probed qc = q0;
 		f0 = f1;
-		if (S + 64 < n)
-			q0 = probe(f1.c);
-		if (S + 128 < n)
-			f1 = fetch(S + 128);
+		q0 = probe(f1.c);                  // harmless beyond n: every index is masked into the ring
+		f1 = fetch(S + 128);
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
 		const uint32_t p = S + lane;
