@@ -1,19 +1,671 @@
-// hd_deflate_dynamic.hpp -- levels >= 2: dynamic Huffman (and lazy parse from 5).
-// PLACEHOLDER WIRING for the first GPU bring-up: until the dynamic kernel lands,
-// levels >= 2 run the level-1 kernel (the CPU twin does the same), so the
-// output is valid and twin-identical at every level.
+// hd_deflate_dynamic.hpp -- levels >= 2: the wave parse of hd_deflate_static.hpp
+// followed by DYNAMIC Huffman coding (BASELINE config 5, "level-6-like").
+//
+// Replaces, for BGZF_METHOD=hip2..9, libdeflate_deflate_compress at levels >= 2:
+// deflate_compress_greedy / _lazy (lib/libdeflate/deflate_compress.c:2530-2809),
+// deflate_make_huffman_code (:1319-1396), the precode / header computation
+// (:1483-1631) and the dynamic branch of deflate_flush_block (:1861-2018).
+// oracle/hd_deflate_twin.c (deflate_dynamic) is the serial statement of exactly
+// this kernel and must produce the same bytes.
+//
+// One wavefront per block, persistent over a grid-stride loop so that every
+// workgroup owns one token slab in HBM:
+//   pass 1  parse (same 64-position step, prefix-scan greedy, optional one-lane
+//           lazy deferral), tokens -> slab (coalesced 4 B/lane), symbol
+//           histograms -> LDS (ds_add_u32)
+//   build   litlen/offset/precode code lengths: rank sort by all lanes, then the
+//           two-queue merge, depth, overflow and RLE steps on lane 0
+//   pass 2  tokens read back 64 at a time, codes looked up in LDS, <= 48 bits
+//           per token placed by a DPP prefix sum as two <= 32-bit fields
+// A DEFLATE block is closed at the first step boundary with >= 32768 tokens.
+// HBM traffic: input once, output once, + 8 B per token for the slab (L2/MALL
+// resident in practice).
 #pragma once
 #include "hd_deflate_static.hpp"
 
 namespace hd {
 
-inline uint64_t dynamic_scratch_bytes(uint32_t, uint32_t, int) { return 0; }
+constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
+
+inline uint32_t dynamic_grid(uint32_t nblocks, int level)
+{
+	// enough resident waves to fill the chip at the LDS footprint of the level
+	const uint32_t per_cu = level >= 5 ? 3u : 7u;
+	const uint32_t slots = 256u * per_cu;
+	return nblocks < slots ? nblocks : slots;
+}
+
+inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t, int level)
+{
+	if (level < 2)
+		return 0;
+	return (uint64_t)dynamic_grid(nblocks, level) * DYN_SLAB_TOKENS * 4;
+}
+
+struct HuffScratch {
+	uint32_t freq[288];      // working copy (dummy symbols added)
+	uint32_t nf[576];        // node weights: leaves ascending, then internal nodes
+	uint16_t parent[576];
+	uint16_t order[288];     // symbols by (freq, symbol)
+	uint8_t depth[576];
+	uint32_t blc[16];
+	uint32_t next[16];
+};
+
+// Code lengths + canonical (bit-reversed) codewords for one alphabet.
+// out[s] = code | len << 16.  Mirrors build_code() of the twin step by step.
+__device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms, uint32_t maxbits, uint32_t *out,
+					 HuffScratch &h, uint32_t lane)
+{
+	// working copy, dummies so that at least two symbols are used
+	uint32_t nu = 0;
+	for (uint32_t base = 0; base < nsyms; base += 64) {
+		const uint32_t s = base + lane;
+		const uint32_t f = s < nsyms ? freq_in[s] : 0;
+		if (s < nsyms)
+			h.freq[s] = f;
+		nu += __popcll(__ballot(f != 0));
+	}
+	if (nu < 2) {
+		if (lane == 0) {
+			if (nu == 0) {
+				h.freq[0] = 1;
+				h.freq[1] = 1;
+			} else {
+				h.freq[h.freq[0] ? 1 : 0] = 1;
+			}
+		}
+		nu = 2;
+	}
+	// rank sort: r = number of used symbols ordered before s
+	for (uint32_t base = 0; base < nsyms; base += 64) {
+		const uint32_t s = base + lane;
+		const uint32_t fs = s < nsyms ? h.freq[s] : 0;
+		uint32_t r = 0;
+		for (uint32_t t = 0; t < nsyms; t++) {
+			const uint32_t ft = h.freq[t];
+			r += (ft != 0 && (ft < fs || (ft == fs && t < s))) ? 1u : 0u;
+		}
+		if (fs) {
+			h.order[r] = (uint16_t)s;
+			h.nf[r] = fs;
+		}
+	}
+	if (lane < 16) {
+		h.blc[lane] = 0;
+		h.next[lane] = 0;
+	}
+	if (lane == 0) {
+		// two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2
+		uint32_t i = 0, j = nu, k = nu;
+		while (k < 2 * nu - 1) {
+			uint32_t pick[2];
+#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				if (i < nu && (j >= k || h.nf[i] <= h.nf[j]))
+					pick[t] = i++;
+				else
+					pick[t] = j++;
+			}
+			h.nf[k] = h.nf[pick[0]] + h.nf[pick[1]];
+			h.parent[pick[0]] = (uint16_t)k;
+			h.parent[pick[1]] = (uint16_t)k;
+			k++;
+		}
+		h.depth[2 * nu - 2] = 0;
+		for (int x = (int)(2 * nu - 3); x >= 0; x--)
+			h.depth[x] = (uint8_t)(h.depth[h.parent[x]] + 1);
+		// level counts, overflow pushed up the tree
+		int overflow = 0;
+		for (uint32_t x = 0; x < nu; x++) {
+			uint32_t d = h.depth[x];
+			if (d > maxbits) {
+				d = maxbits;
+				overflow++;
+			}
+			h.blc[d]++;
+		}
+		while (overflow > 0) {
+			uint32_t bits = maxbits - 1;
+			while (h.blc[bits] == 0)
+				bits--;
+			h.blc[bits]--;
+			h.blc[bits + 1] += 2;
+			h.blc[maxbits]--;
+			overflow -= 2;
+		}
+		// canonical first codes
+		uint32_t code = 0;
+		for (uint32_t bits = 1; bits <= maxbits; bits++) {
+			code = (code + (bits > 1 ? h.blc[bits - 1] : 0)) << 1;
+			h.next[bits] = code;
+		}
+	}
+	// lengths: the leaf at sorted position x gets `bits` where the level counts,
+	// walked from maxbits down, reach x  (smallest frequency = longest code)
+	for (uint32_t base = 0; base < nsyms; base += 64)
+		if (base + lane < nsyms)
+			out[base + lane] = 0;
+	for (uint32_t base = 0; base < nu; base += 64) {
+		const uint32_t x = base + lane;
+		uint32_t acc = 0, bits = 0;
+		for (uint32_t bb = maxbits; bb >= 1; bb--) {
+			const uint32_t c = h.blc[bb];
+			if (bits == 0 && x < acc + c)
+				bits = bb;
+			acc += c;
+		}
+		if (x < nu)
+			out[h.order[x]] = bits << 16;
+	}
+	// canonical codewords in symbol order: next[len] + rank among equal lengths
+	uint32_t run[16];
+#pragma unroll
+	for (int l = 0; l < 16; l++)
+		run[l] = 0;
+	for (uint32_t base = 0; base < nsyms; base += 64) {
+		const uint32_t s = base + lane;
+		const uint32_t len = s < nsyms ? out[s] >> 16 : 0;
+		uint32_t rank = 0;
+#pragma unroll
+		for (int l = 1; l < 16; l++) {
+			const uint64_t m = __ballot(len == (uint32_t)l);
+			if (len == (uint32_t)l)
+				rank = run[l] + __popcll(m & ((1ull << lane) - 1));
+			run[l] += __popcll(m);
+		}
+		if (len) {
+			const uint32_t cw = h.next[len] + rank;
+			out[s] = (len << 16) | (__brev(cw) >> (32 - len));
+		}
+	}
+}
+
+struct DynLds {
+	uint32_t lf[288], df[32];          // histograms of the open DEFLATE block
+	uint32_t lcode[288], dcode[32];    // code | len << 16
+	uint32_t pcode[19], pfreq[19];
+	uint16_t items[288 + 32];          // RLE of the code lengths: symbol | extra << 8
+	uint8_t lens[288 + 32];
+	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen
+	HuffScratch hs;
+};
+
+__constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY>
+__global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
+{
+	constexpr uint32_t W = 1u << WIN_BITS;
+	constexpr uint32_t W4M = W / 4 - 1;
+	constexpr uint32_t HS = 1u << HASH_BITS;
+	constexpr uint32_t STG = 256;
+	constexpr uint32_t FLUSH_DW = 128;
+
+	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
+	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
+	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
+	__shared__ DynLds L;
+	const uint8_t *ring8 = (const uint8_t *)ring32;
+	const uint32_t lane = threadIdx.x;
+	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
+	const CrcTables *ct = a.ct;
+
+	for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+		const uint8_t *src = a.in + a.in_off[b];
+		const uint32_t n = a.in_len[b];
+		const bool aligned = (((uintptr_t)src) & 15) == 0;
+		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
+
+		const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+		uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+		if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
+			cap64 = 65536;
+		const uint32_t cap = (uint32_t)cap64;
+		const uint32_t stored = HD_STORED_SIZE(n);
+		uint32_t limit = stored - 1;
+		bool alive = cap >= hdr + trl + 2;
+		if (alive && cap - hdr - trl < limit)
+			limit = cap - hdr - trl;
+		const uint64_t limit_bits = 8ull * limit;
+
+		// ---- init LDS ---------------------------------------------------
+		for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
+			((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+		for (uint32_t i = lane; i < STG; i += 64)
+			stage[i] = 0;
+		for (uint32_t i = lane; i < 288; i += 64)
+			L.lf[i] = 0;
+		if (lane < 32)
+			L.df[lane] = 0;
+		if (lane < 4 && hdr)
+			stage[lane] = lane == 0 ? 0x04088b1fu : lane == 1 ? 0u
+				: lane == 2 ? (a.frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u)
+					    : (a.frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du);
+
+		CrcLanes crc;
+		crc.init(lane, n);
+		uint32_t filled = 0;
+		uint4 pre = load_slot(src, n, 0, lane, aligned);
+		uint32_t bitpos = 8 * hdr, flushed = 0;
+		const uint32_t paybase = 8 * hdr;
+		uint32_t ntok = 0;
+
+		auto put = [&](uint32_t code, uint32_t nbits, uint32_t bp) {
+			if (nbits) {
+				const uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
+				atomicOr(&stage[i], code << sh);
+				if (sh + nbits > 32)
+					atomicOr(&stage[(i + 1) & (STG - 1)], code >> (32 - sh));
+			}
+		};
+		auto flush_ready = [&]() {
+			if ((bitpos >> 5) - flushed >= FLUSH_DW) {
+				const uint32_t i = (flushed & (STG - 1)) + 2 * lane;
+				const uint2 v = *(const uint2 *)&stage[i];
+				*(uint2 *)&stage[i] = make_uint2(0, 0);
+				*(uint2 *)&dst32[flushed + 2 * lane] = v;
+				flushed += FLUSH_DW;
+			}
+		};
+		// one field per lane (nbits <= 32, 0 = none), in lane order
+		auto emit1 = [&](uint32_t code, uint32_t nbits) {
+			const uint32_t incl = wave_incl_scan(nbits);
+			put(code, nbits, bitpos + incl - nbits);
+			bitpos += readlane(incl, 63);
+			flush_ready();
+		};
+		auto fill_piece = [&]() {
+			const uint32_t piece = filled / HD_PIECE;
+			const uint4 v = pre;
+			filled += HD_PIECE;
+			if (filled < n)
+				pre = load_slot(src, n, piece + 1, lane, aligned);
+			const uint32_t ro = (piece * HD_PIECE) & (W - 1);
+			((uint4 *)ring32)[ro / 16 + lane] = v;
+			if (ro == 0 && lane == 0)
+				((uint4 *)ring32)[W / 16] = v;
+			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+		};
+		struct Fetched {
+			uint32_t v, vh, c;
+		};
+		auto fetch = [&](uint32_t S_) -> Fetched {
+			Fetched f;
+			const uint32_t p = S_ + lane;
+			const uint32_t *w = &ring32[(p >> 2) & W4M];
+			const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+			f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+			f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
+			const bool can = p + HD_MIN_MATCH <= n;
+			const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
+			const uint16_t mine = (uint16_t)(p + 1);
+			const uint32_t e = table[h];
+			table[h] = mine;
+			const uint32_t back = (p + 1 - e) & 0xffffu;
+			f.c = (can && e && back) ? p + 1 - back : 0u;
+			for (;;) {
+				const uint16_t now = table[h];
+				const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;
+				if (!__ballot(again))
+					break;
+				if (again)
+					table[h] = mine;
+			}
+			return f;
+		};
+		struct Probed {
+			uint32_t c0, c1, c2;
+		};
+		auto probe = [&](uint32_t c) -> Probed {
+			Probed q;
+			const uint32_t *w = &ring32[((c - 1) >> 2) & W4M];
+			q.c0 = w[0];
+			q.c1 = w[1];
+			q.c2 = w[2];
+			return q;
+		};
+
+		// Close the open DEFLATE block: build codes, pick dynamic vs static, emit.
+		// Returns false if the member would exceed `limit` (-> stored fallback).
+		auto flush_block = [&](bool final) -> bool {
+			if (lane == 0)
+				L.lf[256] += 1;                     // end of block
+			build_code(L.lf, 288, HD_LITLEN_MAXBITS, L.lcode, L.hs, lane);
+			build_code(L.df, 32, HD_OFFSET_MAXBITS, L.dcode, L.hs, lane);
+			if (lane < 19)
+				L.pfreq[lane] = 0;
+			if (lane == 0) {
+				uint32_t hlit = 286, hdist = 30;
+				while (hlit > 257 && (L.lcode[hlit - 1] >> 16) == 0)
+					hlit--;
+				while (hdist > 1 && (L.dcode[hdist - 1] >> 16) == 0)
+					hdist--;
+				for (uint32_t i = 0; i < hlit; i++)
+					L.lens[i] = (uint8_t)(L.lcode[i] >> 16);
+				for (uint32_t i = 0; i < hdist; i++)
+					L.lens[hlit + i] = (uint8_t)(L.dcode[i] >> 16);
+				const uint32_t total = hlit + hdist;
+				uint32_t ni = 0, i = 0;
+				while (i < total) {
+					const uint32_t v = L.lens[i];
+					uint32_t run = 1;
+					while (i + run < total && L.lens[i + run] == v)
+						run++;
+					i += run;
+					if (v == 0) {
+						while (run >= 11) {
+							const uint32_t r = run < 138 ? run : 138;
+							L.items[ni++] = (uint16_t)(18 | ((r - 11) << 8));
+							L.pfreq[18]++;
+							run -= r;
+						}
+						if (run >= 3) {
+							L.items[ni++] = (uint16_t)(17 | ((run - 3) << 8));
+							L.pfreq[17]++;
+							run = 0;
+						}
+					} else {
+						L.items[ni++] = (uint16_t)v;
+						L.pfreq[v]++;
+						run--;
+						while (run >= 3) {
+							const uint32_t r = run < 6 ? run : 6;
+							L.items[ni++] = (uint16_t)(16 | ((r - 3) << 8));
+							L.pfreq[16]++;
+							run -= r;
+						}
+					}
+					while (run--) {
+						L.items[ni++] = (uint16_t)v;
+						L.pfreq[v]++;
+					}
+				}
+				L.misc[0] = ni;
+				L.misc[1] = hlit;
+				L.misc[2] = hdist;
+			}
+			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, L.hs, lane);
+			const uint32_t ni = uniform(L.misc[0]), hlit = uniform(L.misc[1]), hdist = uniform(L.misc[2]);
+			uint32_t hclen = 19;
+			while (hclen > 4 && (uniform(L.pcode[k_perm19[hclen - 1]]) >> 16) == 0)
+				hclen--;
+			// exact bit costs (extra bits are common to both codes)
+			uint32_t dyn = 0, sta = 0, extra = 0;
+			for (uint32_t base = 0; base < ni; base += 64) {
+				const uint32_t k = base + lane;
+				if (k < ni) {
+					const uint32_t sym = L.items[k] & 31;
+					dyn += (L.pcode[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
+				}
+			}
+			for (uint32_t base = 0; base < 286; base += 64) {
+				const uint32_t s = base + lane;
+				if (s < 286) {
+					const uint32_t f = L.lf[s];
+					dyn += f * (L.lcode[s] >> 16);
+					sta += f * (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
+					if (s >= 265 && s < 285)
+						extra += f * ((s - 261) >> 2);
+				}
+			}
+			if (lane < 30) {
+				const uint32_t f = L.df[lane];
+				dyn += f * (L.dcode[lane] >> 16);
+				sta += f * 5u;
+				extra += f * (lane < 4 ? 0u : (lane >> 1) - 1);
+			}
+			dyn = readlane(wave_incl_scan(dyn), 63) + 3 + 5 + 5 + 4 + 3 * hclen;
+			sta = readlane(wave_incl_scan(sta), 63) + 3;
+			extra = readlane(wave_incl_scan(extra), 63);
+			const bool use_dynamic = dyn < sta;
+			const uint64_t blockbits = (uint64_t)(use_dynamic ? dyn : sta) + extra;
+			if ((uint64_t)(bitpos - paybase) + blockbits > limit_bits)
+				return false;
+			if (use_dynamic) {
+				// BFINAL, BTYPE=10, HLIT, HDIST, HCLEN in lanes 0..4, then the precode lengths
+				uint32_t c0 = 0, n0 = 0;
+				if (lane == 0) { c0 = final ? 1u : 0u; n0 = 1; }
+				else if (lane == 1) { c0 = 2; n0 = 2; }
+				else if (lane == 2) { c0 = hlit - 257; n0 = 5; }
+				else if (lane == 3) { c0 = hdist - 1; n0 = 5; }
+				else if (lane == 4) { c0 = hclen - 4; n0 = 4; }
+				else if (lane < 5 + hclen) { c0 = L.pcode[k_perm19[lane - 5]] >> 16; n0 = 3; }
+				emit1(c0, n0);
+				for (uint32_t base = 0; base < ni; base += 64) {
+					const uint32_t k = base + lane;
+					uint32_t cc = 0, nn = 0;
+					if (k < ni) {
+						const uint32_t it = L.items[k], sym = it & 31;
+						const uint32_t pc = L.pcode[sym];
+						cc = (pc & 0xffff) | ((it >> 8) << (pc >> 16));
+						nn = (pc >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
+					}
+					emit1(cc, nn);
+				}
+			} else {
+				emit1(lane == 0 ? (final ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
+				// static code tables in the same format
+				for (uint32_t s = lane; s < 288; s += 64) {
+					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
+					const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
+					L.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
+				}
+				if (lane < 32)
+					L.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
+			}
+			// ---- pass 2: the tokens -------------------------------------------
+			for (uint32_t base = 0; base < ntok; base += 64) {
+				const uint32_t k = base + lane;
+				uint32_t ca = 0, na = 0, cb = 0, nb = 0;
+				if (k < ntok) {
+					const uint32_t tk = tok[k];
+					if (tk & HD_TOKEN_MATCH) {
+						uint32_t ls, leb, lev, ds, deb, dev;
+						len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
+						off_slot((tk & 0xffff) + 1, ds, deb, dev);
+						const uint32_t lc = L.lcode[257 + ls], dc = L.dcode[ds];
+						ca = (lc & 0xffff) | (lev << (lc >> 16));
+						na = (lc >> 16) + leb;
+						cb = (dc & 0xffff) | (dev << (dc >> 16));
+						nb = (dc >> 16) + deb;
+					} else {
+						const uint32_t lc = L.lcode[tk & 0xff];
+						ca = lc & 0xffff;
+						na = lc >> 16;
+					}
+				}
+				const uint32_t incl = wave_incl_scan(na + nb);
+				const uint32_t at = bitpos + incl - (na + nb);
+				put(ca, na, at);
+				put(cb, nb, at + na);
+				bitpos += readlane(incl, 63);
+				flush_ready();
+			}
+			{
+				const uint32_t eob = L.lcode[256];
+				emit1(lane == 0 ? (eob & 0xffff) : 0u, lane == 0 ? (eob >> 16) : 0u);
+			}
+			for (uint32_t i = lane; i < 288; i += 64)
+				L.lf[i] = 0;
+			if (lane < 32)
+				L.df[lane] = 0;
+			ntok = 0;
+			return true;
+		};
+
+		// ---- pass 1: the parse ------------------------------------------------
+		Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
+		Probed q0 = { 0, 0, 0 };
+		if (alive && n) {
+			fill_piece();
+			f0 = fetch(0);
+			q0 = probe(f0.c);
+			f1 = fetch(64);
+		}
+		uint32_t carry = 0;
+		for (uint32_t S = 0; S < n && alive; S += 64) {
+			if (filled < n && filled < S + HD_LOOKAHEAD)
+				fill_piece();
+			const uint32_t lo = filled > W ? filled - W : 0;
+			const uint32_t lanes = n - S < 64 ? n - S : 64;
+			const Fetched fc = f0;
+			const Probed qc = q0;
+			f0 = f1;
+			q0 = probe(f1.c);
+			f1 = fetch(S + 128);
+
+			const uint32_t p = S + lane;
+			const bool can = p + HD_MIN_MATCH <= n;
+			const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
+			const bool had = can && fc.c != 0 && cp >= lo;
+			const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
+			const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
+			const uint32_t x = cvh ^ cvh0;
+			const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
+			const uint32_t room = n - p;
+			uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
+			bool ok = had && cv == cv0 && mylen >= (uint32_t)MINLEN;
+			if (LAZY) {
+				// a candidate steps aside when its right neighbour's 8-byte length is longer
+				const uint32_t l8 = ok ? (mylen < 8 ? mylen : 8u) : 0u;
+				const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l8, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+				const bool defer = ok && lane + 1 < lanes && nx > l8;
+				ok = ok && !defer;
+			}
+			const uint32_t dist = ok ? p - cp : 1u;
+
+			if (carry >= lanes) {
+				carry -= lanes;
+			} else {
+				const bool capped = ok && eqb == 4 && room > 8;
+				const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;
+				uint64_t starts;
+				{
+					const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1));
+					const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138, 0xf, 0xf, false);
+					starts = __ballot(sin == 0 && lane >= carry);
+				}
+				const uint64_t capmask = __ballot(capped);
+				uint64_t cm = starts & capmask;
+				while (cm) {
+					const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
+					const uint32_t dm = readlane(dist, m);
+					const uint32_t pm = S + m;
+					const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+					uint32_t len = 8;
+					for (;;) {
+						const uint32_t idx = len + lane;
+						bool diff = true;
+						if (idx < maxlen)
+							diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
+						const uint64_t nq = __ballot(diff);
+						const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
+						len += k;
+						if (k < 64)
+							break;
+					}
+					const uint64_t upto_m = (2ull << m) - 1;
+					if (len > 8) {
+						if (lane == m)
+							mylen = len;
+						const uint32_t q = m + len;
+						uint64_t fresh = 0;
+						uint32_t xx = q;
+						while (xx < 64 && !((starts >> xx) & 1)) {
+							fresh |= 1ull << xx;
+							xx += readlane(jump8, xx);
+						}
+						const uint64_t below_x = xx >= 64 ? ~0ull : ((1ull << xx) - 1);
+						starts = (starts & (upto_m | ~below_x)) | fresh;
+					}
+					cm = starts & capmask & ~upto_m;
+				}
+				const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);
+				const uint32_t E = last + readlane(ok ? mylen : 1u, last);
+				const bool is_start = (starts >> lane) & 1;
+				const bool is_match = is_start && ok;
+				const bool is_lit = is_start && !ok && lane < lanes;
+				carry = (lanes == 64 && E > 64) ? E - 64 : 0;
+
+				// tokens -> slab (compacted in lane order), symbols -> histograms
+				const bool is_tok = is_match || is_lit;
+				const uint64_t tm = __ballot(is_tok);
+				const uint32_t at = ntok + __popcll(tm & ((1ull << lane) - 1));
+				if (is_match) {
+					uint32_t ls, leb, lev, ds, deb, dev;
+					len_slot(mylen, ls, leb, lev);
+					off_slot(dist, ds, deb, dev);
+					tok[at] = HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1);
+					atomicAdd(&L.lf[257 + ls], 1u);
+					atomicAdd(&L.df[ds], 1u);
+				} else if (is_lit) {
+					tok[at] = cv0 & 0xff;
+					atomicAdd(&L.lf[cv0 & 0xff], 1u);
+				}
+				ntok += __popcll(tm);
+			}
+			if (ntok >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
+				// our own token stores must be visible to our own loads
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				alive = flush_block(false);
+			}
+		}
+		if (alive) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			alive = flush_block(true);
+		}
+
+		while (filled < n) {
+			const uint32_t piece = filled / HD_PIECE;
+			const uint4 pv = pre;
+			filled += HD_PIECE;
+			if (filled < n)
+				pre = load_slot(src, n, piece + 1, lane, aligned);
+			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
+		}
+		const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
+
+		if (!alive) {
+			write_stored_member(a, b, src, n, crcv, lane);
+			continue;
+		}
+		bitpos = (bitpos + 7) & ~7u;
+		const uint32_t paylen = (bitpos - paybase) >> 3;
+		if (trl) {
+			uint32_t tcode = 0, nb = 0;
+			if (lane < 4) {
+				tcode = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
+				nb = 16;
+			}
+			emit1(tcode, nb);
+		}
+		for (uint32_t i = flushed + lane; i < ((bitpos + 31) >> 5); i += 64)
+			dst32[i] = stage[i & (STG - 1)];
+		if (lane == 0) {
+			const uint32_t total = hdr + paylen + trl;
+			if (a.frame == HD_FRAME_BGZF)
+				*(uint16_t *)((uint8_t *)dst32 + 16) = (uint16_t)(total - 1);
+			else if (a.frame == HD_FRAME_MIGZ)
+				dst32[4] = paylen;
+			a.out_len[b] = total;
+			if (a.status) a.status[b] = 0;
+			if (a.crc) a.crc[b] = crcv;
+		}
+	}
+}
 
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
-	DeflateArgs b = a;
-	b.level = level;
-	hipLaunchKernelGGL((k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS>), dim3(a.nblocks), dim3(64), 0, st, b);
+	const uint32_t grid = dynamic_grid(a.nblocks, level);
+	if (level <= 4)
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0>), dim3(grid), dim3(64),
+				   0, st, a);
+	else
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1>), dim3(grid), dim3(64),
+				   0, st, a);
 	return 0;
 }
 

@@ -30,14 +30,25 @@
 #define HD_L1_WIN_BITS     12          /* 4 KiB LDS ring window (occupancy)  */
 #define HD_L1_HASH_BITS    11          /* 2048 x u32 = 8 KiB LDS            */
 
-/* levels >= 2: dynamic Huffman, tokens buffered in a global scratch slab */
-#define HD_L2_WIN_BITS     15          /* 32 KiB ring: full DEFLATE window  */
-#define HD_L2_HASH_BITS    12
+/* levels 2..4: greedy parse, dynamic Huffman; tokens buffered in a per-wave
+ * scratch slab in HBM between the parse and the emit pass */
+#define HD_L2_WIN_BITS     13          /* 8 KiB ring                         */
+#define HD_L2_HASH_BITS    11
+#define HD_L2_MIN_LEN      4
+/* levels 5..9: one-lane-lookahead lazy parse, dynamic Huffman */
+#define HD_L5_WIN_BITS     15          /* 32 KiB ring: the full DEFLATE window */
+#define HD_L5_HASH_BITS    12
+#define HD_L5_MIN_LEN      5
 
 #define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
 
-/* a DEFLATE block of the dynamic path ends after this many tokens */
-#define HD_DYN_MAX_TOKENS  (1u << 16)
+/* a DEFLATE block of the dynamic path is closed at the first step boundary at
+ * which it holds at least this many tokens (scratch slab = this + 64 tokens) */
+#define HD_DYN_BLOCK_TOKENS (1u << 15)
+#define HD_TOKEN_MATCH     0x80000000u /* token: literal byte | MATCH | (len-3)<<16 | (dist-1) */
+#define HD_LITLEN_MAXBITS  15
+#define HD_OFFSET_MAXBITS  15
+#define HD_PRECODE_MAXBITS 7
 
 /* worst-case bits one parse step can emit with the static code:
  * 64 tokens x (8+5 + 5+13 = 31 bits) */

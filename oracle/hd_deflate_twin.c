@@ -135,10 +135,11 @@ static uint32_t load32(const uint8_t *p)
 	return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry, step_t *st)
+static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
+		       unsigned minlen, int lazy, step_t *st)
 {
 	uint32_t cand[HD_WAVE];
-	uint8_t ok[HD_WAVE];
+	uint8_t ok[HD_WAVE], cap8[HD_WAVE];
 	unsigned lanes = n - S < HD_WAVE ? (unsigned)(n - S) : HD_WAVE;
 
 	/* the ring is refilled a 1 KiB piece at a time until it holds
@@ -177,8 +178,25 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 			continue;
 		if (load32(in + c) != load32(in + p))
 			continue;
+		/* what the 64 lanes learn in parallel: the length up to 8 */
+		unsigned room = n - p < 8 ? (unsigned)(n - p) : 8, l8 = 4;
+		while (l8 < room && in[p + l8] == in[c + l8])
+			l8++;
+		if (l8 < minlen)
+			continue;
 		ok[l] = 1;
+		cap8[l] = (uint8_t)l8;
 		st->dist[l] = (uint32_t)(p - c);
+	}
+	if (lazy) {
+		/* one-lane lookahead: a candidate steps aside (becomes a literal) when
+		 * its right neighbour's match is longer, judged on the 8-byte lengths */
+		uint8_t defer[HD_WAVE];
+		for (unsigned l = 0; l < lanes; l++)
+			defer[l] = ok[l] && l + 1 < lanes && ok[l + 1] && cap8[l + 1] > cap8[l];
+		for (unsigned l = 0; l < lanes; l++)
+			if (defer[l])
+				ok[l] = 0;
 	}
 	unsigned E = carry;                             /* 4. greedy */
 	for (unsigned l = 0; l < lanes; l++) {
@@ -204,6 +222,8 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	st->carry_out = E > lanes ? E - lanes : 0;   /* E >= carry always */
 }
 
+static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n);
+
 /* ---- level 1: greedy + static Huffman, streaming ------------------------ */
 static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
 			  unsigned win_bits, unsigned hash_bits)
@@ -225,7 +245,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	bw_put(&w, 1, 2);       /* BTYPE = 01 */
 	unsigned carry = 0;
 	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
-		parse_step(&mf, in, n, S, carry, &st);
+		parse_step(&mf, in, n, S, carry, HD_MIN_MATCH, 0, &st);
 		carry = st.carry_out;
 		/* the kernel knows the step's bit count (wave prefix sum) before it
 		 * writes anything; once the stream plus the end-of-block code can no
@@ -256,23 +276,335 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 		bw_put(&w, 0, 7);  /* end of block */
 		*destLen = (size_t)((w.bitpos + 7) >> 3);
 		memcpy(dest, tmp, *destLen);
-	} else if (stored <= cap) {
-		/* one BFINAL-terminated run of stored blocks; an empty input still
-		 * gets its one empty stored block here (unlike store_deflate) */
-		size_t o = 0, left = n;
-		do {
-			size_t blk = left < 65535 ? left : 65535;
-			dest[o] = left - blk ? 0 : 1;
-			dest[o + 1] = blk & 0xff; dest[o + 2] = blk >> 8;
-			dest[o + 3] = ~blk & 0xff; dest[o + 4] = (~blk >> 8) & 0xff;
-			memcpy(dest + o + 5, in + (n - left), blk);
-			o += 5 + blk;
-			left -= blk;
-		} while (left);
-		*destLen = o;
 	} else {
-		ret = 1;            /* !Z_OK, as libdeflate_deflate lib/zlibutil.c:189 */
+		ret = write_stored(dest, destLen, in, n);
 	}
+	free(mf.table);
+	free(tmp);
+	return ret;
+}
+
+/* ---- levels >= 2: dynamic Huffman ------------------------------------------
+ * Role of deflate_make_huffman_code (deflate_compress.c:1319-1396),
+ * deflate_precompute_huffman_header (:1571-1631) and the dynamic branch of
+ * deflate_flush_block (:1861-1926), restated with the (deliberately simple,
+ * serial) algorithms the kernel runs on one lane:
+ *   - symbols sorted by (frequency, symbol) through an explicit rank,
+ *   - two-queue Huffman merge, depths from parent links,
+ *   - lengths limited by moving overflow up the tree level counts,
+ *   - canonical codewords in symbol order,
+ *   - greedy RLE of the code lengths with precode symbols 16/17/18. */
+typedef struct {
+	uint8_t len[288];
+	uint16_t code[288];    /* bit-reversed, ready for the LSB-first writer */
+} huff_t;
+
+static void build_code(const uint32_t *freq_in, unsigned nsyms, unsigned maxbits, huff_t *h)
+{
+	uint32_t freq[288];
+	uint16_t order[288];
+	uint32_t nf[576];
+	uint16_t parent[576];
+	uint8_t depth[576];
+	unsigned blc[16] = { 0 };
+	unsigned nu = 0;
+
+	memcpy(freq, freq_in, nsyms * 4);
+	for (unsigned s = 0; s < nsyms; s++)
+		nu += freq[s] != 0;
+	/* at least two codewords (old decoders; deflate_compress.c:1369-1378) */
+	if (nu == 0) {
+		freq[0] = freq[1] = 1;
+	} else if (nu == 1) {
+		freq[freq[0] ? 1 : 0] = 1;
+	}
+	nu = 0;
+	for (unsigned s = 0; s < nsyms; s++)
+		nu += freq[s] != 0;
+	/* rank = number of used symbols that sort before s */
+	for (unsigned s = 0; s < nsyms; s++) {
+		if (!freq[s])
+			continue;
+		unsigned r = 0;
+		for (unsigned t = 0; t < nsyms; t++)
+			if (freq[t] && (freq[t] < freq[s] || (freq[t] == freq[s] && t < s)))
+				r++;
+		order[r] = (uint16_t)s;
+	}
+	for (unsigned i = 0; i < nu; i++)
+		nf[i] = freq[order[i]];
+	/* two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2 */
+	unsigned i = 0, j = nu, k = nu;
+	while (k < 2 * nu - 1) {
+		unsigned pick[2];
+		for (int t = 0; t < 2; t++) {
+			if (i < nu && (j >= k || nf[i] <= nf[j]))
+				pick[t] = i++;
+			else
+				pick[t] = j++;
+		}
+		nf[k] = nf[pick[0]] + nf[pick[1]];
+		parent[pick[0]] = parent[pick[1]] = (uint16_t)k;
+		k++;
+	}
+	depth[2 * nu - 2] = 0;
+	for (int x = (int)(2 * nu - 3); x >= 0; x--)
+		depth[x] = (uint8_t)(depth[parent[x]] + 1);
+	/* level counts, overflow pushed up */
+	int overflow = 0;
+	for (unsigned x = 0; x < nu; x++) {
+		unsigned d = depth[x];
+		if (d > maxbits) {
+			d = maxbits;
+			overflow++;
+		}
+		blc[d]++;
+	}
+	while (overflow > 0) {
+		unsigned bits = maxbits - 1;
+		while (blc[bits] == 0)
+			bits--;
+		blc[bits]--;
+		blc[bits + 1] += 2;
+		blc[maxbits]--;
+		overflow -= 2;
+	}
+	memset(h->len, 0, sizeof(h->len));
+	unsigned idx = 0;
+	for (unsigned bits = maxbits; bits >= 1; bits--)
+		for (unsigned c = blc[bits]; c; c--)
+			h->len[order[idx++]] = (uint8_t)bits;
+	/* canonical codewords */
+	unsigned next[17] = { 0 }, code = 0;
+	for (unsigned bits = 1; bits <= maxbits; bits++) {
+		code = (code + blc[bits - 1]) << 1;
+		next[bits] = code;
+	}
+	blc[0] = 0;
+	memset(h->code, 0, sizeof(h->code));
+	for (unsigned s = 0; s < nsyms; s++)
+		if (h->len[s])
+			h->code[s] = (uint16_t)bitrev(next[h->len[s]]++, h->len[s]);
+}
+
+static const uint8_t precode_perm[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+/* RLE items: low 5 bits symbol, bits 8.. extra value */
+static unsigned rle_lens(const uint8_t *lens, unsigned total, uint16_t *items, uint32_t *pfreq)
+{
+	unsigned ni = 0, i = 0;
+	while (i < total) {
+		unsigned v = lens[i], run = 1;
+		while (i + run < total && lens[i + run] == v)
+			run++;
+		i += run;
+		if (v == 0) {
+			while (run >= 11) {
+				unsigned r = run < 138 ? run : 138;
+				items[ni++] = (uint16_t)(18 | ((r - 11) << 8));
+				pfreq[18]++;
+				run -= r;
+			}
+			if (run >= 3) {
+				items[ni++] = (uint16_t)(17 | ((run - 3) << 8));
+				pfreq[17]++;
+				run = 0;
+			}
+		} else {
+			items[ni++] = (uint16_t)v;
+			pfreq[v]++;
+			run--;
+			while (run >= 3) {
+				unsigned r = run < 6 ? run : 6;
+				items[ni++] = (uint16_t)(16 | ((r - 3) << 8));
+				pfreq[16]++;
+				run -= r;
+			}
+		}
+		while (run--) {
+			items[ni++] = (uint16_t)v;
+			pfreq[v]++;
+		}
+	}
+	return ni;
+}
+
+typedef struct {
+	uint32_t lf[288], df[32];
+	uint32_t *tok;
+	unsigned ntok;
+} dynblk_t;
+
+static void static_lens(uint8_t *ll, uint8_t *dl)
+{
+	for (unsigned s = 0; s < 288; s++)
+		ll[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+	for (unsigned s = 0; s < 32; s++)
+		dl[s] = 5;
+}
+
+/* emit one DEFLATE block from the token slab; returns 0 if it would push the
+ * payload past `limit` bytes (the kernel then abandons for the stored form) */
+static int flush_dyn_block(bw_t *w, dynblk_t *b, int final, uint64_t limit_bits)
+{
+	huff_t lh, dh, ph;
+	uint16_t items[288 + 32];
+	uint32_t pfreq[19] = { 0 };
+	uint8_t lens[288 + 32];
+	static const uint8_t lextra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+	static const uint8_t dextra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+	b->lf[256]++;                                   /* end of block */
+	build_code(b->lf, 288, HD_LITLEN_MAXBITS, &lh);
+	build_code(b->df, 32, HD_OFFSET_MAXBITS, &dh);
+	unsigned hlit = 286, hdist = 30;
+	while (hlit > 257 && lh.len[hlit - 1] == 0)
+		hlit--;
+	while (hdist > 1 && dh.len[hdist - 1] == 0)
+		hdist--;
+	memcpy(lens, lh.len, hlit);
+	memcpy(lens + hlit, dh.len, hdist);
+	unsigned ni = rle_lens(lens, hlit + hdist, items, pfreq);
+	build_code(pfreq, 19, HD_PRECODE_MAXBITS, &ph);
+	unsigned hclen = 19;
+	while (hclen > 4 && ph.len[precode_perm[hclen - 1]] == 0)
+		hclen--;
+	/* exact costs: extra bits are common to both codes */
+	uint64_t extra = 0, dyn = 3 + 5 + 5 + 4 + 3 * hclen, sta = 3;
+	uint8_t sl[288], sd[32];
+	static_lens(sl, sd);
+	for (unsigned k = 0; k < ni; k++) {
+		unsigned sym = items[k] & 31;
+		dyn += ph.len[sym] + (sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0);
+	}
+	for (unsigned s = 0; s < 286; s++) {
+		dyn += (uint64_t)b->lf[s] * lh.len[s];
+		sta += (uint64_t)b->lf[s] * sl[s];
+		if (s >= 257)
+			extra += (uint64_t)b->lf[s] * lextra[s - 257];
+	}
+	for (unsigned s = 0; s < 30; s++) {
+		dyn += (uint64_t)b->df[s] * dh.len[s];
+		sta += (uint64_t)b->df[s] * sd[s];
+		extra += (uint64_t)b->df[s] * dextra[s];
+	}
+	int use_dynamic = dyn < sta;                    /* tie -> static (deflate_compress.c:1861-1867) */
+	uint64_t blockbits = (use_dynamic ? dyn : sta) + extra;
+	if (w->bitpos + blockbits > limit_bits)
+		return 0;
+	bw_put(w, final ? 1 : 0, 1);
+	if (use_dynamic) {
+		bw_put(w, 2, 2);
+		bw_put(w, hlit - 257, 5);
+		bw_put(w, hdist - 1, 5);
+		bw_put(w, hclen - 4, 4);
+		for (unsigned k = 0; k < hclen; k++)
+			bw_put(w, ph.len[precode_perm[k]], 3);
+		for (unsigned k = 0; k < ni; k++) {
+			unsigned sym = items[k] & 31, ev = items[k] >> 8;
+			bw_put(w, ph.code[sym], ph.len[sym]);
+			if (sym == 16) bw_put(w, ev, 2);
+			else if (sym == 17) bw_put(w, ev, 3);
+			else if (sym == 18) bw_put(w, ev, 7);
+		}
+	} else {
+		bw_put(w, 1, 2);
+		static_lens(lh.len, dh.len);
+		for (unsigned s = 0; s < 288; s++) {
+			uint32_t c; unsigned nn;
+			static_litlen(s, &c, &nn);
+			lh.code[s] = (uint16_t)c;
+		}
+		for (unsigned s = 0; s < 32; s++)
+			dh.code[s] = (uint16_t)bitrev(s, 5);
+	}
+	for (unsigned t = 0; t < b->ntok; t++) {
+		uint32_t tk = b->tok[t];
+		if (!(tk & HD_TOKEN_MATCH)) {
+			bw_put(w, lh.code[tk & 0xff], lh.len[tk & 0xff]);
+			continue;
+		}
+		unsigned sym, eb, ev;
+		len_slot(((tk >> 16) & 0xff) + 3, &sym, &eb, &ev);
+		bw_put(w, lh.code[sym], lh.len[sym]);
+		bw_put(w, ev, eb);
+		off_slot((tk & 0xffff) + 1, &sym, &eb, &ev);
+		bw_put(w, dh.code[sym], dh.len[sym]);
+		bw_put(w, ev, eb);
+	}
+	bw_put(w, lh.code[256], lh.len[256]);
+	memset(b->lf, 0, sizeof(b->lf));
+	memset(b->df, 0, sizeof(b->df));
+	b->ntok = 0;
+	return 1;
+}
+
+static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n)
+{
+	/* one BFINAL-terminated run of stored blocks; an empty input still gets its
+	 * one empty stored block here (unlike store_deflate) */
+	if (HD_STORED_SIZE(n) > *destLen)
+		return 1;           /* !Z_OK, as libdeflate_deflate lib/zlibutil.c:189 */
+	size_t o = 0, left = n;
+	do {
+		size_t blk = left < 65535 ? left : 65535;
+		dest[o] = left - blk ? 0 : 1;
+		dest[o + 1] = blk & 0xff; dest[o + 2] = blk >> 8;
+		dest[o + 3] = ~blk & 0xff; dest[o + 4] = (~blk >> 8) & 0xff;
+		memcpy(dest + o + 5, in + (n - left), blk);
+		o += 5 + blk;
+		left -= blk;
+	} while (left);
+	*destLen = o;
+	return 0;
+}
+
+static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
+			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy)
+{
+	size_t cap = *destLen;
+	size_t stored = HD_STORED_SIZE(n);
+	size_t limit = cap < stored - 1 ? cap : stored - 1;
+	uint8_t *tmp = calloc(1, limit + 64);
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
+	dynblk_t b;
+	bw_t w = { tmp, 0 };
+	step_t st;
+	int alive = 1;
+
+	memset(&b, 0, sizeof(b));
+	b.tok = malloc((HD_DYN_BLOCK_TOKENS + 64) * 4);
+	unsigned carry = 0;
+	for (size_t S = 0; S < n && alive; S += HD_WAVE) {
+		parse_step(&mf, in, n, S, carry, minlen, lazy, &st);
+		carry = st.carry_out;
+		for (unsigned l = 0; l < st.lanes; l++) {
+			if (st.is_match[l]) {
+				unsigned sym, eb, ev;
+				b.tok[b.ntok++] = HD_TOKEN_MATCH | ((uint32_t)(st.len[l] - 3) << 16) | (st.dist[l] - 1);
+				len_slot(st.len[l], &sym, &eb, &ev);
+				b.lf[sym]++;
+				off_slot(st.dist[l], &sym, &eb, &ev);
+				b.df[sym]++;
+			} else if (st.is_lit[l]) {
+				b.tok[b.ntok++] = in[S + l];
+				b.lf[in[S + l]]++;
+			}
+		}
+		if (b.ntok >= HD_DYN_BLOCK_TOKENS && S + HD_WAVE < n)
+			alive = flush_dyn_block(&w, &b, 0, 8 * (uint64_t)limit);
+	}
+	if (alive)
+		alive = flush_dyn_block(&w, &b, 1, 8 * (uint64_t)limit);
+	int ret;
+	if (alive) {
+		*destLen = (size_t)((w.bitpos + 7) >> 3);
+		memcpy(dest, tmp, *destLen);
+		ret = 0;
+	} else {
+		ret = write_stored(dest, destLen, in, n);
+	}
+	free(b.tok);
 	free(mf.table);
 	free(tmp);
 	return ret;
@@ -281,26 +613,13 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level)
 {
-	if (level <= 0) {
-		size_t stored = HD_STORED_SIZE(sourceLen);
-		if (stored > *destLen)
-			return 1;
-		size_t cap0 = 0; /* force the stored branch */
-		(void)cap0;
-		/* level 0 = the stored branch of the level-1 encoder */
-		size_t o = 0, left = sourceLen;
-		do {
-			size_t blk = left < 65535 ? left : 65535;
-			dest[o] = left - blk ? 0 : 1;
-			dest[o + 1] = blk & 0xff; dest[o + 2] = blk >> 8;
-			dest[o + 3] = ~blk & 0xff; dest[o + 4] = (~blk >> 8) & 0xff;
-			memcpy(dest + o + 5, source + (sourceLen - left), blk);
-			o += 5 + blk;
-			left -= blk;
-		} while (left);
-		*destLen = o;
-		return 0;
-	}
-	return deflate_static(dest, destLen, source, sourceLen,
-			      HD_L1_WIN_BITS, HD_L1_HASH_BITS);
+	if (level <= 0)
+		return write_stored(dest, destLen, source, sourceLen);   /* level 0 = the stored branch */
+	if (level == 1)
+		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS);
+	if (level <= 4)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
+				       HD_L2_MIN_LEN, 0);
+	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
+			       HD_L5_MIN_LEN, 1);
 }
