@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-BLOCK = 0xff00                 # applet/7bgzf.c:146-147
+BLOCK = 0xff00                 # applet/7bgzf.c:146-147 (overridden by --block-kib for MiGz)
 
 
 def parse():
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--gib", type=float, default=16.0, help="input GiB per GPU")
     ap.add_argument("--tile-mib", type=int, default=64, help="host-generated tile replicated on the device")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--data", default="fastq", choices=["fastq", "text", "random"],
+                    help="fastq = configs[1..3]; text = config 5 (enwik-like); random = config 1 stand-in")
+    ap.add_argument("--block-kib", type=int, default=0, help="0 = BGZF 0xff00-byte blocks; else MiGz blocks of N KiB")
     return ap.parse_args()
 
 
@@ -129,7 +132,10 @@ def cpu_baseline(tile, level, mode, sample_budget_s=16.0):
 
 
 def main():
+    global BLOCK
     args = parse()
+    if args.block_kib:
+        BLOCK = args.block_kib * 1024
     import torch
     import torch.distributed as dist
 
@@ -148,7 +154,12 @@ def main():
 
     # ---- synthetic input: a seeded FASTQ-like tile replicated to G GiB in HBM ---------
     tile_bytes = args.tile_mib << 20
-    tile_np = synth.fastq_like(tile_bytes, seed=1234 + rank, first_record=1 + rank * 10_000_000)
+    if args.data == "fastq":
+        tile_np = synth.fastq_like(tile_bytes, seed=1234 + rank, first_record=1 + rank * 10_000_000)
+    elif args.data == "text":
+        tile_np = synth.text_like(tile_bytes, seed=4321 + rank)
+    else:
+        tile_np = synth.random_bytes(tile_bytes, seed=99 + rank)
     assert len(tile_np) == tile_bytes
     total = int(args.gib * (1 << 30))
     reps = max(1, total // tile_bytes)
@@ -160,22 +171,26 @@ def main():
     off, ln = dev.block_table(total, BLOCK)
     nb = off.numel()
 
-    enc = dev.DeviceDeflate(nb)
+    frame = pkg.FRAME_MIGZ if args.block_kib else pkg.FRAME_BGZF
+    hdr = 20 if args.block_kib else 18
+    slot = 65536 if not args.block_kib else ((BLOCK + BLOCK // 8 + 4096 + 15) & ~15)
+    enc = dev.DeviceDeflate(nb, slot=slot)
     if args.mode == "encode":
         level = args.level
-        packed = torch.empty(int(total * (0.62 if level >= 1 else 1.01)) + (1 << 20), dtype=torch.uint8, device="cuda")
+        packed = torch.empty(int(total * (0.75 if (level >= 1 and args.data != "random") else 1.01)) + (1 << 20),
+                             dtype=torch.uint8, device="cuda")
     else:
         # decode: the stream to inflate is produced once, untimed, by our own encoder at
         # --level (valid RFC 1951 multi-member BGZF); it then stays resident in HBM
         level = args.level
-        enc.run(data, off, ln, level=level, frame=pkg.FRAME_BGZF)
+        enc.run(data, off, ln, level=level, frame=frame)
         enc.scan()
         torch.cuda.synchronize()
         comp_total = int(enc.total.item())
         packed = torch.empty(comp_total + 16, dtype=torch.uint8, device="cuda")
         enc.compact(packed)
-        in_off = enc.dst_off + 18
-        in_len = (enc.out_len - 18).to(torch.int32)
+        in_off = enc.dst_off + hdr
+        in_len = (enc.out_len - hdr).to(torch.int32)
         out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
         crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
         st = torch.zeros(nb, dtype=torch.int32, device="cuda")
@@ -190,7 +205,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if args.mode == "encode":
             e0.record()
-            enc.run(data, off, ln, level=level, frame=pkg.FRAME_BGZF)
+            enc.run(data, off, ln, level=level, frame=frame)
             e1.record()
             enc.scan()
             if world > 1:
@@ -251,16 +266,21 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "GB/s input compressed, BGZF 64KiB blocks" if args.mode == "encode"
-            else "GB/s output produced, BGZF 64KiB blocks (inflate)",
+            "metric": ("GB/s input compressed, %s blocks" if args.mode == "encode"
+                       else "GB/s output produced, %s blocks (inflate)") % (
+                           "BGZF 64KiB" if not args.block_kib else "MiGz %d KiB" % args.block_kib),
             "value": round(gbs, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BGZF %s, 0xff00-byte blocks, %s, %.2f GiB FASTQ-like per GPU (seeded generator, "
+            "config": {"workload": "%s %s, %s blocks, %s, %.2f GiB %s per GPU (seeded generator, "
                                    "%d MiB tile x %d), %d blocks/GPU, HBM-resident" % (
-                                       args.mode,
-                                       ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else "level %d" % level,
-                                       total / 2 ** 30, args.tile_mib, reps, nb),
+                                       "MiGz" if args.block_kib else "BGZF", args.mode,
+                                       ("%d KiB" % args.block_kib) if args.block_kib else "0xff00-byte",
+                                       ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else
+                                       ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy" if level >= 5 else "greedy")) if level >= 2
+                                       else "level 0: stored",
+                                       total / 2 ** 30, {"fastq": "FASTQ-like", "text": "enwik-like text", "random": "random bytes"}[args.data],
+                                       args.tile_mib, reps, nb),
                        "blocks_per_gpu": nb, "ratio": round(ratio, 4), "parallelism": "block-range shard x%d" % world,
                        "step": "encode kernel + size scan (+ all_gather of totals) + compact" if args.mode == "encode"
                        else "inflate kernel"},
