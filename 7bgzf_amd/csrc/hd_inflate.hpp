@@ -81,6 +81,7 @@ struct InfLds {
 	uint16_t off_sorted[32];
 	uint16_t lit_count[16], off_count[16];
 	uint8_t pre_lens[32];
+	uint32_t t_cnt[16], t_first[16], t_offs[16], t_base[16];   // table-build scratch, one entry per code length
 	uint8_t cl[288 + 32 + 138 + 6];           // + worst-case RLE overrun (decompress_template.h:171)
 	__attribute__((aligned(16))) uint8_t ring[INF_RING];
 };
@@ -88,74 +89,72 @@ struct InfLds {
 // Build one decode table from code lengths (all 64 lanes).  Returns false for
 // what build_decode_table() rejects (deflate_decompress.c:799-853).
 //   nsyms <= 288; tbits = direct table bits; kind 0 litlen / 1 offset / 2 precode
+// Per-length counters live in LDS (one lane per code length), not in registers:
+// sixteen-element uniform arrays would cost 64 SGPRs and spill the symbol loop.
+struct InfLds;
 template <int KIND>
-__device__ __forceinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
-					      uint16_t *sorted, uint16_t *count_out, uint32_t lane)
+__device__ __noinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
+					  uint16_t *sorted, uint16_t *count_out, uint32_t *t_cnt, uint32_t *t_first,
+					  uint32_t *t_offs, uint32_t *t_base, uint32_t lane)
 {
-	// per-length counts and canonical first codes (uniform)
-	uint32_t count[16], first[16], offs[16];
-#pragma unroll
-	for (int l = 0; l < 16; l++)
-		count[l] = 0;
+	if (lane < 16)
+		t_cnt[lane] = 0;
 	for (uint32_t base = 0; base < nsyms; base += 64) {
 		const uint32_t s = base + lane;
 		const uint32_t len = s < nsyms ? lens[s] : 0;
-#pragma unroll
-		for (int l = 1; l < 16; l++)
-			count[l] += __popcll(__ballot(len == (uint32_t)l));
+		if (len)
+			atomicAdd(&t_cnt[len], 1u);
 	}
-	uint32_t used = 0, code = 0, o = 0, maxlen = 0;
-#pragma unroll
-	for (int l = 1; l < 16; l++) {
-		code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
-		first[l] = code;
-		offs[l] = o;
-		o += count[l];
-		used += count[l] << (15 - l);
-		if (count[l])
-			maxlen = l;
+	// lane l (1..15) derives its length's first codeword, sorted offset and codespace share
+	uint32_t code = 0, o = 0, mine = 0;
+	if (lane >= 1 && lane < 16) {
+		for (uint32_t l = 1; l <= lane; l++) {
+			code = (code + (l > 1 ? t_cnt[l - 1] : 0)) << 1;
+			if (l < lane)
+				o += t_cnt[l];
+		}
+		mine = t_cnt[lane];
+		t_first[lane] = code;
+		t_offs[lane] = o;
+		t_base[lane] = 0;
 	}
-	if (count_out) {
-		uint32_t mine = 0;
-#pragma unroll
-		for (int l = 1; l < 16; l++)
-			mine = lane == (uint32_t)l ? count[l] : mine;
-		if (lane < 16)
-			count_out[lane] = (uint16_t)mine;
-	}
+	if (count_out && lane < 16)
+		count_out[lane] = (uint16_t)mine;
+	const uint32_t used = readlane(wave_incl_scan((lane >= 1 && lane < 16) ? mine << (15 - lane) : 0u), 63);
+	const uint64_t present = __ballot(mine != 0);
+	const uint32_t maxlen = present ? 63 - (uint32_t)__clzll((long long)present) : 0;
+	const uint32_t ones = readlane(mine, 1);
 	if (used > (1u << 15))
 		return false;                     // overfull
 	bool degenerate = false;
 	if (used < (1u << 15)) {                  // incomplete
-		if (used != 0 && !(count[1] == 1 && maxlen == 1))
+		if (used != 0 && !(ones == 1 && maxlen == 1))
 			return false;
 		degenerate = true;
 	}
-	// rank of every symbol inside its length class, in symbol order
-	uint32_t run[16];
-#pragma unroll
-	for (int l = 0; l < 16; l++)
-		run[l] = 0;
 	uint32_t one_sym = 0;                 // the symbol owning the single 1-bit codeword, if any
 	for (uint32_t base = 0; base < nsyms; base += 64) {
 		const uint32_t s = base + lane;
 		const uint32_t len = s < nsyms ? lens[s] : 0;
-		uint32_t rank = 0, fc = 0, of = 0;
-#pragma unroll
-		for (int l = 1; l < 16; l++) {
-			const uint64_t m = __ballot(len == (uint32_t)l);
-			if (len == (uint32_t)l) {
-				rank = run[l] + __popcll(m & ((1ull << lane) - 1));
-				fc = first[l];
-				of = offs[l];
-			}
-			if (l == 1 && m)
-				one_sym = base + (uint32_t)__ffsll((unsigned long long)m) - 1;
-			run[l] += __popcll(m);
+		// rank inside the length class, in symbol order: one ballot per length present
+		uint32_t rank = 0;
+		uint64_t rem = __ballot(len != 0);
+		while (rem) {
+			const uint32_t lead = (uint32_t)__ffsll((unsigned long long)rem) - 1;
+			const uint32_t lc = readlane(len, lead);
+			const uint64_t m = __ballot(len == lc);
+			const uint32_t b0 = uniform(t_base[lc]);
+			if (len == lc)
+				rank = b0 + __popcll(m & ((1ull << lane) - 1));
+			if (lane == lead)
+				t_base[lc] = b0 + __popcll(m);
+			if (lc == 1)
+				one_sym = base + lead;
+			rem &= ~m;
 		}
 		if (len) {
-			sorted[of + rank] = (uint16_t)s;
-			const uint32_t cw = fc + rank;              // MSB-first codeword
+			sorted[t_offs[len] + rank] = (uint16_t)s;
+			const uint32_t cw = t_first[len] + rank;        // MSB-first codeword
 			const uint32_t rev = __brev(cw) >> (32 - len);
 			if (!degenerate) {
 				if (len <= tbits) {
@@ -182,7 +181,7 @@ __device__ __forceinline__ bool build_table(const uint8_t *lens, uint32_t nsyms,
 }
 
 // bit-serial canonical decode for codewords longer than the direct table
-__device__ __forceinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted,
+__device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted,
 						 uint32_t &len_out)
 {
 	uint32_t code = 0, first = 0, index = 0;
@@ -255,6 +254,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		}
 	};
 	auto consumed_bits = [&]() -> int64_t { return (int64_t)dw * 32 - bc - 8 * (int64_t)mis; };
+	// consumed_bits() > 8 n + 64 in 32-bit arithmetic (n < 2^28): (dw << 5) - bc > over_t
+	const uint32_t over_t = 8 * n + 64 + 8 * mis;
+	auto overrun = [&]() -> bool { return (dw << 5) - bc > over_t; };
 	auto seek_byte = [&](uint32_t byteoff) {       // restart the bit reader at src + byteoff
 		const uint32_t o = mis + byteoff;
 		dw = o >> 2;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					bb >>= 3;
 					bc -= 3;
 				}
-				if (!build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, lane)) { st = HD_BAD_DATA; break; }
+				if (!build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) { st = HD_BAD_DATA; break; }
 				uint8_t *cl = L.cl;
 				uint32_t i = 0, prev = 0;
 				bool bad = false;
@@ -389,8 +391,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				}
 				if (bad || i != nlit + noff) { st = HD_BAD_DATA; break; }
 				static_loaded = false;
-				if (!build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, lane) ||
-				    !build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, lane)) {
+				if (!build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane) ||
+				    !build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) {
 					st = HD_BAD_DATA;
 					break;
 				}
@@ -399,15 +401,18 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				uint8_t *cl = L.cl;
 				for (uint32_t s = lane; s < 320; s += 64)
 					cl[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
-				build_table<1>(cl + 288, 32, L.off, INF_DT_BITS, L.off_sorted, L.off_count, lane);
-				build_table<0>(cl, 288, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, lane);
+				build_table<1>(cl + 288, 32, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane);
+				build_table<0>(cl, 288, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane);
 				static_loaded = true;
 			}
 
 			// ---- symbol loop ----------------------------------------------
 			for (;;) {
+				// one flush site for the whole symbol loop (at most 1023 + 258 bytes pending)
+				if (pos - flushed >= HD_PIECE)
+					flush_pieces();
 				refill();
-				if (consumed_bits() > 8 * (int64_t)n + 64) { st = HD_BAD_DATA; break; }
+				if (overrun()) { st = HD_BAD_DATA; break; }
 				uint32_t e = uniform(L.lit[(uint32_t)bb & ((1u << INF_LT_BITS) - 1)]);
 				if (((e >> 8) & 3) == K_SLOW) {
 					uint32_t l;
@@ -420,11 +425,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t kind = (e >> 8) & 3;
 				if (kind == K_LIT) {
 					if (pos == cap) { st = HD_INSUFFICIENT_SPACE; break; }
-					if (lane == 0)
-						L.ring[pos & (INF_RING - 1)] = (uint8_t)(e >> 16);
+					// every lane stores the same byte to the same address: no exec juggling
+					L.ring[pos & (INF_RING - 1)] = (uint8_t)(e >> 16);
 					pos++;
-					if (pos - flushed >= HD_PIECE)
-						flush_pieces();
 					continue;
 				}
 				if (kind == K_EOB)
@@ -451,20 +454,30 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 
 				// ---- match copy, 64 bytes per step ------------------------
 				if (offset <= INF_NEAR) {
-					for (uint32_t i = lane; i < length; i += 64) {
-						const uint32_t r = offset < length ? i % offset : i;
-						const uint8_t v = L.ring[(pos - offset + r) & (INF_RING - 1)];
-						L.ring[(pos + i) & (INF_RING - 1)] = v;
+					if (offset >= length) {
+						// disjoint: the common case, one pass per 64 bytes
+						for (uint32_t i = lane; i < length; i += 64)
+							L.ring[(pos + i) & (INF_RING - 1)] = L.ring[(pos - offset + i) & (INF_RING - 1)];
+					} else {
+						// overlapping (run of period `offset`): source index i mod offset,
+						// by a uniform reciprocal; all sources lie before pos
+						const float rcp = 1.0f / (float)offset;
+						for (uint32_t i = lane; i < length; i += 64) {
+							uint32_t q = (uint32_t)((float)i * rcp);
+							uint32_t r = i - q * offset;
+							r = (int32_t)r < 0 ? r + offset : r;
+							r = r >= offset ? r - offset : r;
+							L.ring[(pos + i) & (INF_RING - 1)] = L.ring[(pos - offset + r) & (INF_RING - 1)];
+						}
 					}
 				} else {
 					// source was flushed long ago: make our own stores visible
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
 					for (uint32_t i = lane; i < length; i += 64)
 						L.ring[(pos + i) & (INF_RING - 1)] = dst[pos - offset + i];
 				}
 				pos += length;
-				if (pos - flushed >= HD_PIECE)
-					flush_pieces();
 			}
 			if (st != HD_OK)
 				break;
