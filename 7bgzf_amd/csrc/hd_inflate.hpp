@@ -93,7 +93,7 @@ struct InfLds {
 // sixteen-element uniform arrays would cost 64 SGPRs and spill the symbol loop.
 struct InfLds;
 template <int KIND>
-__device__ __noinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
+__device__ __noinline__ uint32_t build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
 					  uint16_t *sorted, uint16_t *count_out, uint32_t *t_cnt, uint32_t *t_first,
 					  uint32_t *t_offs, uint32_t *t_base, uint32_t lane)
 {
@@ -125,11 +125,11 @@ __device__ __noinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, ui
 	const uint32_t maxlen = present ? 63 - (uint32_t)__clzll((long long)present) : 0;
 	const uint32_t ones = readlane(mine, 1);
 	if (used > (1u << 15))
-		return false;                     // overfull
+		return 0;                         // overfull
 	bool degenerate = false;
 	if (used < (1u << 15)) {                  // incomplete
 		if (used != 0 && !(ones == 1 && maxlen == 1))
-			return false;
+			return 0;
 		degenerate = true;
 	}
 	uint32_t one_sym = 0;                 // the symbol owning the single 1-bit codeword, if any
@@ -177,27 +177,25 @@ __device__ __noinline__ bool build_table(const uint8_t *lens, uint32_t nsyms, ui
 		for (uint32_t i = lane; i < (1u << tbits); i += 64)
 			table[i] = e;
 	}
-	return true;
+	return 1;
 }
 
-// bit-serial canonical decode for codewords longer than the direct table
-__device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted,
-						 uint32_t &len_out)
+// bit-serial canonical decode for codewords longer than the direct table;
+// returns symbol | length << 16.  (Function results come back in VGPRs: callers
+// pass them through readfirstlane so that the decode state stays scalar.)
+__device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted)
 {
 	uint32_t code = 0, first = 0, index = 0;
 	for (uint32_t l = 1; l <= 15; l++) {
 		code |= (uint32_t)(bb >> (l - 1)) & 1;
 		const uint32_t cnt = uniform(count[l]);
-		if (code - first < cnt) {
-			len_out = l;
-			return uniform(sorted[index + (code - first)]);
-		}
+		if (code - first < cnt)
+			return uniform(sorted[index + (code - first)]) | (l << 16);
 		index += cnt;
 		first = (first + cnt) << 1;
 		code <<= 1;
 	}
-	len_out = 15;
-	return 0;
+	return 15u << 16;
 }
 
 __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
@@ -299,6 +297,21 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 
 	int32_t st = HD_OK;
 	bool static_loaded = false;
+	// The direct tables are built in LDS, then kept in VGPRs for the symbol loop:
+	// entry i lives in lane i & 63 of register i >> 6, a lookup is one relative
+	// v_mov (s_set_gpr_idx) + v_readlane -- no LDS round trip per symbol.
+	typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	u32x16 LT;
+	u32x4 DT;
+	auto load_tables = [&]() {
+#pragma unroll
+		for (int r = 0; r < 16; r++)
+			LT[r] = L.lit[r * 64 + lane];
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			DT[r] = L.off[r * 64 + lane];
+	};
 
 	for (;;) {
 		refill();
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					bb >>= 3;
 					bc -= 3;
 				}
-				if (!build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) { st = HD_BAD_DATA; break; }
+				if (!uniform(build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane))) { st = HD_BAD_DATA; break; }
 				uint8_t *cl = L.cl;
 				uint32_t i = 0, prev = 0;
 				bool bad = false;
@@ -391,8 +404,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				}
 				if (bad || i != nlit + noff) { st = HD_BAD_DATA; break; }
 				static_loaded = false;
-				if (!build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane) ||
-				    !build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) {
+				if (!uniform(build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) ||
+				    !uniform(build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane))) {
 					st = HD_BAD_DATA;
 					break;
 				}
@@ -406,6 +419,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				static_loaded = true;
 			}
 
+			load_tables();
 			// ---- symbol loop ----------------------------------------------
 			for (;;) {
 				// one flush site for the whole symbol loop (at most 1023 + 258 bytes pending)
@@ -413,11 +427,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					flush_pieces();
 				refill();
 				if (overrun()) { st = HD_BAD_DATA; break; }
-				uint32_t e = uniform(L.lit[(uint32_t)bb & ((1u << INF_LT_BITS) - 1)]);
+				const uint32_t li = (uint32_t)bb & ((1u << INF_LT_BITS) - 1);
+				uint32_t e = readlane(LT[li >> 6], li & 63);
 				if (((e >> 8) & 3) == K_SLOW) {
-					uint32_t l;
-					const uint32_t s = slow_decode(bb, L.lit_count, L.lit_sorted, l);
-					e = litlen_entry(s, l);
+					const uint32_t sl = uniform(slow_decode(bb, L.lit_count, L.lit_sorted));
+					e = litlen_entry(sl & 0xffff, sl >> 16);
 				}
 				const uint32_t clen = e & 15;
 				bb >>= clen;
@@ -438,11 +452,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				bc -= eb;
 				if (length > cap - pos) { st = HD_INSUFFICIENT_SPACE; break; }
 				refill();
-				uint32_t d = uniform(L.off[(uint32_t)bb & ((1u << INF_DT_BITS) - 1)]);
+				const uint32_t di = (uint32_t)bb & ((1u << INF_DT_BITS) - 1);
+				uint32_t d = readlane(DT[di >> 6], di & 63);
 				if (((d >> 8) & 3) == K_SLOW) {
-					uint32_t l;
-					const uint32_t s = slow_decode(bb, L.off_count, L.off_sorted, l);
-					d = offset_entry(s, l);
+					const uint32_t sl = uniform(slow_decode(bb, L.off_count, L.off_sorted));
+					d = offset_entry(sl & 0xffff, sl >> 16);
 				}
 				const uint32_t dlen = d & 15, deb = (d >> 4) & 15;
 				bb >>= dlen;
