@@ -63,6 +63,34 @@ def test_encode_matches_twin_small_corpus(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(data), k
 
 
+@pytest.mark.parametrize("level", [1, 3, 6])
+def test_encode_migz_1mib_blocks_match_twin(pkg, level):
+    """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
+    member holds several DEFLATE blocks (one per 32768 tokens), positions exceed 16 bits
+    (the hash table stores them mod 2^16) and the ring wraps many times."""
+    s = hdtest.synth()
+    data = bytes(s.text_like(2 * (1 << 20) + 300000, seed=77)) + bytes(s.fastq_like(1 << 20, seed=78))
+    offs = [0, 1 << 20, 2 << 20, (2 << 20) + 300000]
+    lens = [1 << 20, 1 << 20, 300000, 1 << 20]
+    slot = ((1 << 20) + (1 << 17) + 4096 + 15) & ~15
+    members, crc, st = pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_MIGZ, slot=slot)
+    for i in range(len(offs)):
+        chunk = data[offs[i]:offs[i] + lens[i]]
+        assert st[i] == 0
+        m = members[i]
+        assert m[:16] == bytes.fromhex("1f8b08040000000000ff08004d5a0400")
+        payload = m[20:-8]
+        assert int.from_bytes(m[16:20], "little") == len(payload)
+        r, twin = hdtest.oracle_twin(chunk, level, cap=slot - 28)
+        assert r == 0 and payload == twin, (i, level, len(payload), len(twin))
+        assert zlib.decompress(payload, -15) == chunk
+        assert int.from_bytes(m[-8:-4], "little") == zlib.crc32(chunk) == int(crc[i])
+    # and our inflate takes them back (multi-block members, 32 KiB-distance matches at level 6)
+    outs, crc2, st2 = pkg.batch_inflate([m[20:] for m in members], lens)
+    for i in range(len(offs)):
+        assert st2[i] == 0 and outs[i] == data[offs[i]:offs[i] + lens[i]] and int(crc2[i]) == int(crc[i])
+
+
 def test_encode_unaligned_offsets_and_ragged_lengths(pkg):
     s = hdtest.synth()
     data = bytes(s.fastq_like(300000, seed=3))
