@@ -193,13 +193,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 
 	// OR one token per lane (nbits == 0: none) into the staging ring
 	auto put = [&](uint32_t code, uint32_t nbits, uint32_t incl, uint32_t total) {
+		// branch-free: a lane without a token ORs zeros; the second dword gets the
+		// bits that spill over (zero when the token does not cross a dword)
 		const uint32_t bp = bitpos + incl - nbits;
-		if (nbits) {
-			const uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
-			atomicOr(&stage[i], code << sh);
-			if (sh + nbits > 32)
-				atomicOr(&stage[(i + 1) & (STG - 1)], code >> (32 - sh));
-		}
+		const uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
+		const uint64_t wide = (uint64_t)(nbits ? code : 0u) << sh;
+		atomicOr(&stage[i], (uint32_t)wide);
+		atomicOr(&stage[(i + 1) & (STG - 1)], (uint32_t)(wide >> 32));
 		bitpos += total;
 	};
 	// whenever 128 whole dwords are ready they leave as one 8-byte-per-lane store
