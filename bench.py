@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--data", default="fastq", choices=["fastq", "text", "random"],
                     help="fastq = configs[1..3]; text = config 5 (enwik-like); random = config 1 stand-in")
     ap.add_argument("--block-kib", type=int, default=0, help="0 = BGZF 0xff00-byte blocks; else MiGz blocks of N KiB")
+    ap.add_argument("--stream", default="own", choices=["own", "libdeflate6", "zlib6", "libdeflate1"],
+                    help="decode mode: who compressed the stream (reference encoders need oracle/_ref/libref.so)")
     return ap.parse_args()
 
 
@@ -143,7 +145,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("HD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     pkg = importlib.import_module("7bgzf_amd")
     dev = importlib.import_module("7bgzf_amd.device")
@@ -154,6 +157,8 @@ def main():
 
     # ---- synthetic input: a seeded FASTQ-like tile replicated to G GiB in HBM ---------
     tile_bytes = args.tile_mib << 20
+    if args.mode == "decode" and args.stream != "own":
+        tile_bytes = tile_bytes // BLOCK * BLOCK      # whole blocks per tile: the compressed tile repeats too
     if args.data == "fastq":
         tile_np = synth.fastq_like(tile_bytes, seed=1234 + rank, first_record=1 + rank * 10_000_000)
     elif args.data == "text":
@@ -180,17 +185,49 @@ def main():
         packed = torch.empty(int(total * (0.75 if (level >= 1 and args.data != "random") else 1.01)) + (1 << 20),
                              dtype=torch.uint8, device="cuda")
     else:
-        # decode: the stream to inflate is produced once, untimed, by our own encoder at
-        # --level (valid RFC 1951 multi-member BGZF); it then stays resident in HBM
         level = args.level
-        enc.run(data, off, ln, level=level, frame=frame)
-        enc.scan()
-        torch.cuda.synchronize()
-        comp_total = int(enc.total.item())
-        packed = torch.empty(comp_total + 16, dtype=torch.uint8, device="cuda")
-        enc.compact(packed)
-        in_off = enc.dst_off + hdr
-        in_len = (enc.out_len - hdr).to(torch.int32)
+        if args.stream == "own":
+            # the stream to inflate is produced once, untimed, by our own encoder at --level
+            # (valid RFC 1951 multi-member BGZF); it then stays resident in HBM
+            enc.run(data, off, ln, level=level, frame=frame)
+            enc.scan()
+            torch.cuda.synchronize()
+            comp_total = int(enc.total.item())
+            packed = torch.empty(comp_total + 16, dtype=torch.uint8, device="cuda")
+            enc.compact(packed)
+            in_off = enc.dst_off + hdr
+            in_len = (enc.out_len - hdr).to(torch.int32)
+            want_crc = enc.crc
+        else:
+            # BASELINE config 3: the REFERENCE's encoder (libdeflate 1.23 / zlib 1.3.1 built from
+            # the reference tree) compresses one tile of whole blocks on the host, untimed; the
+            # compressed tile is replicated like the data
+            import zlib as _z
+            from concurrent.futures import ThreadPoolExecutor
+            ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref.so"))
+            fn, lvl = {"libdeflate6": (ref.libdeflate_deflate, 6), "libdeflate1": (ref.libdeflate_deflate, 1),
+                       "zlib6": (ref.zlib_deflate, 6)}[args.stream]
+            tb = tile_np.tobytes()
+            nbt = tile_bytes // BLOCK
+
+            def comp(i):
+                src = tb[i * BLOCK:(i + 1) * BLOCK]
+                dst = ctypes.create_string_buffer(BLOCK * 2)
+                n = ctypes.c_size_t(BLOCK * 2)
+                assert fn(dst, ctypes.byref(n), src, ctypes.c_size_t(BLOCK), lvl) == 0
+                return dst.raw[:n.value], _z.crc32(src)
+            with ThreadPoolExecutor(16) as ex:
+                res = list(ex.map(comp, range(nbt)))
+            lens_t = np.array([len(r[0]) for r in res], dtype=np.int64)
+            offs_t = np.concatenate([[0], np.cumsum(lens_t)[:-1]])
+            ctile = np.frombuffer(b"".join(r[0] for r in res), dtype=np.uint8)
+            packed = torch.from_numpy(ctile.copy()).cuda().repeat(reps)
+            comp_total = packed.numel()
+            in_off = (torch.from_numpy(offs_t).cuda()[None, :] +
+                      (torch.arange(reps, device="cuda", dtype=torch.int64) * len(ctile))[:, None]).reshape(-1)
+            in_len = torch.from_numpy(lens_t.astype(np.int32)).cuda().repeat(reps)
+            want_crc = torch.from_numpy(np.array([r[1] for r in res], dtype=np.uint32).view(np.int32)).cuda().repeat(reps)
+            level = lvl
         out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
         crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
         st = torch.zeros(nb, dtype=torch.int32, device="cuda")
@@ -208,7 +245,7 @@ def main():
             enc.run(data, off, ln, level=level, frame=frame)
             e1.record()
             enc.scan()
-            if world > 1:
+            if world > 1 or force_dist:
                 # the ONE exchange of the path: per-rank compressed totals -> base offsets
                 dist.all_gather_into_tensor(totals, enc.total)
             enc.compact(packed)
@@ -221,7 +258,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +270,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -244,7 +281,8 @@ def main():
         comp_total = int(enc.total.item())
     else:
         assert int(st.abs().sum()) == 0 and torch.equal(out_len, ln)
-        assert torch.equal(out[: 4 * BLOCK], data[: 4 * BLOCK]) and torch.equal(crc, enc.crc)
+        assert torch.equal(out[: 4 * BLOCK], data[: 4 * BLOCK]) and torch.equal(out[-BLOCK:], data[-BLOCK:])
+        assert torch.equal(crc, want_crc)
     ratio = comp_total / total
 
     kms = [a.elapsed_time(b) for a, b in kern_ms]
@@ -276,6 +314,8 @@ def main():
                                    "%d MiB tile x %d), %d blocks/GPU, HBM-resident" % (
                                        "MiGz" if args.block_kib else "BGZF", args.mode,
                                        ("%d KiB" % args.block_kib) if args.block_kib else "0xff00-byte",
+                                       ("stream from the reference's %s (built from the reference tree)" % args.stream)
+                                       if (args.mode == "decode" and args.stream != "own") else
                                        ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else
                                        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy" if level >= 5 else "greedy")) if level >= 2
                                        else "level 0: stored",
@@ -283,7 +323,7 @@ def main():
                                        args.tile_mib, reps, nb),
                        "blocks_per_gpu": nb, "ratio": round(ratio, 4), "parallelism": "block-range shard x%d" % world,
                        "step": "encode kernel + size scan (+ all_gather of totals) + compact" if args.mode == "encode"
-                       else "inflate kernel"},
+                       else "inflate kernel", "stream": args.stream if args.mode == "decode" else None},
             "roofline": {"bound": "hbm", "kernel": "k_deflate_static" if args.mode == "encode" and level <= 1
                          else ("k_deflate_dynamic" if args.mode == "encode" else "k_inflate"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -295,7 +335,7 @@ def main():
         elif not args.no_cpu:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
