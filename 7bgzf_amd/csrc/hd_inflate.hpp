@@ -296,6 +296,154 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		}
 	};
 
+
+	// ---- window decode: 64 speculative tokens per pass -----------------------
+	// The scalar token loop costs ~80 SALU per token on the CU's single scalar ALU.
+	// Here every lane decodes the token that WOULD start at bit B + lane (two LDS
+	// table gathers, VALU only); a short scalar walk then follows the real chain
+	// (~10 SALU per token), literals are stored in parallel at positions from a
+	// DPP prefix sum, matches are copied in order.  A window is entered only
+	// when nothing rare can happen inside it: five whole dwords of stream ahead,
+	// room for the largest output, less than a piece waiting for the flush.
+	// Returns 0 = fall back to the scalar loop for one token, 1 = end of block
+	// consumed, 2 = error (st set).  Reader state is the scalar one on both sides.
+	// output budget of one window: pending <= 1023 + 704 = 1727 <= INF_RING - 64 - 257, so a source is
+	// either wholly in the ring (wend - src <= INF_RING - 64) or wholly flushed to HBM
+	constexpr uint32_t WIN_OUT_BUDGET = 704;
+	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
+	auto run_windows = [&](int32_t &st_out) -> uint32_t {
+		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
+		uint32_t result = 0;
+		for (;;) {
+			if (pos - flushed >= HD_PIECE)
+				flush_pieces();
+			const uint32_t d0 = B >> 5;
+			if (!(d0 + 5 <= dw_safe && pos + WIN_OUT_BUDGET + HD_MAX_MATCH <= cap))
+				break;
+			// pieces: d0 must live in cw, d0 + 4 in cw or cw_next
+			if ((d0 >> 6) != cur_piece) {
+				const uint32_t piece = d0 >> 6;
+				if (piece == cur_piece + 1) {
+					cw = cw_next;
+				} else {
+					cw = load_piece(piece);
+				}
+				cur_piece = piece;
+				cw_next = load_piece(piece + 1);
+			}
+			uint32_t w[5];
+#pragma unroll
+			for (int k = 0; k < 5; k++) {
+				const uint32_t d = d0 + k;
+				const uint32_t a0 = readlane(cw, d & 63), a1 = readlane(cw_next, d & 63);
+				w[k] = (d >> 6) == cur_piece ? a0 : a1;
+			}
+			// 64 bits of stream starting at bit B + lane
+			const uint32_t bl = (B & 31) + lane;          // 0..94
+			const uint32_t k = bl >> 5;                    // 0, 1 or 2
+			const uint32_t lo = k == 0 ? w[0] : k == 1 ? w[1] : w[2];
+			const uint32_t mid = k == 0 ? w[1] : k == 1 ? w[2] : w[3];
+			const uint32_t hi = k == 0 ? w[2] : k == 1 ? w[3] : w[4];
+			const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
+			const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
+			// litlen
+			const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
+			const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
+			const uint32_t length = (e >> 16) + ((a >> len1) & ((1u << eb) - 1));
+			const uint32_t t1 = len1 + eb;                 // <= 9 + 5
+			const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
+			const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
+			const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
+			const uint32_t offset = (dd >> 16) + ((rest >> dlen) & ((1u << deb) - 1));
+			const bool is_len = kind == K_LEN;
+			const bool slow = kind == K_SLOW || (is_len && ((dd >> 8) & 3) == K_SLOW);
+			const uint32_t tokbits = is_len ? t1 + dlen + deb : len1;
+			const uint32_t outlen = kind == K_LIT ? 1u : is_len ? length : 0u;
+			// meta: [5:0] tokbits  [14:6] outlen  [15] slow  [16] eob
+			const uint32_t meta = tokbits | (outlen << 6) | (slow ? 1u << 15 : 0u) | (kind == K_EOB ? 1u << 16 : 0u);
+
+			// the real chain from bit 0 of the window
+			uint32_t b = 0, cum = 0, stop = 0;
+			uint64_t real = 0;
+			while (b < 64) {
+				const uint32_t m = readlane(meta, b);
+				if (m & (1u << 15)) { stop = 2; break; }
+				const uint32_t ol = (m >> 6) & 511;
+				if (cum + ol > WIN_OUT_BUDGET) { stop = 3; break; }
+				real |= 1ull << b;
+				cum += ol;
+				b += m & 63;
+				if (m & (1u << 16)) { stop = 1; break; }
+			}
+			if (real == 0)
+				break;                                     // a slow token right at B: scalar loop
+			const bool mine = (real >> lane) & 1;
+			const uint32_t incl = wave_incl_scan(mine ? outlen : 0u);
+			const uint32_t opos = pos + incl - outlen;     // valid where `mine`
+			if (mine && kind == K_LIT)
+				L.ring[opos & (INF_RING - 1)] = (uint8_t)(e >> 16);
+			uint64_t mm = real & __ballot(is_len);
+			const uint32_t wend = pos + cum;
+			bool bad = false;
+			while (mm) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
+				mm &= mm - 1;
+				const uint32_t mlen = readlane(outlen, m), moff = readlane(offset, m), P = readlane(opos, m);
+				if (moff > P) { bad = true; break; }
+				const uint32_t srcp = P - moff;
+				if (wend - srcp <= INF_RING - 64) {
+					// source still in the ring (the literals of the whole window are already in)
+					if (moff >= mlen) {
+						for (uint32_t i = lane; i < mlen; i += 64)
+							L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + i) & (INF_RING - 1)];
+					} else {
+						const float rcp = 1.0f / (float)moff;
+						for (uint32_t i = lane; i < mlen; i += 64) {
+							uint32_t q = (uint32_t)((float)i * rcp);
+							uint32_t r = i - q * moff;
+							r = (int32_t)r < 0 ? r + moff : r;
+							r = r >= moff ? r - moff : r;
+							L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + r) & (INF_RING - 1)];
+						}
+					}
+				} else {
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+					for (uint32_t i = lane; i < mlen; i += 64)
+						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
+				}
+			}
+			if (bad) {
+				st_out = HD_BAD_DATA;
+				result = 2;
+				break;
+			}
+			pos = wend;
+			B += b;
+			if (stop == 1) {
+				result = 1;
+				break;
+			}
+		}
+		// hand the position back to the scalar reader
+		dw = B >> 5;
+		if ((dw >> 6) != cur_piece) {
+			const uint32_t piece = dw >> 6;
+			if (piece == cur_piece + 1)
+				cw = cw_next;
+			else
+				cw = load_piece(piece);
+			cur_piece = piece;
+			cw_next = load_piece(piece + 1);
+		}
+		bb = 0;
+		bc = 0;
+		refill();
+		bb >>= (B & 31);
+		bc -= (B & 31);
+		return result;
+	};
+
 	int32_t st = HD_OK;
 	bool static_loaded = false;
 	// The direct tables are built in LDS, then kept in VGPRs for the symbol loop:
@@ -423,6 +571,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			load_tables();
 			// ---- symbol loop ----------------------------------------------
 			for (;;) {
+				{
+					const uint32_t wr = uniform(run_windows(st));
+					if (wr)                      // 1: end of block consumed, 2: error
+						break;
+				}
+				// one token through the fully checked scalar path (stream edges, long codes)
 				// one flush site for the whole symbol loop (at most 1023 + 258 bytes pending)
 				if (pos - flushed >= HD_PIECE)
 					flush_pieces();
