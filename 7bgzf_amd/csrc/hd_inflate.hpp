@@ -382,15 +382,25 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t opos = pos + incl - outlen;     // valid where `mine`
 			if (mine && kind == K_LIT)
 				L.ring[opos & (INF_RING - 1)] = (uint8_t)(e >> 16);
-			uint64_t mm = real & __ballot(is_len);
 			const uint32_t wend = pos + cum;
-			bool bad = false;
-			while (mm) {
+			// per-lane verdicts for the matches, so that the scalar loop below only dispatches
+			const bool my_match = mine && is_len;
+			const uint32_t srcl = opos - offset;                         // wraps when offset > opos
+			const bool bad = __ballot(my_match && offset > opos) != 0;    // decompress_template.h:724
+			const bool in_ring = wend - srcl <= INF_RING - 64;
+			const uint64_t simple = __ballot(my_match && in_ring && offset >= length && length <= 64);
+			uint64_t mm = __ballot(my_match);
+			while (mm && !bad) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				mm &= mm - 1;
-				const uint32_t mlen = readlane(outlen, m), moff = readlane(offset, m), P = readlane(opos, m);
-				if (moff > P) { bad = true; break; }
-				const uint32_t srcp = P - moff;
+				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
+				if ((simple >> m) & 1) {
+					// <= 64 bytes, disjoint, source in the ring: one read, one write
+					if (lane < mlen)
+						L.ring[(P + lane) & (INF_RING - 1)] = L.ring[(srcp + lane) & (INF_RING - 1)];
+					continue;
+				}
+				const uint32_t moff = P - srcp;
 				if (wend - srcp <= INF_RING - 64) {
 					// source still in the ring (the literals of the whole window are already in)
 					if (moff >= mlen) {
