@@ -77,13 +77,19 @@ __device__ __forceinline__ uint32_t offset_entry(uint32_t sym, uint32_t len)
 struct InfLds {
 	uint32_t lit[1u << INF_LT_BITS];
 	uint32_t off[1u << INF_DT_BITS];
-	uint32_t pre[128];
 	uint16_t lit_sorted[288];
 	uint16_t off_sorted[32];
 	uint16_t lit_count[16], off_count[16];
 	uint8_t pre_lens[32];
 	uint32_t t_cnt[16], t_first[16], t_offs[16], t_base[16];   // table-build scratch, one entry per code length
-	uint8_t cl[288 + 32 + 138 + 6];           // + worst-case RLE overrun (decompress_template.h:171)
+	// header-time scratch and the window decoder's stream copy are never live together
+	union {
+		struct {
+			uint32_t pre[128];
+			uint8_t cl[288 + 32 + 138 + 6];   // + worst-case RLE overrun (decompress_template.h:171)
+		};
+		uint32_t comp[256];               // 4 pieces of the compressed stream for the window decoder
+	};
 	__attribute__((aligned(16))) uint8_t ring[INF_RING];
 };
 
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	// either wholly in the ring (wend - src <= INF_RING - 64) or wholly flushed to HBM
 	constexpr uint32_t WIN_OUT_BUDGET = 704;
 	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
+	uint32_t lds_p0 = 0xfffffff0u;                // pieces lds_p0, lds_p0 + 1 are in L.comp
 	auto run_windows = [&](int32_t &st_out) -> uint32_t {
 		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
 		uint32_t result = 0;
@@ -320,30 +327,18 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t d0 = B >> 5;
 			if (!(d0 + 5 <= dw_safe && pos + WIN_OUT_BUDGET + HD_MAX_MATCH <= cap))
 				break;
-			// pieces: d0 must live in cw, d0 + 4 in cw or cw_next
-			if ((d0 >> 6) != cur_piece) {
-				const uint32_t piece = d0 >> 6;
-				if (piece == cur_piece + 1) {
-					cw = cw_next;
-				} else {
-					cw = load_piece(piece);
-				}
-				cur_piece = piece;
-				cw_next = load_piece(piece + 1);
+			// the stream bits come from an LDS copy of the pieces around d0 (every lane
+			// reads its own three dwords: no scalar gather)
+			const uint32_t p0 = d0 >> 6;
+			if (p0 != lds_p0) {
+				if (p0 != lds_p0 + 1)
+					L.comp[((p0 & 3) << 6) + lane] = load_piece(p0);
+				L.comp[(((p0 + 1) & 3) << 6) + lane] = load_piece(p0 + 1);
+				lds_p0 = p0;
 			}
-			uint32_t w[5];
-#pragma unroll
-			for (int k = 0; k < 5; k++) {
-				const uint32_t d = d0 + k;
-				const uint32_t a0 = readlane(cw, d & 63), a1 = readlane(cw_next, d & 63);
-				w[k] = (d >> 6) == cur_piece ? a0 : a1;
-			}
-			// 64 bits of stream starting at bit B + lane
 			const uint32_t bl = (B & 31) + lane;          // 0..94
-			const uint32_t k = bl >> 5;                    // 0, 1 or 2
-			const uint32_t lo = k == 0 ? w[0] : k == 1 ? w[1] : w[2];
-			const uint32_t mid = k == 0 ? w[1] : k == 1 ? w[2] : w[3];
-			const uint32_t hi = k == 0 ? w[2] : k == 1 ? w[3] : w[4];
+			const uint32_t di = d0 + (bl >> 5);
+			const uint32_t lo = L.comp[di & 255], mid = L.comp[(di + 1) & 255], hi = L.comp[(di + 2) & 255];
 			const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
 			const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
 			// litlen
@@ -474,6 +469,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 
 	for (;;) {
 		refill();
+		lds_p0 = 0xfffffff0u;                     // header parsing reuses the LDS behind L.comp
 		const uint32_t bfinal = (uint32_t)bb & 1;
 		const uint32_t btype = ((uint32_t)bb >> 1) & 3;
 		bb >>= 3;
