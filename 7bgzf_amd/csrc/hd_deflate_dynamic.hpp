@@ -29,8 +29,9 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
-	// enough resident waves to fill the chip at the LDS footprint of the level
-	const uint32_t per_cu = level >= 5 ? 3u : 7u;
+	// one persistent wave per LDS slot of the level (16 KiB -> 9 safely resident per CU,
+	// 44 KiB -> 3); a grid larger than what is resident would run its tail serially
+	const uint32_t per_cu = level >= 5 ? 3u : 9u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -185,10 +186,16 @@ struct DynLds {
 	uint32_t lf[288], df[32];          // histograms of the open DEFLATE block
 	uint32_t lcode[288], dcode[32];    // code | len << 16
 	uint32_t pcode[19], pfreq[19];
+	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen
+};
+
+// Scratch of the code construction.  It is only live while a DEFLATE block is being
+// closed, when the parse is paused, so it shares its LDS with the ring window (the
+// ring is re-read from HBM after a non-final block; 7 KiB less LDS per wave).
+struct DynBuild {
+	HuffScratch hs;
 	uint16_t items[288 + 32];          // RLE of the code lengths: symbol | extra << 8
 	uint8_t lens[288 + 32];
-	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen
-	HuffScratch hs;
 };
 
 __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
@@ -202,7 +209,13 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	constexpr uint32_t STG = 256;
 	constexpr uint32_t FLUSH_DW = 128;
 
-	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
+	__shared__ __attribute__((aligned(16))) union {
+		uint32_t ring[W / 4 + 4];
+		DynBuild build;
+	} U;
+	static_assert(sizeof(DynBuild) <= sizeof(uint32_t) * (W / 4 + 4), "code-construction scratch must fit under the ring");
+	uint32_t *const ring32 = U.ring;
+	DynBuild &Bd = U.build;
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
 	__shared__ DynLds L;
@@ -331,8 +344,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		auto flush_block = [&](bool final) -> bool {
 			if (lane == 0)
 				L.lf[256] += 1;                     // end of block
-			build_code(L.lf, 288, HD_LITLEN_MAXBITS, L.lcode, L.hs, lane);
-			build_code(L.df, 32, HD_OFFSET_MAXBITS, L.dcode, L.hs, lane);
+			build_code(L.lf, 288, HD_LITLEN_MAXBITS, L.lcode, Bd.hs, lane);
+			build_code(L.df, 32, HD_OFFSET_MAXBITS, L.dcode, Bd.hs, lane);
 			if (lane < 19)
 				L.pfreq[lane] = 0;
 			if (lane == 0) {
@@ -342,42 +355,42 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				while (hdist > 1 && (L.dcode[hdist - 1] >> 16) == 0)
 					hdist--;
 				for (uint32_t i = 0; i < hlit; i++)
-					L.lens[i] = (uint8_t)(L.lcode[i] >> 16);
+					Bd.lens[i] = (uint8_t)(L.lcode[i] >> 16);
 				for (uint32_t i = 0; i < hdist; i++)
-					L.lens[hlit + i] = (uint8_t)(L.dcode[i] >> 16);
+					Bd.lens[hlit + i] = (uint8_t)(L.dcode[i] >> 16);
 				const uint32_t total = hlit + hdist;
 				uint32_t ni = 0, i = 0;
 				while (i < total) {
-					const uint32_t v = L.lens[i];
+					const uint32_t v = Bd.lens[i];
 					uint32_t run = 1;
-					while (i + run < total && L.lens[i + run] == v)
+					while (i + run < total && Bd.lens[i + run] == v)
 						run++;
 					i += run;
 					if (v == 0) {
 						while (run >= 11) {
 							const uint32_t r = run < 138 ? run : 138;
-							L.items[ni++] = (uint16_t)(18 | ((r - 11) << 8));
+							Bd.items[ni++] = (uint16_t)(18 | ((r - 11) << 8));
 							L.pfreq[18]++;
 							run -= r;
 						}
 						if (run >= 3) {
-							L.items[ni++] = (uint16_t)(17 | ((run - 3) << 8));
+							Bd.items[ni++] = (uint16_t)(17 | ((run - 3) << 8));
 							L.pfreq[17]++;
 							run = 0;
 						}
 					} else {
-						L.items[ni++] = (uint16_t)v;
+						Bd.items[ni++] = (uint16_t)v;
 						L.pfreq[v]++;
 						run--;
 						while (run >= 3) {
 							const uint32_t r = run < 6 ? run : 6;
-							L.items[ni++] = (uint16_t)(16 | ((r - 3) << 8));
+							Bd.items[ni++] = (uint16_t)(16 | ((r - 3) << 8));
 							L.pfreq[16]++;
 							run -= r;
 						}
 					}
 					while (run--) {
-						L.items[ni++] = (uint16_t)v;
+						Bd.items[ni++] = (uint16_t)v;
 						L.pfreq[v]++;
 					}
 				}
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				L.misc[1] = hlit;
 				L.misc[2] = hdist;
 			}
-			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, L.hs, lane);
+			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane);
 			const uint32_t ni = uniform(L.misc[0]), hlit = uniform(L.misc[1]), hdist = uniform(L.misc[2]);
 			uint32_t hclen = 19;
 			while (hclen > 4 && (uniform(L.pcode[k_perm19[hclen - 1]]) >> 16) == 0)
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			for (uint32_t base = 0; base < ni; base += 64) {
 				const uint32_t k = base + lane;
 				if (k < ni) {
-					const uint32_t sym = L.items[k] & 31;
+					const uint32_t sym = Bd.items[k] & 31;
 					dyn += (L.pcode[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
 				}
 			}
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 					const uint32_t k = base + lane;
 					uint32_t cc = 0, nn = 0;
 					if (k < ni) {
-						const uint32_t it = L.items[k], sym = it & 31;
+						const uint32_t it = Bd.items[k], sym = it & 31;
 						const uint32_t pc = L.pcode[sym];
 						cc = (pc & 0xffff) | ((it >> 8) << (pc >> 16));
 						nn = (pc >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
@@ -610,6 +623,17 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				alive = flush_block(false);
+				// the code construction used the ring's LDS: bring the window back
+				if (alive) {
+					const uint32_t first = filled > W ? (filled - W) / HD_PIECE : 0;
+					for (uint32_t piece = first; piece * HD_PIECE < filled; piece++) {
+						const uint4 v = load_slot(src, n, piece, lane, aligned);
+						const uint32_t ro = (piece * HD_PIECE) & (W - 1);
+						((uint4 *)ring32)[ro / 16 + lane] = v;
+						if (ro == 0 && lane == 0)
+							((uint4 *)ring32)[W / 16] = v;
+					}
+				}
 			}
 		}
 		if (alive) {
