@@ -31,7 +31,7 @@ inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
 	// one persistent wave per LDS slot of the level (16 KiB -> 9 safely resident per CU,
 	// 44 KiB -> 3); a grid larger than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 5 ? 3u : 9u;
+	const uint32_t per_cu = level >= 5 ? 4u : 9u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }

@@ -36,8 +36,9 @@
 #define HD_L2_HASH_BITS    11
 #define HD_L2_MIN_LEN      4
 /* levels 5..9: one-lane-lookahead lazy parse, dynamic Huffman */
-#define HD_L5_WIN_BITS     15          /* 32 KiB ring: the full DEFLATE window */
-#define HD_L5_HASH_BITS    12
+#define HD_L5_WIN_BITS     14          /* 16 KiB ring: with a 2^13 table it compresses better than
+                                        * 32 KiB + 2^12 and leaves room for 4 waves per CU */
+#define HD_L5_HASH_BITS    13
 #define HD_L5_MIN_LEN      5
 
 #define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
