@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t HS = 1u << HASH_BITS;
 	constexpr uint32_t STG = 256;            // staging ring, dwords
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
-	constexpr uint32_t STEP = HD_L1_STEP;    // positions per step, two per lane
+	constexpr uint32_t TOKQ = 128;           // token queue: < 64 waiting + <= 64 of one step
 
 	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
 	// unaligned 8-byte read never wrap
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// (position + 1) mod 2^16, 0 = empty; slot HS is a dump for lanes with nothing to publish
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
-	// the step's tokens in position order; [STEP, STEP + 64) = dump slots of lanes without one
-	__shared__ uint32_t tokbuf[STEP + 64];
+	// tokens waiting for the emit pass; [TOKQ, TOKQ + 64) = dump slots of lanes without one
+	__shared__ uint32_t tokbuf[TOKQ + 64];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 
 	const uint32_t lane = threadIdx.x;
@@ -228,132 +228,132 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 	};
 	// ---- the front of the pipeline -------------------------------------------
-	// A step covers 128 positions: lane l stands on p0 = S + 2l and p1 = p0 + 1
-	// (the three ring dwords under p0 hold the 8 bytes of both).  It is split in
-	// three stages that run one iteration apart, so that no LDS round trip is
-	// waited for where it is issued:
-	//   fetch(k+2)  own bytes, hashes, table lookups, publish
-	//   probe(k+1)  the ring dwords under the two candidates found by fetch
-	//   compute(k)  verify, scan, compact the tokens, codes, emit
+	// A step is split in three stages that run one iteration apart, so that no
+	// LDS round trip is waited for where it is issued:
+	//   fetch(k+2)  own 8 bytes at S + lane, hash, table lookup, publish
+	//   probe(k+1)  the three ring dwords under the candidate found by fetch
+	//   compute(k)  verify, scan, codes, emit
 	// The table holds (position + 1) mod 2^16 in 16 bits (0 = empty): half the
-	// LDS of 32-bit entries, which buys occupancy.  Several positions of a step
-	// may publish to one slot; the hardware picks an arbitrary winner, so the
+	// LDS of 32-bit entries, which buys occupancy.  Several lanes of a step may
+	// publish to one slot; the hardware picks an arbitrary winner, so the
 	// losers with a LARGER position write again until the slot holds the
 	// maximum -- the order-independent result the CPU twin computes.
 	struct Fetched {
-		uint32_t v0, vh0, v1, vh1;   // own bytes [p,p+4), [p+4,p+8) of both positions
-		uint32_t c0, c1;             // candidate position + 1 (0 = none)
+		uint32_t v, vh, c;           // own bytes [p,p+4), [p+4,p+8); candidate position + 1 (0 = none)
 	};
 	auto fetch = [&](uint32_t S_) -> Fetched {
 		Fetched f;
-		const uint32_t p0 = S_ + 2 * lane;
-		const uint32_t *w = &ring32[(p0 >> 2) & W4M];
+		const uint32_t p = S_ + lane;
+		const uint32_t *w = &ring32[(p >> 2) & W4M];
 		const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-		const uint32_t sh = p0 & 3;                              // 0 or 2
-		f.v0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
-		f.vh0 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-		f.v1 = __builtin_amdgcn_alignbyte(w1, w0, sh + 1);
-		f.vh1 = __builtin_amdgcn_alignbyte(w2, w1, sh + 1);
-		const bool can0 = p0 + HD_MIN_MATCH <= n, can1 = p0 + 1 + HD_MIN_MATCH <= n;
-		const uint32_t h0 = can0 ? (f.v0 * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
-		const uint32_t h1 = can1 ? (f.v1 * HD_HASH_MUL) >> (32 - HASH_BITS) : HS + 1;
-		const uint16_t mine0 = (uint16_t)(p0 + 1), mine1 = (uint16_t)(p0 + 2);
-		const uint32_t e0 = table[h0], e1 = table[h1];
-		table[h0] = mine0;
-		table[h1] = mine1;
+		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
+		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
+		const bool can = p + HD_MIN_MATCH <= n;
+		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
+		const uint16_t mine = (uint16_t)(p + 1);
+		const uint32_t e = table[h];
+		table[h] = mine;
 		// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
-		const uint32_t back0 = (p0 + 1 - e0) & 0xffffu;          // 0: an entry exactly 2^16 back, i.e. stale
-		const uint32_t back1 = (p0 + 2 - e1) & 0xffffu;
-		f.c0 = (can0 && e0 && back0) ? p0 + 1 - back0 : 0u;
-		f.c1 = (can1 && e1 && back1) ? p0 + 2 - back1 : 0u;
-		// settle publish conflicts inside this step (positions differ by < 128)
+		const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
+		f.c = (can && e && back) ? p + 1 - back : 0u;
+		// settle publish conflicts inside this step (positions differ by < 64)
 		for (;;) {
-			const uint16_t now0 = table[h0], now1 = table[h1];
-			const bool again0 = can0 && (uint16_t)(mine0 - now0) - 1u < 0x7fffu;   // mine > now (mod 2^16)
-			const bool again1 = can1 && (uint16_t)(mine1 - now1) - 1u < 0x7fffu;
-			if (!__ballot(again0 || again1))
+			const uint16_t now = table[h];
+			const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;   // mine > now (mod 2^16)
+			if (!__ballot(again))
 				break;
-			if (again0)
-				table[h0] = mine0;
-			if (again1)
-				table[h1] = mine1;
+			if (again)
+				table[h] = mine;
 		}
 		return f;
 	};
 	struct Probed {
-		uint32_t a0, a1, a2, b0, b1, b2;
+		uint32_t c0, c1, c2;
 	};
-	auto probe = [&](const Fetched &f) -> Probed {
+	auto probe = [&](uint32_t c) -> Probed {
 		Probed q;
-		const uint32_t *wa = &ring32[((f.c0 - 1) >> 2) & W4M];
-		const uint32_t *wb = &ring32[((f.c1 - 1) >> 2) & W4M];
-		q.a0 = wa[0];
-		q.a1 = wa[1];
-		q.a2 = wa[2];
-		q.b0 = wb[0];
-		q.b1 = wb[1];
-		q.b2 = wb[2];
+		const uint32_t *w = &ring32[((c - 1) >> 2) & W4M];
+		q.c0 = w[0];
+		q.c1 = w[1];
+		q.c2 = w[2];
 		return q;
 	};
-	// lanes l < k
-	auto lanes_lt = [](uint32_t k) -> uint64_t { return k >= 64 ? ~0ull : ((1ull << k) - 1); };
+
+	// ---- the back of the pipeline: codes + bit packing for up to 64 queued tokens
+	// (straight-line: both forms computed, one selected); false = the static
+	// stream no longer fits under `limit`
+	uint32_t qhead = 0, qtail = 0;
+	auto emit_tokens = [&](uint32_t count) -> bool {
+		const uint32_t t = tokbuf[(qhead + lane) & (TOKQ - 1)];
+		qhead += count;
+		const bool is_match = (t & HD_TOKEN_MATCH) != 0;
+		uint32_t code, nbits;
+		{
+			uint32_t ls, leb, lev, ds, deb, dev;
+			len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
+			off_slot((t & 0xffff) + 1, ds, deb, dev);
+			// litlen symbols 257..279: 7 bits (sym-256); 280..287: 8 bits 0xC0+(sym-280)
+			const uint32_t lc = ls < 23 ? __brev(ls + 1) >> 25 : __brev(0xC0 + (ls - 23)) >> 24;
+			const uint32_t ln7 = ls < 23 ? 7u : 8u;
+			uint32_t mc = lc | (lev << ln7);
+			uint32_t mn = ln7 + leb;
+			mc |= (__brev(ds) >> 27) << mn;
+			mn += 5;
+			mc |= dev << mn;
+			mn += deb;
+			const uint32_t byte = t & 0xff;
+			const uint32_t lcode = byte < 144 ? __brev(0x30 + byte) >> 24 : __brev(0x190 + (byte - 144)) >> 23;
+			const uint32_t lbits = byte < 144 ? 8u : 9u;
+			code = is_match ? mc : lcode;
+			nbits = lane < count ? (is_match ? mn : lbits) : 0u;
+		}
+		const uint32_t incl = wave_incl_scan(nbits);
+		const uint32_t total = readlane(incl, 63);
+		if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit)
+			return false;
+		put(code, nbits, incl, total);
+		flush_ready();
+		return true;
+	};
 
 	// BFINAL = 1, BTYPE = 01
 	put(3u, lane == 0 ? 3u : 0u, 3u, 3u);
 
-	Fetched f0 = { 0, 0, 0, 0, 0, 0 }, f1 = { 0, 0, 0, 0, 0, 0 };
-	Probed q0 = { 0, 0, 0, 0, 0, 0 };
+	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
+	Probed q0 = { 0, 0, 0 };
 	if (use_static && n) {
 		fill_piece();
 		f0 = fetch(0);
-		q0 = probe(f0);
-		f1 = fetch(STEP);
+		q0 = probe(f0.c);
+		f1 = fetch(64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
-	for (uint32_t S = 0; S < n && use_static; S += STEP) {
-		if (filled < n && filled < S + HD_L1_LOOKAHEAD)
+	for (uint32_t S = 0; S < n && use_static; S += 64) {
+		if (filled < n && filled < S + HD_LOOKAHEAD)
 			fill_piece();
 		const uint32_t lo = filled > W ? filled - W : 0;
-		const uint32_t lanes = n - S < STEP ? n - S : STEP;
+		const uint32_t lanes = n - S < 64 ? n - S : 64;
 
 		// stage 2 of step k+1 and stage 1 of step k+2 go out first
 		const Fetched fc = f0;
 		const Probed qc = q0;
 		f0 = f1;
-		q0 = probe(f1);                    // harmless beyond n: every index is masked into the ring
-		f1 = fetch(S + 2 * STEP);
+		q0 = probe(f1.c);                  // harmless beyond n: every index is masked into the ring
+		f1 = fetch(S + 128);
 
-		// ---- 3. verify the candidates + first 8 bytes of their lengths -----
-		const uint32_t p0 = S + 2 * lane;
-		uint32_t dist0, dist1, mylen0, mylen1, eqb0, eqb1;
-		bool ok0, ok1;
-		{
-			const bool can = p0 + HD_MIN_MATCH <= n;
-			const uint32_t cp = fc.c0 - 1;
-			const bool had = can && fc.c0 != 0 && cp >= lo;
-			const uint32_t cv = __builtin_amdgcn_alignbyte(qc.a1, qc.a0, cp & 3);
-			const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.a2, qc.a1, cp & 3);
-			ok0 = had && cv == fc.v0;
-			dist0 = ok0 ? p0 - cp : 1u;
-			const uint32_t x = cvh ^ fc.vh0;
-			eqb0 = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-			const uint32_t room = n - p0;             // >= 4 where ok
-			mylen0 = 4 + eqb0 < room ? 4 + eqb0 : room;
-		}
-		{
-			const uint32_t p1 = p0 + 1;
-			const bool can = p1 + HD_MIN_MATCH <= n;
-			const uint32_t cp = fc.c1 - 1;
-			const bool had = can && fc.c1 != 0 && cp >= lo;
-			const uint32_t cv = __builtin_amdgcn_alignbyte(qc.b1, qc.b0, cp & 3);
-			const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.b2, qc.b1, cp & 3);
-			ok1 = had && cv == fc.v1;
-			dist1 = ok1 ? p1 - cp : 1u;
-			const uint32_t x = cvh ^ fc.vh1;
-			eqb1 = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-			const uint32_t room = n - p1;
-			mylen1 = 4 + eqb1 < room ? 4 + eqb1 : room;
-		}
+		// ---- 3. verify the candidate + first 8 bytes of its length ---------
+		const uint32_t p = S + lane;
+		const bool can = p + HD_MIN_MATCH <= n;
+		const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
+		const bool had = can && fc.c != 0 && cp >= lo;
+		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
+		const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
+		const bool ok = had && cv == cv0;
+		const uint32_t dist = ok ? p - cp : 1u;
+		const uint32_t x = cvh ^ cvh0;
+		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
+		const uint32_t room = n - p;                  // >= 4 where ok
+		uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
 
 		if (carry >= lanes) {                // the whole step lies inside the last match
 			carry -= lanes;
@@ -361,45 +361,36 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		}
 
 		// ---- 4. greedy resolution as a wave prefix scan ---------------------
-		// The greedy parse is a little automaton walking the positions: its state
-		// r = "positions still covered by the current match"; a position with
-		// r == 0 starts a token and sets r = len - 1 (0 for a literal), otherwise
-		// r -= 1.  Each position's transition f : {0..7} -> {0..7} is eight bytes;
-		// composing two of them is two v_perm_b32 table lookups, so a lane first
-		// composes its own two positions and the state entering every lane comes
-		// out of a 6-stage DPP scan -- no per-match serial loop (DNA-like data has
-		// ~12 matches per 64 bytes).  Matches whose first 8 bytes all agree
-		// ("capped") are rare; when the scan takes one it is extended
-		// cooperatively and the chain behind it is re-threaded.
-		const bool capped0 = ok0 && eqb0 == 4 && n - p0 > 8;
-		const bool capped1 = ok1 && eqb1 == 4 && n - p0 > 9;
-		const uint32_t jump0 = ok0 ? (mylen0 < 8 ? mylen0 : 8u) : 1u;   // token length as the scan sees it
-		const uint32_t jump1 = ok1 ? (mylen1 < 8 ? mylen1 : 8u) : 1u;
-		const bool live0 = 2 * lane >= carry, live1 = 2 * lane + 1 >= carry;
-		uint64_t starts0, starts1;
+		// The greedy parse is a little automaton walking the lanes: its state
+		// r = "lanes still covered by the current match"; a lane with r == 0
+		// starts a token and sets r = len - 1 (0 for a literal), otherwise
+		// r -= 1.  Each lane's transition f_l : {0..7} -> {0..7} is eight bytes;
+		// composing two of them is two v_perm_b32 table lookups, so the state
+		// entering every lane comes out of a 6-stage DPP scan -- no per-match
+		// serial loop (DNA-like data has ~12 matches per 64 bytes).  Matches
+		// whose first 8 bytes all agree ("capped") are rare; when the scan
+		// takes one it is extended cooperatively and the scan is redone for
+		// the lanes behind it.
+		const bool capped = ok && eqb == 4 && room > 8;
+		const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;   // token length as the scan sees it
+		uint64_t starts;
 		{
-			const Fn8 fa = fn8_make(live0, jump0 - 1), fb = fn8_make(live1, jump1 - 1);
-			const Fn8 w = fn8_scan(fn8_compose(fb, fa));
-			// state entering lane l = (g_{l-1} o ... o g_0)(0): byte 0 of lane l-1
+			const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1));
+			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1
 			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138 /* wave_shr:1 */,
 										   0xf, 0xf, false);
-			const uint32_t mid = live0 ? (sin ? sin - 1 : jump0 - 1) : sin;   // state entering p1
-			starts0 = __ballot(sin == 0 && live0);
-			starts1 = __ballot(mid == 0 && live1);
+			starts = __ballot(sin == 0 && lane >= carry);
 		}
 		// Capped matches the scan took: extend each (left to right) to its true
 		// length, drop the token starts it now covers, and re-thread the chain
-		// behind it.  Two parses that start a token on the same position coincide
+		// behind it.  Two parses that start a token on the same lane coincide
 		// from there on, so the walk stops at the first old start it lands on
-		// (a few hops) instead of re-scanning the wave.  Positions are numbered
-		// q = 2 * lane + slot here.
-		const uint64_t capmask0 = __ballot(capped0), capmask1 = __ballot(capped1);
-		uint64_t cm0 = starts0 & capmask0, cm1 = starts1 & capmask1;
-		while (cm0 | cm1) {
-			const uint32_t m0 = cm0 ? 2 * ((uint32_t)__ffsll((unsigned long long)cm0) - 1) : 999u;
-			const uint32_t m1 = cm1 ? 2 * ((uint32_t)__ffsll((unsigned long long)cm1) - 1) + 1 : 999u;
-			const uint32_t m = m0 < m1 ? m0 : m1;
-			const uint32_t dm = (m & 1) ? readlane(dist1, m >> 1) : readlane(dist0, m >> 1);
+		// (a few hops) instead of re-scanning the wave.
+		const uint64_t capmask = __ballot(capped);
+		uint64_t cm = starts & capmask;
+		while (cm) {
+			const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
+			const uint32_t dm = readlane(dist, m);
 			const uint32_t pm = S + m;
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
 			uint32_t len = 8;
@@ -414,97 +405,50 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 				if (k < 64)
 					break;
 			}
-			// positions <= m, per slot
-			const uint64_t upto0 = lanes_lt((m + 2) >> 1), upto1 = lanes_lt((m + 1) >> 1);
+			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
 			if (len > 8) {
-				if (lane == (m >> 1)) {
-					if (m & 1)
-						mylen1 = len;
-					else
-						mylen0 = len;
+				if (lane == m)
+					mylen = len;
+				const uint32_t q = m + len;                   // first lane behind the match
+				uint64_t fresh = 0;
+				uint32_t x = q;
+				while (x < 64 && !((starts >> x) & 1)) {
+					fresh |= 1ull << x;
+					x += readlane(jump8, x);
 				}
-				uint64_t fresh0 = 0, fresh1 = 0;
-				uint32_t x = m + len;                         // first position behind the match
-				while (x < STEP) {
-					const uint32_t xl = x >> 1;
-					if (x & 1) {
-						if ((starts1 >> xl) & 1)
-							break;
-						fresh1 |= 1ull << xl;
-						x += readlane(jump1, xl);
-					} else {
-						if ((starts0 >> xl) & 1)
-							break;
-						fresh0 |= 1ull << xl;
-						x += readlane(jump0, xl);
-					}
-				}
-				// positions < x, per slot
-				const uint64_t below0 = lanes_lt((x + 1) >> 1), below1 = lanes_lt(x >> 1);
-				starts0 = (starts0 & (upto0 | ~below0)) | fresh0;
-				starts1 = (starts1 & (upto1 | ~below1)) | fresh1;
+				const uint64_t below_x = x >= 64 ? ~0ull : ((1ull << x) - 1);
+				starts = (starts & (upto_m | ~below_x)) | fresh;
 			}
-			cm0 = starts0 & capmask0 & ~upto0;
-			cm1 = starts1 & capmask1 & ~upto1;
+			cm = starts & capmask & ~upto_m;
 		}
-		// coverage behind the last token of the step (starts != 0: carry < lanes)
+		// coverage behind the last token of the step
+		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
+		const uint32_t E = last + (readlane(ok ? mylen : 1u, last));
+		const bool is_start = (starts >> lane) & 1;
+		const bool is_match = is_start && ok;
+		const bool is_lit = is_start && !ok && lane < lanes;
+		carry = (lanes == 64 && E > 64) ? E - 64 : 0;   // tail step: matches are clipped to n
+
+		// ---- 5. queue the step's tokens in position order -------------------
+		// token word: literal byte, or HD_TOKEN_MATCH | (len - 3) << 16 | (dist - 1).
+		// The code generation and the bit packing below cost the same for 1 or 64
+		// tokens, and DNA-like input yields only ~14 tokens per step: they wait in
+		// a small LDS ring until 64 are there.
 		{
-			const uint32_t l0 = starts0 ? 2 * (63 - (uint32_t)__clzll((long long)starts0)) : 0u;
-			const uint32_t l1 = starts1 ? 2 * (63 - (uint32_t)__clzll((long long)starts1)) + 1 : 0u;
-			const uint32_t last = l0 > l1 ? l0 : l1;
-			const uint32_t ll = (last & 1) ? readlane(ok1 ? mylen1 : 1u, last >> 1)
-						       : readlane(ok0 ? mylen0 : 1u, last >> 1);
-			const uint32_t E = last + ll;
-			carry = (lanes == STEP && E > STEP) ? E - STEP : 0;   // tail step: matches are clipped to n
+			const bool is_tok = is_match || is_lit;
+			const uint64_t tm = __ballot(is_tok);
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
+			tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + lane] =
+				is_match ? (HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1)) : (cv0 & 0xff);
+			qtail += (uint32_t)__popcll(tm);
 		}
-
-		// ---- 5. compact the tokens of the 128 positions into position order --
-		// token word: literal byte, or HD_TOKEN_MATCH | (len - 3) << 16 | (dist - 1)
-		const bool tok0 = ((starts0 >> lane) & 1) && 2 * lane < lanes;
-		const bool tok1 = ((starts1 >> lane) & 1) && 2 * lane + 1 < lanes;
-		const uint64_t tm0 = __ballot(tok0), tm1 = __ballot(tok1);
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm0, 0)) +
-				      __builtin_amdgcn_mbcnt_hi((uint32_t)(tm1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm1, 0));
-		const uint32_t ntok = (uint32_t)__popcll(tm0) + (uint32_t)__popcll(tm1);
-		tokbuf[tok0 ? rank : STEP + lane] = ok0 ? (HD_TOKEN_MATCH | ((mylen0 - 3) << 16) | (dist0 - 1)) : (fc.v0 & 0xff);
-		tokbuf[tok1 ? rank + (tok0 ? 1u : 0u) : STEP + lane] =
-			ok1 ? (HD_TOKEN_MATCH | ((mylen1 - 3) << 16) | (dist1 - 1)) : (fc.v1 & 0xff);
-
-		// ---- 6. codes (straight-line: both forms computed, one selected) ---
-		for (uint32_t base = 0; base < ntok; base += 64) {
-			const uint32_t t = tokbuf[base + lane];
-			const bool valid = base + lane < ntok;
-			const bool is_match = (t & HD_TOKEN_MATCH) != 0;
-			uint32_t code, nbits;
-			{
-				uint32_t ls, leb, lev, ds, deb, dev;
-				len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
-				off_slot((t & 0xffff) + 1, ds, deb, dev);
-				// litlen symbols 257..279: 7 bits (sym-256); 280..287: 8 bits 0xC0+(sym-280)
-				const uint32_t lc = ls < 23 ? __brev(ls + 1) >> 25 : __brev(0xC0 + (ls - 23)) >> 24;
-				const uint32_t ln7 = ls < 23 ? 7u : 8u;
-				uint32_t mc = lc | (lev << ln7);
-				uint32_t mn = ln7 + leb;
-				mc |= (__brev(ds) >> 27) << mn;
-				mn += 5;
-				mc |= dev << mn;
-				mn += deb;
-				const uint32_t byte = t & 0xff;
-				const uint32_t lcode = byte < 144 ? __brev(0x30 + byte) >> 24 : __brev(0x190 + (byte - 144)) >> 23;
-				const uint32_t lbits = byte < 144 ? 8u : 9u;
-				code = is_match ? mc : lcode;
-				nbits = valid ? (is_match ? mn : lbits) : 0u;
-			}
-			const uint32_t incl = wave_incl_scan(nbits);
-			const uint32_t total = readlane(incl, 63);
-			if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit) {
-				use_static = false;
-				break;
-			}
-			put(code, nbits, incl, total);
-			flush_ready();
+		if (qtail - qhead >= 64 && !emit_tokens(64)) {
+			use_static = false;
+			break;
 		}
 	}
+	if (use_static && qtail != qhead && !emit_tokens(qtail - qhead))
+		use_static = false;
 
 	// the CRC needs every piece, also when the static stream was abandoned
 	while (filled < n) {

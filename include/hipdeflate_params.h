@@ -25,14 +25,8 @@
 #define HD_MAX_MATCH       258         /* RFC 1951 3.2.5                    */
 #define HD_PIECE           1024        /* window refill granule (64 x 16 B) */
 #define HD_LOOKAHEAD       384         /* >= 64 + 258 + 8, bytes past S     */
-#define HD_MAX_STEP        128         /* widest step any level uses        */
 
-/* level 1: static Huffman, streaming emit (no token buffer).  Each lane stands
- * on TWO adjacent positions, so a step covers 128 bytes: the table lookups of
- * all 128 positions see only earlier steps (a little ratio for a lot of speed:
- * one scan, one compaction and one code pass serve twice the input) */
-#define HD_L1_STEP         128
-#define HD_L1_LOOKAHEAD    512         /* >= 3 * 128 + 16 (fetch runs two steps ahead) and >= 128 + 258 + 64 */
+/* level 1: static Huffman, streaming emit (no token buffer) */
 #define HD_L1_WIN_BITS     12          /* 4 KiB LDS ring window (occupancy)  */
 #define HD_L1_HASH_BITS    11          /* 2048 x u32 = 8 KiB LDS            */
 
@@ -58,8 +52,8 @@
 #define HD_PRECODE_MAXBITS 7
 
 /* worst-case bits one parse step can emit with the static code:
- * 128 tokens x (8+5 + 5+13 = 31 bits) */
-#define HD_STEP_MAX_BITS   (HD_MAX_STEP * 31)
+ * 64 tokens x (8+5 + 5+13 = 31 bits) */
+#define HD_STEP_MAX_BITS   (64 * 31)
 
 /* stored-block framing cost: 5 bytes per <=65535-byte block, at least one */
 #define HD_STORED_SIZE(n)  ((n) + 5u * ((n) == 0 ? 1u : (((n) + 65534u) / 65535u)))

@@ -18,10 +18,9 @@
  *   length/offset slot tables (:237-318)                -> len_slot()/off_slot()
  *
  * The algorithm (one "step" = what one wavefront does at once):
- *   Steps stand on fixed strides: S = 0, 64, 128, ... at the dynamic levels
- *   (lane l on p = S + l), S = 0, 128, 256, ... at level 1 (lane l on the two
- *   positions S + 2l and S + 2l + 1); `carry` = how many leading positions the
- *   previous steps' last match still covers (it may cover whole steps).
+ *   Steps stand on fixed 64-byte strides: S = 0, 64, 128, ...  Lanes l = 0..63
+ *   stand on p = S + l; `carry` = how many leading positions the previous
+ *   steps' last match still covers (it may cover whole steps).
  *   1. every lane with 4 bytes left hashes in[p..p+4) and reads the table
  *      entry (latest earlier position with that hash, from PREVIOUS steps only),
  *   2. then every such lane -- covered or not -- publishes p:
@@ -31,7 +30,7 @@
  *   4. greedy resolution left to right from lane `carry`: the first candidate at
  *      or after the cursor E is taken, extended to its full length (<= 258,
  *      <= n - p), and E jumps past it; lanes not covered are literals,
- *   5. tokens are emitted in position order; carry = max(E - step width, 0).
+ *   5. tokens are emitted in position order; carry = max(E - 64, 0).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -120,17 +119,15 @@ typedef struct {
 	unsigned hash_bits;
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
-	unsigned width;       /* positions per step: 64, or 128 at level 1 (two per lane) */
-	unsigned lookahead;   /* the ring is kept filled this far past S */
 } mf_t;
 
 typedef struct {
 	unsigned lanes;           /* positions covered by lanes this step */
 	unsigned carry_out;       /* lanes of the NEXT step the last match covers */
-	uint8_t  is_match[HD_MAX_STEP];
-	uint8_t  is_lit[HD_MAX_STEP];
-	uint16_t len[HD_MAX_STEP];
-	uint32_t dist[HD_MAX_STEP];
+	uint8_t  is_match[HD_WAVE];
+	uint8_t  is_lit[HD_WAVE];
+	uint16_t len[HD_WAVE];
+	uint32_t dist[HD_WAVE];
 } step_t;
 
 static uint32_t load32(const uint8_t *p)
@@ -141,13 +138,13 @@ static uint32_t load32(const uint8_t *p)
 static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
 		       unsigned minlen, int lazy, step_t *st)
 {
-	uint32_t cand[HD_MAX_STEP];
-	uint8_t ok[HD_MAX_STEP], cap8[HD_MAX_STEP];
-	unsigned lanes = n - S < mf->width ? (unsigned)(n - S) : mf->width;
+	uint32_t cand[HD_WAVE];
+	uint8_t ok[HD_WAVE], cap8[HD_WAVE];
+	unsigned lanes = n - S < HD_WAVE ? (unsigned)(n - S) : HD_WAVE;
 
 	/* the ring is refilled a 1 KiB piece at a time until it holds
-	 * `lookahead` bytes past S (or the whole input) */
-	while (mf->filled < n && mf->filled < S + mf->lookahead)
+	 * HD_LOOKAHEAD bytes past S (or the whole input) */
+	while (mf->filled < n && mf->filled < S + HD_LOOKAHEAD)
 		mf->filled += HD_PIECE;
 	size_t lo = mf->filled > mf->win ? mf->filled - mf->win : 0;
 
@@ -194,7 +191,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	if (lazy) {
 		/* one-lane lookahead: a candidate steps aside (becomes a literal) when
 		 * its right neighbour's match is longer, judged on the 8-byte lengths */
-		uint8_t defer[HD_MAX_STEP];
+		uint8_t defer[HD_WAVE];
 		for (unsigned l = 0; l < lanes; l++)
 			defer[l] = ok[l] && l + 1 < lanes && ok[l + 1] && cap8[l + 1] > cap8[l];
 		for (unsigned l = 0; l < lanes; l++)
@@ -238,7 +235,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, HD_L1_STEP, HD_L1_LOOKAHEAD };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
@@ -247,7 +244,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	bw_put(&w, 1, 1);       /* BFINAL */
 	bw_put(&w, 1, 2);       /* BTYPE = 01 */
 	unsigned carry = 0;
-	for (size_t S = 0; S < n && use_static; S += HD_L1_STEP) {
+	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
 		parse_step(&mf, in, n, S, carry, HD_MIN_MATCH, 0, &st);
 		carry = st.carry_out;
 		/* the kernel knows the step's bit count (wave prefix sum) before it
@@ -569,7 +566,7 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	size_t stored = HD_STORED_SIZE(n);
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + 64);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, HD_WAVE, HD_LOOKAHEAD };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
 	step_t st;
