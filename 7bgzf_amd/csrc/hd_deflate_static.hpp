@@ -185,6 +185,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			: lane == 2 ? (a.frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u)
 				    : (a.frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du);
 
+	Fn8Ident fid;
+	fid.init(lane);
 	CrcLanes crc;
 	crc.init(lane, n);
 	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;   // token length as the scan sees it
 		uint64_t starts;
 		{
-			const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1));
+			const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1), fid);
 			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1
 			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138 /* wave_shr:1 */,
 										   0xf, 0xf, false);
@@ -395,10 +397,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
 			uint32_t len = 8;
 			for (;;) {
+				// (every index is masked into the ring, so lanes past maxlen may read too)
 				const uint32_t idx = len + lane;
-				bool diff = true;
-				if (idx < maxlen)
-					diff = ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)];
+				const bool diff = (idx >= maxlen) |
+						  (ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]);
 				const uint64_t nq = __ballot(diff);
 				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
 				len += k;

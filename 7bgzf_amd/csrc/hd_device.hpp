@@ -51,13 +51,31 @@ struct Fn8 {
 	uint32_t lo, hi;
 };
 
+// Lanes that a DPP stage leaves without a source must see the identity map
+// {0,1,2,3 | 4,5,6,7}.  The shifted value is read with "0 where there is no
+// source" and OR-ed with a per-lane constant that is the identity exactly on
+// those lanes: mov_dpp + or fold into one v_or_b32_dpp, where seeding the
+// destination with the identity would cost an extra v_mov per dword and stage.
+struct Fn8Ident {
+	uint32_t lo[6], hi[6];          // per scan stage
+	__device__ __forceinline__ void init(uint32_t lane)
+	{
+		const uint32_t r = lane & 15;
+		const bool none[6] = { r < 1, r < 2, r < 4, r < 8, !((lane >> 4) & 1), lane < 32 };
+#pragma unroll
+		for (int k = 0; k < 6; k++) {
+			lo[k] = none[k] ? 0x03020100u : 0u;
+			hi[k] = none[k] ? 0x07060504u : 0u;
+		}
+	}
+};
+
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ Fn8 fn8_dpp(Fn8 v)
+__device__ __forceinline__ Fn8 fn8_dpp(Fn8 v, uint32_t id_lo, uint32_t id_hi)
 {
-	// lanes without a source keep the identity map {0,1,2,3 | 4,5,6,7}
 	Fn8 r;
-	r.lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.lo, CTRL, ROW_MASK, 0xf, false);
-	r.hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.hi, CTRL, ROW_MASK, 0xf, false);
+	r.lo = dpp0<CTRL, ROW_MASK, 0xf>(v.lo) | id_lo;
+	r.hi = dpp0<CTRL, ROW_MASK, 0xf>(v.hi) | id_hi;
 	return r;
 }
 
@@ -71,14 +89,36 @@ __device__ __forceinline__ Fn8 fn8_compose(Fn8 then, Fn8 first)
 }
 
 // inclusive scan: result at lane l = f_l o ... o f_0
+__device__ __forceinline__ Fn8 fn8_scan(Fn8 w, const Fn8Ident &id)
+{
+	w = fn8_compose(w, fn8_dpp<0x111, 0xf>(w, id.lo[0], id.hi[0]));   // row_shr:1
+	w = fn8_compose(w, fn8_dpp<0x112, 0xf>(w, id.lo[1], id.hi[1]));   // row_shr:2
+	w = fn8_compose(w, fn8_dpp<0x114, 0xf>(w, id.lo[2], id.hi[2]));   // row_shr:4
+	w = fn8_compose(w, fn8_dpp<0x118, 0xf>(w, id.lo[3], id.hi[3]));   // row_shr:8
+	w = fn8_compose(w, fn8_dpp<0x142, 0xa>(w, id.lo[4], id.hi[4]));   // row_bcast:15 -> rows 1,3
+	w = fn8_compose(w, fn8_dpp<0x143, 0xc>(w, id.lo[5], id.hi[5]));   // row_bcast:31 -> rows 2,3
+	return w;
+}
+
+// the same scan with the identity seeded by v_mov instead of the 12 registers
+// of Fn8Ident (the dynamic-level kernels sit at their VGPR budget)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Fn8 fn8_dpp_seeded(Fn8 v)
+{
+	Fn8 r;
+	r.lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0x03020100, (int)v.lo, CTRL, ROW_MASK, 0xf, false);
+	r.hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x07060504, (int)v.hi, CTRL, ROW_MASK, 0xf, false);
+	return r;
+}
+
 __device__ __forceinline__ Fn8 fn8_scan(Fn8 w)
 {
-	w = fn8_compose(w, fn8_dpp<0x111, 0xf>(w));   // row_shr:1
-	w = fn8_compose(w, fn8_dpp<0x112, 0xf>(w));   // row_shr:2
-	w = fn8_compose(w, fn8_dpp<0x114, 0xf>(w));   // row_shr:4
-	w = fn8_compose(w, fn8_dpp<0x118, 0xf>(w));   // row_shr:8
-	w = fn8_compose(w, fn8_dpp<0x142, 0xa>(w));   // row_bcast:15 -> rows 1,3
-	w = fn8_compose(w, fn8_dpp<0x143, 0xc>(w));   // row_bcast:31 -> rows 2,3
+	w = fn8_compose(w, fn8_dpp_seeded<0x111, 0xf>(w));
+	w = fn8_compose(w, fn8_dpp_seeded<0x112, 0xf>(w));
+	w = fn8_compose(w, fn8_dpp_seeded<0x114, 0xf>(w));
+	w = fn8_compose(w, fn8_dpp_seeded<0x118, 0xf>(w));
+	w = fn8_compose(w, fn8_dpp_seeded<0x142, 0xa>(w));
+	w = fn8_compose(w, fn8_dpp_seeded<0x143, 0xc>(w));
 	return w;
 }
 
