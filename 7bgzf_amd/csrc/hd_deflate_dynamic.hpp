@@ -29,9 +29,10 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
-	// one persistent wave per LDS slot of the level (16 KiB -> 9 safely resident per CU,
-	// 44 KiB -> 3); a grid larger than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 5 ? 4u : 9u;
+	// one persistent wave per LDS slot of the level (14.5 KiB -> 10 resident per CU -- 11 do
+	// not fit, measured --, 34.5 KiB -> 4); a grid larger than what is resident would run
+	// its tail serially
+	const uint32_t per_cu = level >= 5 ? 4u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -184,7 +185,6 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 
 struct DynLds {
 	uint32_t lf[288], df[32];          // histograms of the open DEFLATE block
-	uint32_t lcode[288], dcode[32];    // code | len << 16
 	uint32_t pcode[19], pfreq[19];
 	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen
 };
@@ -196,6 +196,7 @@ struct DynBuild {
 	HuffScratch hs;
 	uint16_t items[288 + 32];          // RLE of the code lengths: symbol | extra << 8
 	uint8_t lens[288 + 32];
+	uint32_t lcode[288], dcode[32];    // code | len << 16: live from the construction to the end of the emit pass
 };
 
 __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
@@ -344,20 +345,20 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		auto flush_block = [&](bool final) -> bool {
 			if (lane == 0)
 				L.lf[256] += 1;                     // end of block
-			build_code(L.lf, 288, HD_LITLEN_MAXBITS, L.lcode, Bd.hs, lane);
-			build_code(L.df, 32, HD_OFFSET_MAXBITS, L.dcode, Bd.hs, lane);
+			build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane);
+			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, Bd.hs, lane);
 			if (lane < 19)
 				L.pfreq[lane] = 0;
 			if (lane == 0) {
 				uint32_t hlit = 286, hdist = 30;
-				while (hlit > 257 && (L.lcode[hlit - 1] >> 16) == 0)
+				while (hlit > 257 && (Bd.lcode[hlit - 1] >> 16) == 0)
 					hlit--;
-				while (hdist > 1 && (L.dcode[hdist - 1] >> 16) == 0)
+				while (hdist > 1 && (Bd.dcode[hdist - 1] >> 16) == 0)
 					hdist--;
 				for (uint32_t i = 0; i < hlit; i++)
-					Bd.lens[i] = (uint8_t)(L.lcode[i] >> 16);
+					Bd.lens[i] = (uint8_t)(Bd.lcode[i] >> 16);
 				for (uint32_t i = 0; i < hdist; i++)
-					Bd.lens[hlit + i] = (uint8_t)(L.dcode[i] >> 16);
+					Bd.lens[hlit + i] = (uint8_t)(Bd.dcode[i] >> 16);
 				const uint32_t total = hlit + hdist;
 				uint32_t ni = 0, i = 0;
 				while (i < total) {
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				const uint32_t s = base + lane;
 				if (s < 286) {
 					const uint32_t f = L.lf[s];
-					dyn += f * (L.lcode[s] >> 16);
+					dyn += f * (Bd.lcode[s] >> 16);
 					sta += f * (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
 					if (s >= 265 && s < 285)
 						extra += f * ((s - 261) >> 2);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			}
 			if (lane < 30) {
 				const uint32_t f = L.df[lane];
-				dyn += f * (L.dcode[lane] >> 16);
+				dyn += f * (Bd.dcode[lane] >> 16);
 				sta += f * 5u;
 				extra += f * (lane < 4 ? 0u : (lane >> 1) - 1);
 			}
@@ -462,10 +463,10 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				for (uint32_t s = lane; s < 288; s += 64) {
 					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
 					const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
-					L.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
+					Bd.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
 				}
 				if (lane < 32)
-					L.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
+					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
 			}
 			// ---- pass 2: the tokens -------------------------------------------
 			for (uint32_t base = 0; base < ntok; base += 64) {
@@ -477,13 +478,13 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 						uint32_t ls, leb, lev, ds, deb, dev;
 						len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
 						off_slot((tk & 0xffff) + 1, ds, deb, dev);
-						const uint32_t lc = L.lcode[257 + ls], dc = L.dcode[ds];
+						const uint32_t lc = Bd.lcode[257 + ls], dc = Bd.dcode[ds];
 						ca = (lc & 0xffff) | (lev << (lc >> 16));
 						na = (lc >> 16) + leb;
 						cb = (dc & 0xffff) | (dev << (dc >> 16));
 						nb = (dc >> 16) + deb;
 					} else {
-						const uint32_t lc = L.lcode[tk & 0xff];
+						const uint32_t lc = Bd.lcode[tk & 0xff];
 						ca = lc & 0xffff;
 						na = lc >> 16;
 					}
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				flush_ready();
 			}
 			{
-				const uint32_t eob = L.lcode[256];
+				const uint32_t eob = Bd.lcode[256];
 				emit1(lane == 0 ? (eob & 0xffff) : 0u, lane == 0 ? (eob >> 16) : 0u);
 			}
 			for (uint32_t i = lane; i < 288; i += 64)
