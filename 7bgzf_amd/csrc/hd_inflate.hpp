@@ -354,26 +354,42 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const bool slow = kind == K_SLOW || (is_len && ((dd >> 8) & 3) == K_SLOW);
 			const uint32_t tokbits = is_len ? t1 + dlen + deb : len1;
 			const uint32_t outlen = kind == K_LIT ? 1u : is_len ? length : 0u;
-			// meta: [5:0] tokbits  [14:6] outlen  [15] slow  [16] eob
-			const uint32_t meta = tokbits | (outlen << 6) | (slow ? 1u << 15 : 0u) | (kind == K_EOB ? 1u << 16 : 0u);
 
-			// the real chain from bit 0 of the window
-			uint32_t b = 0, cum = 0, stop = 0;
-			uint64_t real = 0;
-			while (b < 64) {
-				const uint32_t m = readlane(meta, b);
-				if (m & (1u << 15)) { stop = 2; break; }
-				const uint32_t ol = (m >> 6) & 511;
-				if (cum + ol > WIN_OUT_BUDGET) { stop = 3; break; }
-				real |= 1ull << b;
-				cum += ol;
-				b += m & 63;
-				if (m & (1u << 16)) { stop = 1; break; }
+			// The real chain from bit 0 of the window.  This walk is the hottest scalar
+			// code of the kernel (the CU has one scalar ALU) and the compiler spends ~20
+			// instructions per token on it, so it is written out: 4 SALU + 2 branches
+			// + 1 v_readlane per token.  It stops in front of the first token the window
+			// cannot take (long codeword, end of block); that one goes to the scalar loop.
+			const uint32_t walk = tokbits | ((slow || kind == K_EOB) ? 64u : 0u);
+			uint32_t b, wm;
+			uint64_t real;
+			// (a lane select written by the SALU needs no wait states before v_readlane,
+			// only one written by the VALU does)
+			asm volatile("s_mov_b32 %0, 0\n\t"
+				     "s_mov_b64 %1, 0\n"
+				     "Lhd_walk_%=:\n\t"
+				     "v_readlane_b32 %2, %3, %0\n\t"
+				     "s_bitcmp1_b32 %2, 6\n\t"
+				     "s_cbranch_scc1 Lhd_walk_done_%=\n\t"
+				     "s_bitset1_b64 %1, %0\n\t"
+				     "s_add_u32 %0, %0, %2\n\t"
+				     "s_cmp_lt_u32 %0, 64\n\t"
+				     "s_cbranch_scc1 Lhd_walk_%=\n"
+				     "Lhd_walk_done_%=:"
+				     : "=&s"(b), "=&s"(real), "=&s"(wm)
+				     : "v"(walk)
+				     : "scc");
+			// cut in front of the first token that would overrun the output budget
+			const uint32_t incl = wave_incl_scan(((real >> lane) & 1) ? outlen : 0u);
+			const uint64_t over = __ballot(((real >> lane) & 1) && incl > WIN_OUT_BUDGET);
+			if (over) {
+				b = (uint32_t)__ffsll((unsigned long long)over) - 1;
+				real &= (1ull << b) - 1;
 			}
 			if (real == 0)
-				break;                                     // a slow token right at B: scalar loop
+				break;                                     // the token at B is not for a window: scalar loop
+			const uint32_t cum = readlane(incl, 63 - (uint32_t)__clzll((long long)real));
 			const bool mine = (real >> lane) & 1;
-			const uint32_t incl = wave_incl_scan(mine ? outlen : 0u);
 			const uint32_t opos = pos + incl - outlen;     // valid where `mine`
 			if (mine && kind == K_LIT)
 				L.ring[opos & (INF_RING - 1)] = (uint8_t)(e >> 16);
@@ -425,10 +441,6 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			}
 			pos = wend;
 			B += b;
-			if (stop == 1) {
-				result = 1;
-				break;
-			}
 		}
 		// hand the position back to the scalar reader
 		dw = B >> 5;
