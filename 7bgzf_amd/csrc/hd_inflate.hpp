@@ -90,7 +90,7 @@ struct InfLds {
 		};
 		uint32_t comp[256];               // 4 pieces of the compressed stream for the window decoder
 	};
-	__attribute__((aligned(16))) uint8_t ring[INF_RING];
+	__attribute__((aligned(16))) uint8_t ring[INF_RING + 64];   // + a dump slot per lane
 };
 
 // Build one decode table from code lengths (all 64 lanes).  Returns false for
@@ -399,18 +399,25 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t srcl = opos - offset;                         // wraps when offset > opos
 			const bool bad = __ballot(my_match && offset > opos) != 0;    // decompress_template.h:724
 			const bool in_ring = wend - srcl <= INF_RING - 64;
-			const uint64_t simple = __ballot(my_match && in_ring && offset >= length && length <= 64);
-			uint64_t mm = __ballot(my_match);
+			// "simple": source wholly in the ring and wholly in front of this window's output,
+			// at most 64 bytes.  Nothing in the window feeds them, so they go first, in a
+			// loop with no exec juggling (lanes past the length write to a dump slot behind
+			// the ring); whatever else there is follows in stream order.
+			const uint32_t opos_rel = incl - outlen;
+			const uint64_t simple = __ballot(my_match && in_ring && offset >= opos_rel + length && length <= 64);
+			uint64_t sm = bad ? 0 : simple;
+			while (sm) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
+				sm &= sm - 1;
+				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
+				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
+				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
+			}
+			uint64_t mm = __ballot(my_match) & ~simple;
 			while (mm && !bad) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				mm &= mm - 1;
 				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
-				if ((simple >> m) & 1) {
-					// <= 64 bytes, disjoint, source in the ring: one read, one write
-					if (lane < mlen)
-						L.ring[(P + lane) & (INF_RING - 1)] = L.ring[(srcp + lane) & (INF_RING - 1)];
-					continue;
-				}
 				const uint32_t moff = P - srcp;
 				if (wend - srcp <= INF_RING - 64) {
 					// source still in the ring (the literals of the whole window are already in)
