@@ -397,7 +397,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// per-lane verdicts for the matches, so that the scalar loop below only dispatches
 			const bool my_match = mine && is_len;
 			const uint32_t srcl = opos - offset;                         // wraps when offset > opos
-			const bool bad = __ballot(my_match && offset > opos) != 0;    // decompress_template.h:724
+			if (__ballot(my_match && offset > opos)) {                   // decompress_template.h:724
+				st_out = HD_BAD_DATA;
+				result = 2;
+				break;
+			}
 			const bool in_ring = wend - srcl <= INF_RING - 64;
 			// "simple": source wholly in the ring and wholly in front of this window's output,
 			// at most 64 bytes.  Nothing in the window feeds them, so they go first, in a
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// the ring); whatever else there is follows in stream order.
 			const uint32_t opos_rel = incl - outlen;
 			const uint64_t simple = __ballot(my_match && in_ring && offset >= opos_rel + length && length <= 64);
-			uint64_t sm = bad ? 0 : simple;
+			uint64_t sm = simple;
 			while (sm) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				sm &= sm - 1;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
 			uint64_t mm = __ballot(my_match) & ~simple;
-			while (mm && !bad) {
+			while (mm) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				mm &= mm - 1;
 				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
@@ -440,11 +444,6 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					for (uint32_t i = lane; i < mlen; i += 64)
 						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
 				}
-			}
-			if (bad) {
-				st_out = HD_BAD_DATA;
-				result = 2;
-				break;
 			}
 			pos = wend;
 			B += b;
