@@ -21,7 +21,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhipdeflate.so")
 
-FRAME_RAW, FRAME_BGZF, FRAME_MIGZ = 0, 1, 2
+FRAME_RAW, FRAME_BGZF, FRAME_MIGZ, FRAME_RAW_FLUSH = 0, 1, 2, 3
 DEFLATE_HIP = 11
 HD_E_NODEVICE, HD_E_ARG, HD_E_NOMEM = 100, 101, 102
 
@@ -39,7 +39,7 @@ _vp = ctypes.c_void_p
 # every symbol include/hipdeflate.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "hipdeflate_init", "hipdeflate_shutdown", "hipdeflate_available", "hipdeflate_version",
-    "hip_deflate", "hip_inflate", "hipdeflate_batch_deflate", "hipdeflate_batch_inflate",
+    "hip_deflate", "hip_deflate_flush", "hip_inflate", "hipdeflate_batch_deflate", "hipdeflate_batch_inflate",
     "hipdeflate_batch_deflate_dev", "hipdeflate_batch_inflate_dev", "hipdeflate_scan_sizes_dev",
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
 ]
@@ -87,6 +87,7 @@ def lib():
     L.hipdeflate_init.argtypes = [ctypes.c_int]
     sz_p = ctypes.POINTER(ctypes.c_size_t)
     L.hip_deflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
+    L.hip_deflate_flush.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hip_inflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t]
     L.bgzf_compress.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hipdeflate_batch_deflate.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _vp,
@@ -141,6 +142,17 @@ def hip_deflate(data, level=1, cap=None):
     dst = np.zeros(max(cap, 1), dtype=np.uint8)
     n = ctypes.c_size_t(cap)
     r = lib().hip_deflate(_p(dst), ctypes.byref(n), _p(src), len(src), level)
+    return r, bytes(dst[: n.value]) if r == 0 else b""
+
+
+def hip_deflate_flush(data, level=1, cap=None):
+    """-> (ret, bytes) in full-flush form: what zlibutil_buffer_full_flush
+    (applet/7dictzip.c:93-126) makes of a codec's output."""
+    src = as_u8(data)
+    cap = (len(src) + len(src) // 2 + 64) if cap is None else cap
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = ctypes.c_size_t(cap)
+    r = lib().hip_deflate_flush(_p(dst), ctypes.byref(n), _p(src), len(src), level)
     return r, bytes(dst[: n.value]) if r == 0 else b""
 
 

@@ -225,7 +225,7 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	int r = ensure();
 	if (r)
 		return r;
-	if (frame < HD_FRAME_RAW || frame > HD_FRAME_MIGZ || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
+	if (frame < HD_FRAME_RAW || frame > HD_FRAME_RAW_FLUSH || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
 		return HD_E_ARG;
 	hd::DeflateArgs a;
 	a.in = (const uint8_t *)in;
@@ -343,7 +343,7 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 		return r;
 	if (nblocks == 0)
 		return 0;
-	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_MIGZ)
+	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_RAW_FLUSH)
 		return HD_E_ARG;
 	std::lock_guard<std::mutex> lk(g.mu);
 	if ((r = bind_device()))
@@ -494,7 +494,8 @@ int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const ui
 
 /* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */
 
-int hip_deflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level)
+static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level,
+		       int frame)
 {
 	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xffffffffu - 65536u)
 		return HD_E_ARG;
@@ -503,7 +504,7 @@ int hip_deflate(unsigned char *dest, size_t *destLen, const unsigned char *sourc
 	int32_t st = 0;
 	const size_t cap = *destLen > 0xfffffff0u ? 0xfffffff0u : *destLen;
 	// the slot stride handed to the batch call only needs to cover `cap`
-	int r = hipdeflate_batch_deflate(source, &off, &len, 1, level, HD_FRAME_RAW, dest, up16(cap) ? up16(cap) : 16,
+	int r = hipdeflate_batch_deflate(source, &off, &len, 1, level, frame, dest, up16(cap) ? up16(cap) : 16,
 					 (uint32_t)cap, &olen, nullptr, &st);
 	if (r)
 		return r;
@@ -511,6 +512,16 @@ int hip_deflate(unsigned char *dest, size_t *destLen, const unsigned char *sourc
 		return 1; /* !Z_OK, as libdeflate_deflate (lib/zlibutil.c:189) */
 	*destLen = olen;
 	return 0;
+}
+
+int hip_deflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level)
+{
+	return deflate_one(dest, destLen, source, sourceLen, level, HD_FRAME_RAW);
+}
+
+int hip_deflate_flush(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level)
+{
+	return deflate_one(dest, destLen, source, sourceLen, level, HD_FRAME_RAW_FLUSH);
 }
 
 int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)

@@ -238,9 +238,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const uint32_t cap = (uint32_t)cap64;
 		const uint32_t stored = HD_STORED_SIZE(n);
 		uint32_t limit = stored - 1;
-		bool alive = cap >= hdr + trl + 2;
-		if (alive && cap - hdr - trl < limit)
-			limit = cap - hdr - trl;
+		const bool flush = a.frame == HD_FRAME_RAW_FLUSH;
+		const uint32_t sfx = frame_sfx_bytes(a.frame);
+		bool alive = cap >= hdr + trl + sfx + 2;
+		if (alive && cap - hdr - trl - sfx < limit)
+			limit = cap - hdr - trl - sfx;
 		const uint64_t limit_bits = 8ull * limit;
 
 		// ---- init LDS ---------------------------------------------------
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			if (use_dynamic) {
 				// BFINAL, BTYPE=10, HLIT, HDIST, HCLEN in lanes 0..4, then the precode lengths
 				uint32_t c0 = 0, n0 = 0;
-				if (lane == 0) { c0 = final ? 1u : 0u; n0 = 1; }
+				if (lane == 0) { c0 = (final && !flush) ? 1u : 0u; n0 = 1; }
 				else if (lane == 1) { c0 = 2; n0 = 2; }
 				else if (lane == 2) { c0 = hlit - 257; n0 = 5; }
 				else if (lane == 3) { c0 = hdist - 1; n0 = 5; }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 					emit1(cc, nn);
 				}
 			} else {
-				emit1(lane == 0 ? (final ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
+				emit1(lane == 0 ? ((final && !flush) ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
 				// static code tables in the same format
 				for (uint32_t s = lane; s < 288; s += 64) {
 					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
@@ -656,6 +658,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		if (!alive) {
 			write_stored_member(a, b, src, n, crcv, lane);
 			continue;
+		}
+		if (flush) {
+			// empty stored block header (000), alignment, LEN = 0, NLEN = ffff
+			bitpos = (bitpos + 3 + 7) & ~7u;
+			emit1(lane == 1 ? 0xffffu : 0u, lane < 2 ? 16u : 0u);
 		}
 		bitpos = (bitpos + 7) & ~7u;
 		const uint32_t paylen = (bitpos - paybase) >> 3;

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
 	return frame == HD_FRAME_BGZF ? 18u : frame == HD_FRAME_MIGZ ? 20u : 0u;
 }
 
+// HD_FRAME_RAW_FLUSH: room kept for the flush suffix (3 header bits + alignment, 00 00 ff ff)
+__device__ __forceinline__ uint32_t frame_sfx_bytes(int frame)
+{
+	return frame == HD_FRAME_RAW_FLUSH ? 5u : 0u;
+}
+
 // byte `o` of the container header; `sizefield` = BSIZE (u16) or compsize (u32)
 __device__ __forceinline__ uint32_t frame_hdr_byte(int frame, uint32_t o, uint32_t sizefield)
 {
@@ -64,8 +70,9 @@ __device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32
 						  uint32_t crc, uint32_t lane)
 {
 	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+	const bool flush = a.frame == HD_FRAME_RAW_FLUSH;   // no final block; empty stored block 00 | 00 00 ff ff behind
 	const uint32_t stored = HD_STORED_SIZE(n);
-	const uint32_t total = hdr + stored + trl;
+	const uint32_t total = hdr + stored + trl + (flush ? 5u : 0u);
 	uint64_t cap = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
 	if (a.frame == HD_FRAME_BGZF && cap > 65536)
 		cap = 65536;
@@ -90,7 +97,7 @@ __device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32
 				uint32_t q = (o - hdr) / 65540u, r = (o - hdr) - q * 65540u;
 				uint32_t left = n - q * 65535u;
 				uint32_t bl = left < 65535u ? left : 65535u;
-				if (r == 0) v = (q + 1 == nblk) ? 1u : 0u;
+				if (r == 0) v = (q + 1 == nblk && !flush) ? 1u : 0u;
 				else if (r == 1) v = bl & 0xff;
 				else if (r == 2) v = bl >> 8;
 				else if (r == 3) v = ~bl & 0xff;
@@ -98,7 +105,7 @@ __device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32
 				else v = src[q * 65535u + r - 5];
 			} else if (o < total) {
 				uint32_t t = o - hdr - stored;
-				v = ((t < 4 ? crc : n) >> (8 * (t & 3))) & 0xff;
+				v = flush ? (t >= 3 ? 0xffu : 0u) : ((t < 4 ? crc : n) >> (8 * (t & 3))) & 0xff;
 			}
 			w |= v << (8 * k);
 		}
@@ -171,9 +178,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// the static stream survives only while it stays strictly below the stored
 	// size and inside the slot (twin: deflate_static(), `limit`)
 	uint32_t limit = stored - 1;
-	bool use_static = a.level >= 1 && cap >= hdr + trl + 2;   // level 0: stored only
-	if (use_static && cap - hdr - trl < limit)
-		limit = cap - hdr - trl;
+	const bool flush = a.frame == HD_FRAME_RAW_FLUSH;
+	const uint32_t sfx = frame_sfx_bytes(a.frame);
+	bool use_static = a.level >= 1 && cap >= hdr + trl + sfx + 2;   // level 0: stored only
+	if (use_static && cap - hdr - trl - sfx < limit)
+		limit = cap - hdr - trl - sfx;
 
 	// ---- init LDS -------------------------------------------------------
 	for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
@@ -318,8 +327,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		return true;
 	};
 
-	// BFINAL = 1, BTYPE = 01
-	put(3u, lane == 0 ? 3u : 0u, 3u, 3u);
+	// BFINAL = 1 (0 in flush form), BTYPE = 01
+	put(flush ? 2u : 3u, lane == 0 ? 3u : 0u, 3u, 3u);
 
 	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
 	Probed q0 = { 0, 0, 0 };
@@ -472,6 +481,17 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 
 	// end-of-block (7 zero bits), pad to a byte, then CRC32 + ISIZE as 4 x 16 bits
 	bitpos += 7;
+	if (flush) {
+		// header of an empty stored block (BFINAL = 0, BTYPE = 00), alignment, LEN = 0, NLEN = ffff
+		bitpos = (bitpos + 3 + 7) & ~7u;
+		uint32_t tcode = 0, nb = 0;
+		if (lane < 2) {
+			tcode = lane ? 0xffffu : 0u;
+			nb = 16;
+		}
+		const uint32_t incl = wave_incl_scan(nb);
+		put(tcode, nb, incl, 32);
+	}
 	bitpos = (bitpos + 7) & ~7u;
 	const uint32_t paylen = (bitpos - paybase) >> 3;
 	if (trl) {

@@ -119,6 +119,19 @@ hd_zlibutil_buffer *hd_zlibutil_buffer_code(hd_zlibutil_buffer *z)
 	return z;
 }
 
+hd_zlibutil_buffer *hd_zlibutil_buffer_full_flush(hd_zlibutil_buffer *z)
+{
+	/* the reference asserts raw mode here (applet/7dictzip.c:96) */
+	if (!z->encode || z->rfc1950 || z->rfc1952 || z->func != (void *)hip_deflate) {
+		z->ret = -1;
+		return z;
+	}
+	z->func = (void *)hip_deflate_flush;
+	hd_zlibutil_buffer_code(z);
+	z->func = (void *)hip_deflate;
+	return z;
+}
+
 void hd_zlibutil_buffer_free(hd_zlibutil_buffer *z)
 {
 	if (z) {

@@ -32,6 +32,10 @@ typedef int (*hd_zlibutil_code_enc)(unsigned char *, size_t *, const unsigned ch
 
 hd_zlibutil_buffer *hd_zlibutil_buffer_allocate(size_t destSiz, size_t sourceSiz);
 hd_zlibutil_buffer *hd_zlibutil_buffer_code(hd_zlibutil_buffer *zlibbuf);
+/* zlibutil_buffer_full_flush (applet/7dictzip.c:93-126, applet/7razf.c:126-160): code the buffer, then
+ * leave it in full-flush form.  With func = hip_deflate the kernel emits that form itself (no re-inflate);
+ * any other func gives ret = -1, as the reference does when its inflateInit2 fails. */
+hd_zlibutil_buffer *hd_zlibutil_buffer_full_flush(hd_zlibutil_buffer *zlibbuf);
 void hd_zlibutil_buffer_free(hd_zlibutil_buffer *zlibbuf);
 
 /* host checksums used by the RFC 1950 / 1952 wrappers */

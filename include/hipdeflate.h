@@ -45,6 +45,11 @@ extern "C" {
 #define HD_FRAME_RAW   0     /* raw DEFLATE only (what a zlibutil codec returns) */
 #define HD_FRAME_BGZF  1     /* applet/7bgzf.c:263-272: 18 B header, CRC32, ISIZE */
 #define HD_FRAME_MIGZ  2     /* applet/7migz.c:224-233: 20 B header, CRC32, ISIZE */
+#define HD_FRAME_RAW_FLUSH 3 /* raw DEFLATE in full-flush form: no block is final, then an empty stored
+                              * block header, byte alignment and 00 00 ff ff -- byte for byte what
+                              * zlibutil_buffer_full_flush (applet/7dictzip.c:93-126, 7razf.c:126-160)
+                              * makes of a codec's output by re-inflating it with a patched zlib; here it
+                              * comes straight from the kernel.  Chunks in this form concatenate. */
 
 /* ---- lifetime ---------------------------------------------------------- */
 
@@ -71,6 +76,11 @@ int hip_deflate(unsigned char *dest, size_t *destLen,
  * (lib/zlibutil.c:194-204). */
 int hip_inflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen);
+
+/* hip_deflate followed by zlibutil_buffer_full_flush (applet/7dictzip.c:93-126):
+ * same contract, output in HD_FRAME_RAW_FLUSH form. */
+int hip_deflate_flush(unsigned char *dest, size_t *destLen,
+		      const unsigned char *source, size_t sourceLen, int level);
 
 /* ---- batch API, host buffers ------------------------------------------- */
 

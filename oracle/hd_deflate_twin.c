@@ -222,26 +222,28 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	st->carry_out = E > lanes ? E - lanes : 0;   /* E >= carry always */
 }
 
-static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n);
+static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n, int flush);
+static void put_flush_suffix(bw_t *w);
 
 /* ---- level 1: greedy + static Huffman, streaming ------------------------ */
 static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			  unsigned win_bits, unsigned hash_bits)
+			  unsigned win_bits, unsigned hash_bits, int flush)
 {
-	size_t cap = *destLen;
+	/* flush form: 5 bytes are kept free for the suffix (put_flush_suffix) */
+	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
 	/* the static stream is kept only if it ends up strictly smaller than the
 	 * stored form and fits; tie -> stored, as deflate_flush_block's
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
-	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16);
+	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
 	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
 	uint8_t scratch[HD_STEP_MAX_BITS / 8 + 8];
 
-	bw_put(&w, 1, 1);       /* BFINAL */
+	bw_put(&w, flush ? 0 : 1, 1);       /* BFINAL */
 	bw_put(&w, 1, 2);       /* BTYPE = 01 */
 	unsigned carry = 0;
 	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
@@ -274,10 +276,12 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	int ret = 0;
 	if (use_static) {
 		bw_put(&w, 0, 7);  /* end of block */
+		if (flush)
+			put_flush_suffix(&w);
 		*destLen = (size_t)((w.bitpos + 7) >> 3);
 		memcpy(dest, tmp, *destLen);
 	} else {
-		ret = write_stored(dest, destLen, in, n);
+		ret = write_stored(dest, destLen, in, n, flush);
 	}
 	free(mf.table);
 	free(tmp);
@@ -539,33 +543,50 @@ static int flush_dyn_block(bw_t *w, dynblk_t *b, int final, uint64_t limit_bits)
 	return 1;
 }
 
-static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n)
+/* HD_FRAME_RAW_FLUSH: what zlibutil_buffer_full_flush (applet/7dictzip.c:93-126)
+ * leaves behind a stream whose BFINAL bits it cleared: the 3 header bits of an
+ * empty stored block in the unused bits of the last byte (one more zero byte
+ * when fewer than 3 are unused, :117-119), then 00 00 ff ff (:120-123) */
+static void put_flush_suffix(bw_t *w)
+{
+	bw_put(w, 0, 3);
+	w->bitpos = (w->bitpos + 7) & ~(uint64_t)7;
+	bw_put(w, 0xffff0000u, 32);
+}
+
+static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n, int flush)
 {
 	/* one BFINAL-terminated run of stored blocks; an empty input still gets its
-	 * one empty stored block here (unlike store_deflate) */
-	if (HD_STORED_SIZE(n) > *destLen)
+	 * one empty stored block here (unlike store_deflate).  Flush form: no block
+	 * is final, an empty stored block follows. */
+	if (HD_STORED_SIZE(n) + (flush ? 5u : 0u) > *destLen)
 		return 1;           /* !Z_OK, as libdeflate_deflate lib/zlibutil.c:189 */
 	size_t o = 0, left = n;
 	do {
 		size_t blk = left < 65535 ? left : 65535;
-		dest[o] = left - blk ? 0 : 1;
+		dest[o] = (left - blk || flush) ? 0 : 1;
 		dest[o + 1] = blk & 0xff; dest[o + 2] = blk >> 8;
 		dest[o + 3] = ~blk & 0xff; dest[o + 4] = (~blk >> 8) & 0xff;
 		memcpy(dest + o + 5, in + (n - left), blk);
 		o += 5 + blk;
 		left -= blk;
 	} while (left);
+	if (flush) {
+		static const uint8_t sfx[5] = { 0, 0, 0, 0xff, 0xff };
+		memcpy(dest + o, sfx, 5);
+		o += 5;
+	}
 	*destLen = o;
 	return 0;
 }
 
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy)
+			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, int flush)
 {
-	size_t cap = *destLen;
+	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
-	uint8_t *tmp = calloc(1, limit + 64);
+	uint8_t *tmp = calloc(1, limit + 64 + 8);
 	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
@@ -595,14 +616,16 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 			alive = flush_dyn_block(&w, &b, 0, 8 * (uint64_t)limit);
 	}
 	if (alive)
-		alive = flush_dyn_block(&w, &b, 1, 8 * (uint64_t)limit);
+		alive = flush_dyn_block(&w, &b, !flush, 8 * (uint64_t)limit);
 	int ret;
 	if (alive) {
+		if (flush)
+			put_flush_suffix(&w);
 		*destLen = (size_t)((w.bitpos + 7) >> 3);
 		memcpy(dest, tmp, *destLen);
 		ret = 0;
 	} else {
-		ret = write_stored(dest, destLen, in, n);
+		ret = write_stored(dest, destLen, in, n, flush);
 	}
 	free(b.tok);
 	free(mf.table);
@@ -610,16 +633,28 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	return ret;
 }
 
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
+{
+	if (level <= 0)
+		return write_stored(dest, destLen, source, sourceLen, flush);   /* level 0 = the stored branch */
+	if (level == 1)
+		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
+	if (level <= 4)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
+				       HD_L2_MIN_LEN, 0, flush);
+	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
+			       HD_L5_MIN_LEN, 1, flush);
+}
+
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level)
 {
-	if (level <= 0)
-		return write_stored(dest, destLen, source, sourceLen);   /* level 0 = the stored branch */
-	if (level == 1)
-		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS);
-	if (level <= 4)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0);
-	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-			       HD_L5_MIN_LEN, 1);
+	return twin(dest, destLen, source, sourceLen, level, 0);
+}
+
+/* the same encoder in HD_FRAME_RAW_FLUSH form (include/hipdeflate.h) */
+int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			   size_t sourceLen, int level)
+{
+	return twin(dest, destLen, source, sourceLen, level, 1);
 }

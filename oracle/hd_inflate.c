@@ -30,6 +30,7 @@
  *               with actual_out_nbytes_ret given (lib/zlibutil.c:201) a short
  *               output is a success.
  */
+#include <stdlib.h>
 #include <string.h>
 #include "hd_oracle.h"
 #include "../include/hipdeflate_params.h"
@@ -133,8 +134,45 @@ static const uint8_t  off_extra[32] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5
 static const uint8_t  precode_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3,
 	13, 2, 14, 1, 15 };
 
+static int inflate_ex(uint8_t *dest, size_t *destLen, const uint8_t *source,
+		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit);
+
 int hdo_inflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		size_t sourceLen, uint64_t *consumed_bits)
+{
+	return inflate_ex(dest, destLen, source, sourceLen, consumed_bits, NULL);
+}
+
+/* Restatement of zlibutil_buffer_full_flush (applet/7dictzip.c:93-126,
+ * applet/7razf.c:126-160) for a finished raw-DEFLATE stream: the reference
+ * re-inflates it with a zlib whose inflate() clears the BFINAL bit of the last
+ * block header in place and reports how many bits of the last byte are unused
+ * (7razf_testdecode.c:595-606,1024); fewer than 3 -> one more zero byte (the
+ * empty stored block's header needs 3), then 00 00 ff ff.  max_out bounds the
+ * scratch the stream is inflated into.  Returns 0, or the inflate verdict. */
+int hdo_full_flush(uint8_t *stream, size_t *len, size_t cap, size_t max_out)
+{
+	uint64_t end = 0, hdr = 0;
+	size_t outlen = max_out;
+	uint8_t *tmp = malloc(max_out ? max_out : 1);
+	int r = inflate_ex(tmp, &outlen, stream, *len, &end, &hdr);
+	free(tmp);
+	if (r)
+		return r;
+	size_t n = (size_t)((end + 7) >> 3);
+	unsigned unused = (unsigned)(8 * n - end);
+	if (n + (unused < 3) + 4 > cap)
+		return HD_INSUFFICIENT_SPACE;
+	stream[hdr >> 3] &= (uint8_t)~(1u << (hdr & 7));
+	if (unused < 3)
+		stream[n++] = 0;
+	stream[n++] = 0; stream[n++] = 0; stream[n++] = 0xff; stream[n++] = 0xff;
+	*len = n;
+	return 0;
+}
+
+static int inflate_ex(uint8_t *dest, size_t *destLen, const uint8_t *source,
+		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit)
 {
 	bits_t b = { source, (uint64_t)sourceLen * 8, 0 };
 	size_t cap = *destLen, out = 0;
@@ -142,6 +180,8 @@ int hdo_inflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 	uint8_t lens[288 + 32 + 138];
 
 	for (;;) {
+		if (last_header_bit)
+			*last_header_bit = b.pos;
 		unsigned bfinal = getbit(&b);
 		unsigned btype = getbits(&b, 2);
 

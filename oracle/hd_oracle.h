@@ -44,6 +44,11 @@ uint32_t hdo_adler32(uint32_t adler, const uint8_t *buf, size_t n);
 int hdo_inflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		size_t sourceLen, uint64_t *consumed_bits);
 
+/* zlibutil_buffer_full_flush (applet/7dictzip.c:93-126) applied to a finished raw
+ * stream in place: BFINAL of the last block cleared, empty stored block appended.
+ * *len in = stream bytes, out = new length; cap = room in `stream`. */
+int hdo_full_flush(uint8_t *stream, size_t *len, size_t cap, size_t max_out);
+
 /* Stored-only encoder, byte-identical to store_deflate (lib/zlibutil.c:302). */
 int hdo_store_deflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		      size_t sourceLen);
@@ -53,6 +58,9 @@ int hdo_store_deflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
  * *destLen, or non-zero when the result does not fit. */
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level);
+/* ... in full-flush form (HD_FRAME_RAW_FLUSH; applet/7dictzip.c:93-126) */
+int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			   size_t sourceLen, int level);
 
 /* BGZF member framing exactly as applet/7bgzf.c:255-272 and
  * bgzf_compress.c:191-197 write it: 18-byte header, payload, CRC32, ISIZE.

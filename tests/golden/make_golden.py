@@ -18,6 +18,10 @@ The outputs are DATA (inputs, reference outputs, verdicts), not source:
 * mutants.json -- bit-flip / truncation mutants of valid streams with the
   verdict (and output hash on success) of libdeflate_inflate: the accept/reject
   contract of the inflate path.
+* full_flush.json -- chunks of the reference's own 7dictzip (applet/7dictzip.c)
+  next to the raw stream the same encoder gives for the same input: pins the
+  full-flush form (zlibutil_buffer_full_flush, applet/7dictzip.c:93-126) that
+  HD_FRAME_RAW_FLUSH produces on the GPU.
 * boundary.json -- known answers at the drop-in boundary: bgzf_compress
   (bgzf_compress.c:39) return codes/sizes/header bytes, the EOF member,
   zlibutil_buffer_code's RFC1950/1952 wrappers (lib/zlibutil.c:374-405),
@@ -263,6 +267,44 @@ def gen_boundary(ref):
     print("boundary.json:", json.dumps(res["hook_fastq_ff00"]))
 
 
+def gen_full_flush(ref):
+    """Run the reference's 7dictzip applet (oracle/_ref/cielbox_ref, built from the
+    reference's own sources) on small inputs; a .dz is a gzip member whose RA extra
+    field lists the chunk sizes (applet/7dictzip.c:300-330)."""
+    import struct
+    import subprocess
+    import tempfile
+    box = os.path.join(ROOT, "oracle", "_ref", "cielbox_ref")
+    corpus = hdtest.corpus_small()
+    out = []
+    for cname, data in corpus.items():
+        if not 0 < len(data) <= 6000:
+            continue
+        for name, level, opt in (("libdeflate", 1, "-cl1"), ("libdeflate", 6, "-cl6"), ("zlib", 6, "-cz6")):
+            with tempfile.TemporaryDirectory() as td:
+                fi, fo = os.path.join(td, "in.bin"), os.path.join(td, "out.dz")
+                open(fi, "wb").write(data)
+                subprocess.run([box, "7dictzip", opt, fi, fo], check=True, capture_output=True)
+                d = open(fo, "rb").read()
+            assert d[:3] == b"\x1f\x8b\x08" and d[3] & 4
+            xlen = struct.unpack("<H", d[10:12])[0]
+            ex = d[12:12 + xlen]
+            assert ex[:2] == b"RA"
+            _, chlen, chcnt = struct.unpack("<HHH", ex[4:10])
+            assert chcnt == 1
+            clen = struct.unpack("<H", ex[10:12])[0]
+            pos = 12 + xlen
+            if d[3] & 8:
+                pos = d.index(b"\0", pos) + 1
+            chunk = d[pos:pos + clen]
+            z = ref_encode(ref, name, level, data)
+            out.append({"input": cname, "encoder": name, "level": level, "stream": b64(z), "flushed": b64(chunk)})
+    json.dump(out, open(os.path.join(HERE, "full_flush.json"), "w"), indent=0)
+    print("full_flush.json:", len(out), "chunks,", sum(len(o["flushed"]) for o in out) * 3 // 4, "bytes;",
+          sum(1 for o in out if len(base64.b64decode(o["flushed"])) - len(base64.b64decode(o["stream"])) == 5),
+          "with the extra zero byte")
+
+
 def main():
     ref = hdtest.ref()
     assert ref is not None, "build the reference first: make -C oracle ref"
@@ -270,6 +312,7 @@ def main():
     gen_ref_streams(ref)
     gen_mutants(ref)
     gen_boundary(ref)
+    gen_full_flush(ref)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,7 @@ def oracle():
                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
         lib.hdo_deflate_twin.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_int]
+        lib.hdo_deflate_twin_flush.argtypes = lib.hdo_deflate_twin.argtypes
         lib.hdo_store_deflate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
                                           ctypes.c_size_t]
         for f in (lib.hdo_bgzf_frame, lib.hdo_migz_frame):
@@ -114,6 +115,10 @@ def oracle_inflate(data, cap):
 
 def oracle_twin(data, level, cap=None):
     return call_enc(oracle().hdo_deflate_twin, data, level, cap)
+
+
+def oracle_twin_flush(data, level, cap=None):
+    return call_enc(oracle().hdo_deflate_twin_flush, data, level, cap)
 
 
 def oracle_crc32(data):

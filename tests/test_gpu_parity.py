@@ -63,6 +63,37 @@ def test_encode_matches_twin_small_corpus(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(data), k
 
 
+@pytest.mark.parametrize("level", [0, 1, 3, 6])
+def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
+    """HD_FRAME_RAW_FLUSH: kernel bytes == twin bytes; chunks concatenate; and through the
+    per-block entry point hip_deflate_flush (what 7dictzip/7razf would call)."""
+    corpus = hdtest.corpus_small()
+    names = list(corpus)
+    blob = b"".join(corpus[k] + bytes(-len(corpus[k]) % 16) for k in names)
+    offs, lens, o = [], [], 0
+    for k in names:
+        offs.append(o)
+        lens.append(len(corpus[k]))
+        o += len(corpus[k]) + (-len(corpus[k]) % 16)
+    members, crc, st = pkg.batch_deflate(blob, offs, lens, level, pkg.FRAME_RAW_FLUSH)
+    cat = b""
+    for i, k in enumerate(names):
+        data = corpus[k]
+        assert st[i] == 0, k
+        r, twin = hdtest.oracle_twin_flush(data, level)
+        assert r == 0 and members[i] == twin, (k, level, len(members[i]), len(twin))
+        assert members[i].endswith(b"\x00\x00\xff\xff"), k
+        assert int(crc[i]) == hdtest.oracle_crc32(data), k
+        cat += members[i]
+    assert zlib.decompressobj(-15).decompress(cat + b"\x03\x00") == b"".join(corpus[k] for k in names)
+    for k in ("fastq_777", "text_5000", "random_100", "empty"):
+        r, z = pkg.hip_deflate_flush(corpus[k], level)
+        assert r == 0 and z == hdtest.oracle_twin_flush(corpus[k], level)[1], k
+        # capacity: 5 bytes short of the result never fits
+        r, _ = pkg.hip_deflate_flush(corpus[k], level, cap=max(len(z) - 5, 0))
+        assert r != 0, k
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a

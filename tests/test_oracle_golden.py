@@ -1,9 +1,11 @@
 """The oracle (oracle/*.c) against the committed golden vectors that were
 produced by the real reference (tests/golden/make_golden.py).  CPU only."""
 import base64
+import ctypes
 import json
 import os
 
+import numpy as np
 import pytest
 
 import hdtest
@@ -168,4 +170,50 @@ def test_twin_roundtrip_and_bounds(level):
         r3, z3 = hdtest.oracle_twin(data, level, cap=len(z))
         assert r3 == 0 and z3 == z, name
         r4, z4 = hdtest.oracle_twin(data, level, cap=len(z) - 1)
+        assert r4 != 0, name
+
+
+def test_full_flush_matches_reference_dictzip_chunks():
+    """hdo_full_flush (restating zlibutil_buffer_full_flush, applet/7dictzip.c:93-126) applied to
+    the reference encoder's raw stream must give the chunk the reference's own 7dictzip wrote."""
+    o = hdtest.oracle()
+    o.hdo_full_flush.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.c_size_t]
+    vects = json.load(open(os.path.join(hdtest.GOLDEN, "full_flush.json")))
+    assert len(vects) >= 30
+    extra = 0
+    for v in vects:
+        z, want = base64.b64decode(v["stream"]), base64.b64decode(v["flushed"])
+        buf = np.zeros(len(z) + 8, dtype=np.uint8)
+        buf[: len(z)] = np.frombuffer(z, dtype=np.uint8)
+        n = ctypes.c_size_t(len(z))
+        assert o.hdo_full_flush(buf.ctypes.data, ctypes.byref(n), len(buf), 1 << 16) == 0
+        assert bytes(buf[: n.value]) == want, (v["input"], v["encoder"], v["level"])
+        extra += n.value - len(z) == 5
+    assert 0 < extra < len(vects)      # both shapes of the suffix are covered
+
+
+@pytest.mark.parametrize("level", [0, 1, 3, 6])
+def test_twin_flush_form_is_full_flush_of_twin(level):
+    """The twin's flush form == hdo_full_flush(the twin's ordinary stream) whenever the ordinary
+    stream was not capacity-limited, and flushed chunks concatenate (the dictzip/razf property)."""
+    import zlib
+    o = hdtest.oracle()
+    o.hdo_full_flush.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.c_size_t]
+    prev = b""
+    for name, data in hdtest.corpus_small().items():
+        r, z = hdtest.oracle_twin(data, level)
+        r2, zf = hdtest.oracle_twin_flush(data, level)
+        assert r == 0 and r2 == 0, name
+        buf = np.zeros(len(z) + 8, dtype=np.uint8)
+        buf[: len(z)] = np.frombuffer(z, dtype=np.uint8)
+        n = ctypes.c_size_t(len(z))
+        assert o.hdo_full_flush(buf.ctypes.data, ctypes.byref(n), len(buf), len(data) + 1) == 0
+        assert bytes(buf[: n.value]) == zf, name
+        assert zlib.decompressobj(-15).decompress(prev + zf + b"\x03\x00") == \
+            (zlib.decompressobj(-15).decompress(prev + b"\x03\x00") if prev else b"") + data, name
+        prev = zf
+        # 5 bytes are kept free for the suffix: that capacity always works, 5 less never does
+        r3, z3 = hdtest.oracle_twin_flush(data, level, cap=len(zf) + 1)
+        assert r3 == 0 and z3 == zf, name
+        r4, _ = hdtest.oracle_twin_flush(data, level, cap=len(zf) - 5)
         assert r4 != 0, name
