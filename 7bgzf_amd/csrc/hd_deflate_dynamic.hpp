@@ -29,10 +29,10 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
-	// one persistent wave per LDS slot of the level (14.5 KiB -> 10 resident per CU -- 11 do
-	// not fit, measured --, 34.5 KiB -> 4); a grid larger than what is resident would run
-	// its tail serially
-	const uint32_t per_cu = level >= 5 ? 4u : 10u;
+	// one persistent wave per LDS slot of the level (levels 2-4: 14.5 KiB -> 10 resident per CU
+	// -- 11 do not fit, measured --; 5-6: 18.5 KiB -> 8; 7-9: 34.5 KiB -> 4); a grid larger
+	// than what is resident would run its tail serially
+	const uint32_t per_cu = level >= 7 ? 4u : level >= 5 ? 8u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -695,8 +695,11 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 	if (level <= 4)
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0>), dim3(grid), dim3(64),
 				   0, st, a);
-	else
+	else if (level <= 6)
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1>), dim3(grid), dim3(64),
+				   0, st, a);
+	else
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1>), dim3(grid), dim3(64),
 				   0, st, a);
 	return 0;
 }

@@ -14,8 +14,9 @@
  *   0      stored blocks only          (store_deflate, lib/zlibutil.c:302)
  *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like")
  *   2..4   greedy parse, dynamic Huffman
- *   5..9   lazy parse (one-chunk lookahead), dynamic Huffman (config 5,
+ *   5..6   lazy parse (one-lane lookahead), dynamic Huffman (config 5,
  *          "level-6-like")
+ *   7..9   the same with a larger window and hash table
  */
 #ifndef HIPDEFLATE_PARAMS_H
 #define HIPDEFLATE_PARAMS_H
@@ -35,11 +36,16 @@
 #define HD_L2_WIN_BITS     13          /* 8 KiB ring                         */
 #define HD_L2_HASH_BITS    11
 #define HD_L2_MIN_LEN      4
-/* levels 5..9: one-lane-lookahead lazy parse, dynamic Huffman */
-#define HD_L5_WIN_BITS     14          /* 16 KiB ring: with a 2^13 table it compresses better than
-                                        * 32 KiB + 2^12 and leaves room for 4 waves per CU */
-#define HD_L5_HASH_BITS    13
+/* levels 5..6: one-lane-lookahead lazy parse, dynamic Huffman, in the level-2 window
+ * with twice the table: 19 KiB of LDS, 8 waves per CU */
+#define HD_L5_WIN_BITS     13
+#define HD_L5_HASH_BITS    12
 #define HD_L5_MIN_LEN      5
+/* levels 7..9: the same parse with a 16 KiB ring and a 2^13 table (text: 3.5 % smaller
+ * output than levels 5..6; 34.5 KiB of LDS, 4 waves per CU, about half the speed) */
+#define HD_L7_WIN_BITS     14
+#define HD_L7_HASH_BITS    13
+#define HD_L7_MIN_LEN      5
 
 #define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
 

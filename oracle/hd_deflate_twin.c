@@ -642,8 +642,11 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level <= 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
 				       HD_L2_MIN_LEN, 0, flush);
-	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-			       HD_L5_MIN_LEN, 1, flush);
+	if (level <= 6)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
+				       HD_L5_MIN_LEN, 1, flush);
+	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
+			       HD_L7_MIN_LEN, 1, flush);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
