@@ -6,11 +6,15 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 3 --warmup 1 > $OUT/bench_kt.log 2>&1
-tail -1 $OUT/bench_kt.log > $OUT/bench_line.json || true
+grep '^{' $OUT/bench_kt.log > $OUT/bench_line.json || true
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dec -- python3 bench.py --steps 2 --warmup 1 --mode decode --level 6 --no-cpu > $OUT/bench_kt_dec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dec -- python3 bench.py --steps 2 --warmup 1 --mode decode --stream libdeflate6 --no-cpu > $OUT/bench_kt_dec.log 2>&1
+grep '^{' $OUT/bench_kt_dec.log > $OUT/bench_line_dec.json || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l6 -- python3 bench.py --steps 2 --warmup 1 --level 6 --no-cpu > $OUT/bench_kt_l6.log 2>&1
+grep '^{' $OUT/bench_kt_l6.log > $OUT/bench_line_l6.json || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l3 -- python3 bench.py --steps 2 --warmup 1 --level 3 --no-cpu > $OUT/bench_kt_l3.log 2>&1
+grep '^{' $OUT/bench_kt_l3.log > $OUT/bench_line_l3.json || true
 python3 - $OUT <<'PY'
 import csv,glob,sys,json,collections
 out=sys.argv[1]
