@@ -21,7 +21,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhipdeflate.so")
 
-FRAME_RAW, FRAME_BGZF, FRAME_MIGZ, FRAME_RAW_FLUSH = 0, 1, 2, 3
+FRAME_RAW, FRAME_BGZF, FRAME_MIGZ, FRAME_RAW_FLUSH, FRAME_ZLIB, FRAME_GZIP = 0, 1, 2, 3, 4, 5
 DEFLATE_HIP = 11
 HD_E_NODEVICE, HD_E_ARG, HD_E_NOMEM = 100, 101, 102
 

@@ -178,6 +178,9 @@ int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
 		if (r)
 			return r;
 	}
+	if (a.frame == HD_FRAME_ZLIB)
+		hipLaunchKernelGGL(hd::k_adler32_patch, dim3(a.nblocks), dim3(64), 0, st, a.in, a.in_off, a.in_len, a.nblocks,
+				   a.out, a.out_stride, a.out_len, a.status);
 	HD_CHECK(hipGetLastError());
 	return 0;
 }
@@ -225,7 +228,7 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	int r = ensure();
 	if (r)
 		return r;
-	if (frame < HD_FRAME_RAW || frame > HD_FRAME_RAW_FLUSH || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
+	if (frame < HD_FRAME_RAW || frame > HD_FRAME_GZIP || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
 		return HD_E_ARG;
 	hd::DeflateArgs a;
 	a.in = (const uint8_t *)in;
@@ -343,7 +346,7 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 		return r;
 	if (nblocks == 0)
 		return 0;
-	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_RAW_FLUSH)
+	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_GZIP)
 		return HD_E_ARG;
 	std::lock_guard<std::mutex> lk(g.mu);
 	if ((r = bind_device()))

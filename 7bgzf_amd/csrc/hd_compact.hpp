@@ -126,4 +126,39 @@ __global__ __launch_bounds__(64) void k_compact(const uint8_t *slots, uint64_t s
 		d[done + lane] = s[done + lane];
 }
 
+// RFC 1950 members (HD_FRAME_ZLIB): the Adler-32 of every block's input, written big-endian
+// into the last four bytes of its member (lib/zlibutil.c:393-396 computes it on the CPU after
+// the codec returns).  Kept out of the encode kernels, which sit at their register budget;
+// one extra streaming read of the input, only in this frame.  One wavefront per block.
+__global__ __launch_bounds__(64) void k_adler32_patch(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len,
+						      uint32_t nblocks, uint8_t *out, uint64_t out_stride,
+						      const uint32_t *out_len, const int32_t *status)
+{
+	const uint32_t b = blockIdx.x, lane = threadIdx.x;
+	if (b >= nblocks || (status && status[b]) || out_len[b] < 6)
+		return;
+	const uint8_t *src = in + in_off[b];
+	const uint32_t n = in_len[b];
+	const bool aligned = (((uintptr_t)src) & 15) == 0;
+	AdlerLanes adl;
+	adl.init();
+	for (uint32_t piece = 0; piece * HD_PIECE < n; piece++) {
+		const uint32_t o = piece * HD_PIECE + lane * 16;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (aligned && o + 16 <= n) {
+			v = *(const uint4 *)(src + o);
+		} else if (o < n) {
+			uint32_t w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+			for (uint32_t k = 0; k < 16; k++)
+				w[k >> 2] |= (o + k < n ? (uint32_t)src[o + k] : 0u) << (8 * (k & 3));
+			v = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+		adl.fold(piece, lane, v);
+	}
+	const uint32_t a = adl.finish(n);
+	if (lane < 4)
+		out[(uint64_t)b * out_stride + out_len[b] - 4 + lane] = (uint8_t)(a >> (24 - 8 * lane));
+}
+
 } // namespace hd

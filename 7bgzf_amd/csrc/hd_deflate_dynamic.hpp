@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const bool aligned = (((uintptr_t)src) & 15) == 0;
 		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 
-		const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+		const uint32_t hdr = frame_hdr_bytes(a.frame), trl = frame_trl_bytes(a.frame);
 		uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
 		if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
 			cap64 = 65536;
@@ -255,9 +255,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		if (lane < 32)
 			L.df[lane] = 0;
 		if (lane < 4 && hdr)
-			stage[lane] = lane == 0 ? 0x04088b1fu : lane == 1 ? 0u
-				: lane == 2 ? (a.frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u)
-					    : (a.frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du);
+			stage[lane] = frame_hdr_word(a.frame, lane);
 
 		CrcLanes crc;
 		crc.init(lane, n);
@@ -668,8 +666,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const uint32_t paylen = (bitpos - paybase) >> 3;
 		if (trl) {
 			uint32_t tcode = 0, nb = 0;
-			if (lane < 4) {
-				tcode = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
+			if (lane < trl / 2) {
+				tcode = frame_trl_field(a.frame, lane, crcv, n);
 				nb = 16;
 			}
 			emit1(tcode, nb);

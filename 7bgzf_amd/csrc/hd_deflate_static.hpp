@@ -43,7 +43,22 @@ struct DeflateArgs {
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
 {
-	return frame == HD_FRAME_BGZF ? 18u : frame == HD_FRAME_MIGZ ? 20u : 0u;
+	return frame == HD_FRAME_BGZF ? 18u : frame == HD_FRAME_MIGZ ? 20u : frame == HD_FRAME_ZLIB ? 2u
+	     : frame == HD_FRAME_GZIP ? 10u : 0u;
+}
+
+// CRC32 + ISIZE behind the gzip-family members, Adler-32 behind RFC 1950
+__device__ __forceinline__ uint32_t frame_trl_bytes(int frame)
+{
+	return frame == HD_FRAME_ZLIB ? 4u : (frame == HD_FRAME_BGZF || frame == HD_FRAME_MIGZ || frame == HD_FRAME_GZIP) ? 8u : 0u;
+}
+
+// 16-bit field `k` of the trailer: CRC32 then ISIZE; the four Adler-32 bytes of an
+// RFC 1950 member are left zero here, k_adler32_patch writes them
+__device__ __forceinline__ uint32_t frame_trl_field(int frame, uint32_t k, uint32_t crc, uint32_t n)
+{
+	const uint32_t w = k < 2 ? (frame == HD_FRAME_ZLIB ? 0u : crc) : n;
+	return (w >> (16 * (k & 1))) & 0xffff;
 }
 
 // HD_FRAME_RAW_FLUSH: room kept for the flush suffix (3 header bits + alignment, 00 00 ff ff)
@@ -52,14 +67,23 @@ __device__ __forceinline__ uint32_t frame_sfx_bytes(int frame)
 	return frame == HD_FRAME_RAW_FLUSH ? 5u : 0u;
 }
 
+// dword `j` (0..3) of the container header with its size field zero
+__device__ __forceinline__ uint32_t frame_hdr_word(int frame, uint32_t j)
+{
+	// BGZF / MiGz: 1f 8b 08 04 | 00 00 00 00 | 00 ff XL 00 | S1 S2 SL 00     applet/7bgzf.c:263-265
+	// gzip:        1f 8b 08 00 | mtime = 0   | 02 00                          lib/zlibutil.c:380-386
+	// zlib:        78 da                                                       lib/zlibutil.c:375-376
+	const bool bz = frame == HD_FRAME_BGZF, gz = frame == HD_FRAME_GZIP, zl = frame == HD_FRAME_ZLIB;
+	const uint32_t w0 = zl ? 0x0000da78u : gz ? 0x00088b1fu : 0x04088b1fu;
+	const uint32_t w2 = zl ? 0u : gz ? 0x00000002u : bz ? 0x0006ff00u : 0x0008ff00u;
+	const uint32_t w3 = (zl || gz) ? 0u : bz ? 0x00024342u : 0x00045a4du;
+	return j == 0 ? w0 : j == 1 ? 0u : j == 2 ? w2 : w3;
+}
+
 // byte `o` of the container header; `sizefield` = BSIZE (u16) or compsize (u32)
 __device__ __forceinline__ uint32_t frame_hdr_byte(int frame, uint32_t o, uint32_t sizefield)
 {
-	// 1f 8b 08 04 | 00 00 00 00 | 00 ff XL 00 | S1 S2 SL 00 | size...
-	const uint32_t w0 = 0x04088b1fu, w1 = 0u;
-	const uint32_t w2 = frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u;
-	const uint32_t w3 = frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du;
-	uint32_t w = o < 4 ? w0 : o < 8 ? w1 : o < 12 ? w2 : o < 16 ? w3 : sizefield;
+	const uint32_t w = o < 16 ? frame_hdr_word(frame, o >> 2) : sizefield;
 	return (w >> (8 * (o & 3))) & 0xff;
 }
 
@@ -69,7 +93,7 @@ __device__ __forceinline__ uint32_t frame_hdr_byte(int frame, uint32_t o, uint32
 __device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32_t b, const uint8_t *src, uint32_t n,
 						  uint32_t crc, uint32_t lane)
 {
-	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = frame_trl_bytes(a.frame);
 	const bool flush = a.frame == HD_FRAME_RAW_FLUSH;   // no final block; empty stored block 00 | 00 00 ff ff behind
 	const uint32_t stored = HD_STORED_SIZE(n);
 	const uint32_t total = hdr + stored + trl + (flush ? 5u : 0u);
@@ -105,7 +129,7 @@ __device__ __forceinline__ void write_stored_member(const DeflateArgs &a, uint32
 				else v = src[q * 65535u + r - 5];
 			} else if (o < total) {
 				uint32_t t = o - hdr - stored;
-				v = flush ? (t >= 3 ? 0xffu : 0u) : ((t < 4 ? crc : n) >> (8 * (t & 3))) & 0xff;
+				v = flush ? (t >= 3 ? 0xffu : 0u) : (frame_trl_field(a.frame, t >> 1, crc, n) >> (8 * (t & 1))) & 0xff;
 			}
 			w |= v << (8 * k);
 		}
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 	const CrcTables *ct = a.ct;
 
-	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = hdr ? 8u : 0u;
+	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = frame_trl_bytes(a.frame);
 	uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
 	if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
 		cap64 = 65536;
@@ -190,9 +214,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	for (uint32_t i = lane; i < STG; i += 64)
 		stage[i] = 0;
 	if (lane < 4 && hdr)
-		stage[lane] = lane == 0 ? 0x04088b1fu : lane == 1 ? 0u
-			: lane == 2 ? (a.frame == HD_FRAME_BGZF ? 0x0006ff00u : 0x0008ff00u)
-				    : (a.frame == HD_FRAME_BGZF ? 0x00024342u : 0x00045a4du);
+		stage[lane] = frame_hdr_word(a.frame, lane);
 
 	Fn8Ident fid;
 	fid.init(lane);
@@ -496,12 +518,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const uint32_t paylen = (bitpos - paybase) >> 3;
 	if (trl) {
 		uint32_t tcode = 0, nb = 0;
-		if (lane < 4) {
-			tcode = ((lane < 2 ? crcv : n) >> (16 * (lane & 1))) & 0xffff;
+		if (lane < trl / 2) {
+			tcode = frame_trl_field(a.frame, lane, crcv, n);
 			nb = 16;
 		}
 		const uint32_t incl = wave_incl_scan(nb);
-		put(tcode, nb, incl, 64);
+		put(tcode, nb, incl, 8 * trl);
 	}
 	// final flush: everything left, including the last partial dword (< 256 dwords)
 	for (uint32_t i = flushed + lane; i < ((bitpos + 31) >> 5); i += 64)

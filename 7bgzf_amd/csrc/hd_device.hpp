@@ -214,6 +214,38 @@ struct CrcLanes {
 	}
 };
 
+// ---- Adler-32 (RFC 1950) ----------------------------------------------------
+// a = 1 + sum d_i, b = n + sum (n - i) d_i (mod 65521): every lane keeps the plain and
+// the index-weighted byte sum of its 16-byte slots (v_sad_u8 / v_dot4_u32_u8); bytes a
+// ragged slot holds beyond n are zero and add nothing.
+struct AdlerLanes {
+	uint32_t s1, s2;
+	__device__ __forceinline__ void init() { s1 = s2 = 0; }
+	__device__ __forceinline__ void fold(uint32_t piece, uint32_t lane, uint4 v)
+	{
+		uint32_t sum = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
+		sum = __builtin_amdgcn_sad_u8(v.y, 0u, sum);
+		sum = __builtin_amdgcn_sad_u8(v.z, 0u, sum);
+		sum = __builtin_amdgcn_sad_u8(v.w, 0u, sum);                     // <= 4080
+		uint32_t ws = __builtin_amdgcn_udot4(v.x, 0x03020100u, 0u, false);
+		ws = __builtin_amdgcn_udot4(v.y, 0x07060504u, ws, false);
+		ws = __builtin_amdgcn_udot4(v.z, 0x0b0a0908u, ws, false);
+		ws = __builtin_amdgcn_udot4(v.w, 0x0f0e0d0cu, ws, false);          // sum k * d_k, <= 30600
+		const uint32_t g = (piece * HD_PIECE + lane * 16) % 65521u;      // index of the slot's first byte
+		s1 += sum;                                                        // < 2^32 for n < 2^28
+		s2 = (s2 + g * sum + ws) % 65521u;
+	}
+	__device__ __forceinline__ uint32_t finish(uint32_t n)
+	{
+		const uint32_t S1 = readlane(wave_incl_scan(s1 % 65521u), 63) % 65521u;
+		const uint32_t S2 = readlane(wave_incl_scan(s2), 63) % 65521u;
+		const uint32_t nm = n % 65521u;
+		const uint32_t a = (1u + S1) % 65521u;
+		const uint32_t b = (nm + (uint32_t)(((uint64_t)nm * S1) % 65521u) + 65521u - S2) % 65521u;
+		return (b << 16) | a;
+	}
+};
+
 // ---- RFC 1951 3.2.5 slot arithmetic ----------------------------------------
 // length 3..258 -> symbol - 257, extra bit count, extra value
 __device__ __forceinline__ void len_slot(uint32_t len, uint32_t &sym, uint32_t &eb, uint32_t &ev)

@@ -50,6 +50,10 @@ extern "C" {
                               * zlibutil_buffer_full_flush (applet/7dictzip.c:93-126, 7razf.c:126-160)
                               * makes of a codec's output by re-inflating it with a patched zlib; here it
                               * comes straight from the kernel.  Chunks in this form concatenate. */
+#define HD_FRAME_ZLIB  4     /* RFC 1950 as zlibutil_buffer_code writes it (lib/zlibutil.c:374-397):
+                              * 78 da, raw DEFLATE, Adler-32 big-endian -- the Adler-32 comes from the kernel */
+#define HD_FRAME_GZIP  5     /* RFC 1952 as lib/zlibutil.c:379-405: 1f 8b 08 00 <mtime = 0> 02 00, raw
+                              * DEFLATE, CRC32, ISIZE (the reference stamps time(NULL); a batch has no clock) */
 
 /* ---- lifetime ---------------------------------------------------------- */
 

@@ -105,6 +105,39 @@ size_t hdo_migz_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
 	return total;
 }
 
+/* lib/zlibutil.c:374-397: 78 da, the codec's bytes, Adler-32 of the INPUT big-endian */
+size_t hdo_zlib_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
+		      size_t payload_len, uint32_t adler)
+{
+	size_t total = 2 + payload_len + 4;
+	if (total > cap)
+		return 0;
+	memmove(dst + 2, payload, payload_len);
+	dst[0] = 0x78;
+	dst[1] = 0xda;
+	dst[2 + payload_len] = (uint8_t)(adler >> 24);
+	dst[3 + payload_len] = (uint8_t)(adler >> 16);
+	dst[4 + payload_len] = (uint8_t)(adler >> 8);
+	dst[5 + payload_len] = (uint8_t)adler;
+	return total;
+}
+
+/* lib/zlibutil.c:379-405: 1f 8b 08 00 <mtime> 02 00, the codec's bytes, CRC32, ISIZE */
+size_t hdo_gzip_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
+		      size_t payload_len, uint32_t mtime, uint32_t crc, uint32_t isize)
+{
+	size_t total = 10 + payload_len + 8;
+	if (total > cap)
+		return 0;
+	memmove(dst + 10, payload, payload_len);
+	dst[0] = 0x1f; dst[1] = 0x8b; dst[2] = 0x08; dst[3] = 0x00;
+	put32(dst + 4, mtime);
+	dst[8] = 0x02; dst[9] = 0x00;
+	put32(dst + 10 + payload_len, crc);
+	put32(dst + 14 + payload_len, isize);
+	return total;
+}
+
 static uint32_t get16(const uint8_t *p) { return p[0] | (p[1] << 8); }
 static uint32_t get32(const uint8_t *p) { return get16(p) | (get16(p + 2) << 16); }
 

@@ -73,6 +73,12 @@ size_t hdo_bgzf_eof(uint8_t *dst, size_t cap);
 size_t hdo_migz_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
 		      size_t payload_len, uint32_t crc, uint32_t isize);
 
+/* zlibutil_buffer_code's wrappers (lib/zlibutil.c:374-405) around a codec's bytes */
+size_t hdo_zlib_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
+		      size_t payload_len, uint32_t adler);
+size_t hdo_gzip_frame(uint8_t *dst, size_t cap, const uint8_t *payload,
+		      size_t payload_len, uint32_t mtime, uint32_t crc, uint32_t isize);
+
 /* Header parser with the behaviour of _read_gz_header (applet/7bgzf.c:81-131):
  * returns header length n (0 = not recognised) and the member length. */
 int hdo_read_gz_header(const uint8_t *data, int size, int *extra_off,

@@ -62,6 +62,11 @@ def oracle():
             f.restype = ctypes.c_size_t
             f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                           ctypes.c_uint32, ctypes.c_uint32]
+        lib.hdo_zlib_frame.restype = ctypes.c_size_t
+        lib.hdo_zlib_frame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        lib.hdo_gzip_frame.restype = ctypes.c_size_t
+        lib.hdo_gzip_frame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
         lib.hdo_bgzf_eof.restype = ctypes.c_size_t
         lib.hdo_bgzf_eof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         lib.hdo_read_gz_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),

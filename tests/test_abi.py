@@ -124,3 +124,34 @@ def test_zlibutil_mirror_wrappers(pkg):
     assert lib.hd_crc32(0, v, len(v)) == hdtest.oracle_crc32(v)
     a = hdtest.as_u8(v)
     assert lib.hd_adler32(1, v, len(v)) == hdtest.oracle().hdo_adler32(1, a.ctypes.data, len(a))
+
+
+def test_kernel_resource_budgets():
+    """The compiler's resource report of the build (7bgzf_amd/csrc/hd_api.resources.log, written by the
+    Makefile): no kernel may spill, and the dynamic-level kernels must stay at <= 168 VGPRs -- their
+    persistent grids (dynamic_grid(), hd_deflate_dynamic.hpp) assume three waves per SIMD; one
+    register more and a third of the grid runs as a serial tail (measured: 96 -> 55 GB/s)."""
+    import re
+    log = os.path.join(os.path.dirname(hdtest.pkg().LIB_PATH), "csrc", "hd_api.resources.log")
+    assert os.path.exists(log), "build with make -C 7bgzf_amd/csrc"
+    kernels, cur = {}, None
+    for line in open(log):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/\w+\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    dyn = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k}
+    sta = {k: v for k, v in kernels.items() if "k_deflate_static" in k}
+    inf = {k: v for k, v in kernels.items() if "k_inflate" in k}
+    assert len(dyn) == 3 and len(sta) == 1 and len(inf) == 1, list(kernels)
+    for k, v in kernels.items():
+        assert v["ScratchSize"] == 0, (k, v)
+    for k, v in dyn.items():
+        assert v["VGPRs"] <= 168, (k, v)
+    (v,) = sta.values()
+    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 10240, v       # 16 waves per CU
+    (v,) = inf.values()
+    assert v["VGPRs"] <= 96 and v["LDS Size"] <= 7424, v         # 20+ waves per CU

@@ -94,6 +94,48 @@ def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
         assert r != 0, k
 
 
+@pytest.mark.parametrize("level", [0, 1, 3, 6])
+def test_encode_zlib_and_gzip_frames(pkg, level):
+    """HD_FRAME_ZLIB / HD_FRAME_GZIP: member == the oracle's wrapper (pinned against the reference's
+    zlibutil_buffer_code bytes) around the twin's payload; Adler-32 and CRC-32 come from the device."""
+    import gzip
+    o = hdtest.oracle()
+    corpus = hdtest.corpus_small()
+    corpus["hello"] = load("boundary.json")["zlibutil_buffer_code_store"]["rfc1950"]["input"].encode()
+    corpus["fastq_odd"] = corpus["fastq_ff00"][3:40000]          # unaligned start, ragged end
+    names = list(corpus)
+    blob = b"".join(corpus[k] + bytes(-len(corpus[k]) % 16) for k in names)
+    offs, lens, p = [], [], 0
+    for k in names:
+        offs.append(p)
+        lens.append(len(corpus[k]))
+        p += len(corpus[k]) + (-len(corpus[k]) % 16)
+    for frame in (pkg.FRAME_ZLIB, pkg.FRAME_GZIP):
+        members, crc, st = pkg.batch_deflate(blob, offs, lens, level, frame)
+        for i, k in enumerate(names):
+            data = corpus[k]
+            assert st[i] == 0, k
+            r, payload = hdtest.oracle_twin(data, level)
+            assert r == 0
+            pl, a = hdtest.as_u8(payload), hdtest.as_u8(data)
+            buf = np.zeros(len(payload) + 32, dtype=np.uint8)
+            if frame == pkg.FRAME_ZLIB:
+                n = o.hdo_zlib_frame(buf.ctypes.data, len(buf), pl.ctypes.data, len(payload),
+                                     o.hdo_adler32(1, a.ctypes.data, len(data)))
+                assert zlib.decompress(members[i]) == data, k
+            else:
+                n = o.hdo_gzip_frame(buf.ctypes.data, len(buf), pl.ctypes.data, len(payload), 0,
+                                     hdtest.oracle_crc32(data), len(data))
+                assert gzip.decompress(members[i]) == data, k
+            assert members[i] == bytes(buf[:n]), (k, frame, level)
+    if level == 0:
+        g = load("boundary.json")["zlibutil_buffer_code_store"]
+        i = names.index("hello")
+        zl = pkg.batch_deflate(blob, offs, lens, 0, pkg.FRAME_ZLIB)[0][i]
+        gz = pkg.batch_deflate(blob, offs, lens, 0, pkg.FRAME_GZIP)[0][i]
+        assert zl.hex() == g["rfc1950"]["bytes"] and gz.hex() == g["rfc1952"]["bytes"]
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a

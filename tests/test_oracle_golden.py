@@ -217,3 +217,22 @@ def test_twin_flush_form_is_full_flush_of_twin(level):
         assert r3 == 0 and z3 == zf, name
         r4, _ = hdtest.oracle_twin_flush(data, level, cap=len(zf) - 5)
         assert r4 != 0, name
+
+
+def test_zlib_gzip_frames_match_reference_wrappers():
+    """hdo_zlib_frame / hdo_gzip_frame against zlibutil_buffer_code's own output recorded from the
+    reference (boundary.json, lib/zlibutil.c:374-405; mtime zeroed in the golden)."""
+    o = hdtest.oracle()
+    g = load("boundary.json")["zlibutil_buffer_code_store"]
+    data = g["rfc1950"]["input"].encode()
+    r, payload = hdtest.oracle_twin(data, 0)          # the stored form == store_deflate's for one block
+    assert r == 0
+    p = hdtest.as_u8(payload)
+    a = hdtest.as_u8(data)
+    buf = np.zeros(200, dtype=np.uint8)
+    n = o.hdo_zlib_frame(buf.ctypes.data, 200, p.ctypes.data, len(p), o.hdo_adler32(1, a.ctypes.data, len(a)))
+    assert bytes(buf[:n]).hex() == g["rfc1950"]["bytes"]
+    n = o.hdo_gzip_frame(buf.ctypes.data, 200, p.ctypes.data, len(p), 0, hdtest.oracle_crc32(data), len(data))
+    assert bytes(buf[:n]).hex() == g["rfc1952"]["bytes"]
+    assert o.hdo_zlib_frame(buf.ctypes.data, len(p) + 5, p.ctypes.data, len(p), 0) == 0
+    assert o.hdo_gzip_frame(buf.ctypes.data, len(p) + 17, p.ctypes.data, len(p), 0, 0, 0) == 0
