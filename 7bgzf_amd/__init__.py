@@ -42,6 +42,8 @@ EXPORTS = [
     "hip_deflate", "hip_deflate_flush", "hip_inflate", "hipdeflate_batch_deflate", "hipdeflate_batch_inflate",
     "hipdeflate_batch_deflate_dev", "hipdeflate_batch_inflate_dev", "hipdeflate_scan_sizes_dev",
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
+    "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
+    "hipdeflate_pipe_close",
 ]
 
 
@@ -98,6 +100,14 @@ def lib():
     L.hipdeflate_batch_inflate_dev.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.hipdeflate_scan_sizes_dev.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint64, _vp, _vp, _vp]
     L.hipdeflate_compact_dev.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, ctypes.c_uint32, _vp, _vp]
+    L.hipdeflate_pipe_open.restype = _vp
+    L.hipdeflate_pipe_open.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+    L.hipdeflate_pipe_input.restype = _vp
+    L.hipdeflate_pipe_input.argtypes = [_vp, sz_p]
+    L.hipdeflate_pipe_submit.argtypes = [_vp, ctypes.c_size_t]
+    L.hipdeflate_pipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.hipdeflate_pipe_close.restype = None
+    L.hipdeflate_pipe_close.argtypes = [_vp]
     _lib = L
     return L
 
@@ -163,6 +173,49 @@ def hip_inflate(data, cap):
     n = ctypes.c_size_t(cap)
     r = lib().hip_inflate(_p(dst), ctypes.byref(n), _p(src), len(src))
     return r, bytes(dst[: n.value]) if r == 0 else b""
+
+
+def pipe_compress(data, level=1, frame=FRAME_BGZF, block=0xff00, per_batch=64, depth=3):
+    """Run `data` through the streaming encoder (hipdeflate_pipe_*): as many batches in flight as the
+    pipe allows before results are fetched.  -> the concatenated members (no EOF member)."""
+    L = lib()
+    src = as_u8(data)
+    p = L.hipdeflate_pipe_open(level, frame, block, per_batch, depth)
+    if not p:
+        raise HipDeflateError("hipdeflate_pipe_open failed")
+    out, pos, inflight = [], 0, 0
+
+    def fetch():
+        d, n, nb = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_uint32()
+        r = L.hipdeflate_pipe_result(p, ctypes.byref(d), ctypes.byref(n), ctypes.byref(nb))
+        if r:
+            raise HipDeflateError("hipdeflate_pipe_result %d" % r)
+        out.append(ctypes.string_at(d, n.value))
+
+    try:
+        while True:
+            if inflight == depth - 1:        # one slot stays with the caller (the held result)
+                fetch()
+                inflight -= 1
+            cap = ctypes.c_size_t()
+            buf = L.hipdeflate_pipe_input(p, ctypes.byref(cap))
+            if not buf:
+                raise HipDeflateError("hipdeflate_pipe_input failed")
+            n = min(cap.value, len(src) - pos)
+            if n:
+                ctypes.memmove(buf, src[pos:pos + n].ctypes.data, n)
+            if L.hipdeflate_pipe_submit(p, n):
+                raise HipDeflateError("hipdeflate_pipe_submit failed")
+            inflight += 1
+            pos += n
+            if n < cap.value:
+                break
+        while inflight:
+            fetch()
+            inflight -= 1
+    finally:
+        L.hipdeflate_pipe_close(p)
+    return b"".join(out)
 
 
 def bgzf_compress_hook(data, cap=0x10000):

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -75,6 +76,8 @@ struct Ctx {
 	std::mutex mu_dev;
 	Buf d_tok;
 	Buf d_tiles;
+	hipEvent_t ev_tok = nullptr;     // last launch that used d_tok: the next one waits for it
+	hipEvent_t ev_tiles = nullptr;   // the same for d_tiles
 };
 
 Ctx g;
@@ -256,6 +259,15 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 				return HD_E_NOMEM;
 		}
 		a.scratch = (uint8_t *)g.d_tok.p;
+		// the slabs are shared by every launch: launches on different streams take turns
+		if (!g.ev_tok)
+			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
+		else
+			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
+		r = launch_deflate(a, level, (hipStream_t)stream);
+		if (!r)
+			HD_CHECK(hipEventRecord(g.ev_tok, (hipStream_t)stream));
+		return r;
 	}
 	return launch_deflate(a, level, (hipStream_t)stream);
 }
@@ -300,22 +312,25 @@ int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t ba
 		return 0;
 	}
 	const uint32_t ntiles = (nblocks + hd::SCAN_TILE - 1) / hd::SCAN_TILE;
-	uint64_t *tiles;
-	{
-		std::lock_guard<std::mutex> lk(g.mu_dev);
-		if (g.d_tiles.cap < (size_t)ntiles * 8) {
-			HD_CHECK(hipDeviceSynchronize());
-			if (g.d_tiles.reserve((size_t)ntiles * 8))
-				return HD_E_NOMEM;
-		}
-		tiles = (uint64_t *)g.d_tiles.p;
+	// the tile buffer is one for the whole library: scans on different streams take turns
+	std::lock_guard<std::mutex> lk(g.mu_dev);
+	if (g.d_tiles.cap < (size_t)ntiles * 8) {
+		HD_CHECK(hipDeviceSynchronize());
+		if (g.d_tiles.reserve((size_t)ntiles * 8))
+			return HD_E_NOMEM;
 	}
+	uint64_t *tiles = (uint64_t *)g.d_tiles.p;
 	hipStream_t st = (hipStream_t)stream;
+	if (!g.ev_tiles)
+		HD_CHECK(hipEventCreateWithFlags(&g.ev_tiles, hipEventDisableTiming));
+	else
+		HD_CHECK(hipStreamWaitEvent(st, g.ev_tiles, 0));
 	hipLaunchKernelGGL(hd::k_scan_tile_sums, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)out_len, nblocks, tiles);
 	hipLaunchKernelGGL(hd::k_scan_tiles, dim3(1), dim3(256), 0, st, tiles, ntiles, base, (uint64_t *)total);
 	hipLaunchKernelGGL(hd::k_scan_finish, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)out_len, nblocks, tiles,
 			   (uint64_t *)dst_off);
 	HD_CHECK(hipGetLastError());
+	HD_CHECK(hipEventRecord(g.ev_tiles, st));
 	return 0;
 }
 
@@ -493,6 +508,196 @@ int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const ui
 			memcpy(out + out_off[i], (const uint8_t *)g.h_out.p + h_ooff[i], h_olen[i]);
 	}
 	return 0;
+}
+
+/* ---- streaming encoder ---------------------------------------------------------- */
+
+struct PipeSlot {
+	Buf h_in{ nullptr, 0, true }, h_out{ nullptr, 0, true }, h_meta{ nullptr, 0, true };
+	Buf d_in, d_meta, d_slots, d_packed;
+	hipStream_t st = nullptr;
+	size_t nbytes = 0;
+	uint32_t nb = 0;
+	int state = 0;               // 0 free, 1 being filled, 2 submitted, 3 result held by the caller
+};
+
+struct hipdeflate_pipe {
+	int level, frame, depth;
+	uint32_t block, per_batch;
+	size_t slot_stride;
+	std::vector<PipeSlot> slots;
+	std::mutex mu;
+	std::condition_variable cv;
+	uint64_t n_in = 0, n_sub = 0, n_out = 0;     // slots handed out / submitted / fetched
+	int held = -1;
+};
+
+hipdeflate_pipe *hipdeflate_pipe_open(int level, int frame, uint32_t block_bytes, uint32_t blocks_per_batch, int depth)
+{
+	if (ensure() || bind_device())
+		return nullptr;
+	if (frame < HD_FRAME_RAW || frame > HD_FRAME_GZIP || !block_bytes || (block_bytes & 15) || !blocks_per_batch ||
+	    depth < 2 || depth > 16 || (uint64_t)block_bytes * blocks_per_batch > 0xffff0000ull)
+		return nullptr;
+	hipdeflate_pipe *p = new hipdeflate_pipe;
+	p->level = level;
+	p->frame = frame;
+	p->depth = depth;
+	p->block = block_bytes;
+	p->per_batch = blocks_per_batch;
+	// a member never needs more than the stored form + the largest frame
+	p->slot_stride = up16((size_t)block_bytes + 5 * ((size_t)block_bytes / 65535 + 1) + 32);
+	if (frame == HD_FRAME_BGZF && p->slot_stride > 65536)
+		p->slot_stride = 65536;
+	p->slots.resize(depth);
+	const size_t in_cap = (size_t)block_bytes * blocks_per_batch;
+	const size_t meta = (size_t)blocks_per_batch * (8 + 4 + 4 + 4 + 4 + 8) + 16;
+	for (PipeSlot &s : p->slots) {
+		if (s.h_in.reserve(in_cap) || s.d_in.reserve(in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
+		    s.d_slots.reserve(p->slot_stride * blocks_per_batch + 16) ||
+		    s.d_packed.reserve(p->slot_stride * blocks_per_batch + 16) ||
+		    s.h_out.reserve(p->slot_stride * blocks_per_batch + 16) ||
+		    hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+			hipdeflate_pipe_close(p);
+			return nullptr;
+		}
+	}
+	return p;
+}
+
+uint8_t *hipdeflate_pipe_input(hipdeflate_pipe *p, size_t *cap)
+{
+	if (!p)
+		return nullptr;
+	std::unique_lock<std::mutex> lk(p->mu);
+	PipeSlot &s = p->slots[p->n_in % p->depth];
+	if (s.state == 1)
+		return nullptr;                          // input() twice without submit()
+	p->cv.wait(lk, [&] { return s.state == 0; });
+	s.state = 1;
+	if (cap)
+		*cap = (size_t)p->block * p->per_batch;
+	return (uint8_t *)s.h_in.p;
+}
+
+int hipdeflate_pipe_submit(hipdeflate_pipe *p, size_t nbytes)
+{
+	if (!p)
+		return HD_E_ARG;
+	PipeSlot *sp;
+	{
+		std::lock_guard<std::mutex> lk(p->mu);
+		sp = &p->slots[p->n_in % p->depth];
+		if (sp->state != 1 || nbytes > (size_t)p->block * p->per_batch)
+			return HD_E_ARG;
+	}
+	PipeSlot &s = *sp;
+	int r = bind_device();
+	if (r)
+		return r;
+	s.nbytes = nbytes;
+	s.nb = (uint32_t)((nbytes + p->block - 1) / p->block);
+	if (s.nb) {
+		// block table: offsets i * block (16-byte aligned), the last block may be short
+		uint64_t *h_off = (uint64_t *)s.h_meta.p;
+		uint32_t *h_len = (uint32_t *)(h_off + s.nb);
+		for (uint32_t i = 0; i < s.nb; i++) {
+			h_off[i] = (uint64_t)i * p->block;
+			h_len[i] = i + 1 < s.nb ? p->block : (uint32_t)(nbytes - (size_t)i * p->block);
+		}
+		uint8_t *dm = (uint8_t *)s.d_meta.p;
+		uint64_t *d_off = (uint64_t *)dm;
+		uint32_t *d_len = (uint32_t *)(d_off + s.nb);
+		uint32_t *d_olen = d_len + s.nb;
+		uint32_t *d_crc = d_olen + s.nb;
+		int32_t *d_st = (int32_t *)(d_crc + s.nb);
+		uint64_t *d_doff = (uint64_t *)(((uintptr_t)(d_st + s.nb) + 7) & ~(uintptr_t)7);
+		uint64_t *d_total = d_doff + s.nb;
+		HD_CHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, nbytes, hipMemcpyHostToDevice, s.st));
+		HD_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)s.nb * 12, hipMemcpyHostToDevice, s.st));
+		if ((r = hipdeflate_batch_deflate_dev(s.d_in.p, d_off, d_len, s.nb, p->level, p->frame, s.d_slots.p,
+						      p->slot_stride, (uint32_t)p->slot_stride, d_olen, d_crc, d_st, s.st)))
+			return r;
+		if ((r = hipdeflate_scan_sizes_dev(d_olen, s.nb, 0, d_doff, d_total, s.st)))
+			return r;
+		if ((r = hipdeflate_compact_dev(s.d_slots.p, p->slot_stride, d_olen, d_doff, s.nb, s.d_packed.p, s.st)))
+			return r;
+		// sizes, status and the total come back first; the payload follows in result()
+		HD_CHECK(hipMemcpyAsync(s.h_meta.p, d_olen, (size_t)((uint8_t *)(d_total + 1) - (uint8_t *)d_olen),
+					hipMemcpyDeviceToHost, s.st));
+	}
+	std::lock_guard<std::mutex> lk(p->mu);
+	s.state = 2;
+	p->n_in++;
+	p->n_sub++;
+	p->cv.notify_all();
+	return 0;
+}
+
+int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nbytes, uint32_t *nblocks)
+{
+	if (!p || !data || !nbytes)
+		return HD_E_ARG;
+	PipeSlot *sp;
+	{
+		std::unique_lock<std::mutex> lk(p->mu);
+		if (p->held >= 0) {                      // the previous result goes back to the pool
+			p->slots[p->held].state = 0;
+			p->held = -1;
+			p->cv.notify_all();
+		}
+		if (p->n_out == p->n_sub)
+			return HD_E_ARG;                 // nothing pending
+		sp = &p->slots[p->n_out % p->depth];
+	}
+	PipeSlot &s = *sp;
+	int r = bind_device();
+	if (r)
+		return r;
+	int bad = 0;
+	size_t total = 0;
+	if (s.nb) {
+		HD_CHECK(hipStreamSynchronize(s.st));
+		// the device layout from d_olen on: olen[nb], crc[nb], status[nb], doff[nb] (u64), total (u64);
+		// d_meta is 256-byte aligned and 24 nb bytes precede doff, so there is no padding
+		const uint32_t *h_olen = (const uint32_t *)s.h_meta.p;
+		const int32_t *h_st = (const int32_t *)(h_olen + 2 * s.nb);
+		uint64_t t64;
+		memcpy(&t64, (const uint8_t *)s.h_meta.p + (size_t)20 * s.nb, 8);
+		total = (size_t)t64;
+		for (uint32_t i = 0; i < s.nb; i++)
+			bad |= h_st[i] != 0;
+		HD_CHECK(hipMemcpyAsync(s.h_out.p, s.d_packed.p, total, hipMemcpyDeviceToHost, s.st));
+		HD_CHECK(hipStreamSynchronize(s.st));
+	}
+	*data = (const uint8_t *)s.h_out.p;
+	*nbytes = total;
+	if (nblocks)
+		*nblocks = s.nb;
+	std::lock_guard<std::mutex> lk(p->mu);
+	s.state = 3;
+	p->held = (int)(p->n_out % p->depth);
+	p->n_out++;
+	return bad ? 1 : 0;
+}
+
+void hipdeflate_pipe_close(hipdeflate_pipe *p)
+{
+	if (!p)
+		return;
+	(void)hipDeviceSynchronize();
+	for (PipeSlot &s : p->slots) {
+		s.h_in.release();
+		s.h_out.release();
+		s.h_meta.release();
+		s.d_in.release();
+		s.d_meta.release();
+		s.d_slots.release();
+		s.d_packed.release();
+		if (s.st)
+			(void)hipStreamDestroy(s.st);
+	}
+	delete p;
 }
 
 /* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */

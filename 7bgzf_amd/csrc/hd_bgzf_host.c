@@ -11,137 +11,142 @@
  *
  * What changed, and why: the reference reads one <=64 KiB block, compresses it on
  * a fresh pthread and writes it (applet/7bgzf.c:159-277); a GPU needs thousands
- * of blocks per launch, so this host reads HD_BATCH blocks at once, makes ONE
- * hipdeflate_batch_deflate call in HD_FRAME_BGZF mode (the kernel writes header,
- * BSIZE, CRC32, ISIZE) and writes the members back in order.  A reader thread and
- * a writer thread overlap stdio with the device (double buffering).
+ * of blocks per launch, so this host drives a hipdeflate_pipe: batches of HD_BATCH
+ * blocks are read straight into pinned memory, three of them are in flight (H2D
+ * copy, kernels in HD_FRAME_BGZF mode -- the kernel writes header, BSIZE, CRC32,
+ * ISIZE --, device-side gather, D2H copy), and every finished batch is one
+ * contiguous run of members that leaves with a single write().
  * Blocks are 0xff00 bytes (the reference's multi-thread size, :146-147); the
  * single-thread 0x10000 + shrink-by-1024 retry (:256-262) is not needed because
  * the kernel falls back to stored blocks, which always fit.
  */
+#include <errno.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include "hipdeflate.h"
 
-#define HD_BATCH 4096
+#define HD_BATCH 4096          /* decode: members per launch */
+#define HD_PIPE_BATCH 1024     /* encode: blocks per pipe batch (64 MiB of pinned input each) */
 
 static const unsigned char eof_member[28] = { 0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0x00, 0xff, 0x06, 0x00, 'B',
 					      'C',  0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0 };
-
-struct job {
-	unsigned char *in, *out;
-	uint64_t *off, *ooff;
-	uint32_t *len, *olen, *ocap;
-	int32_t *st;
-	size_t in_bytes;
-	uint32_t nb;
-	int eof;                 /* reader hit EOF: no more jobs after this one */
-};
-
-/* two jobs in flight: reader fills one while the device works on the other */
-static struct job jobs[2];
-static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
-static int state[2];             /* 0 free, 1 filled (ready for device), 2 done (ready for writer) */
 
 static uint32_t rd16(const unsigned char *p) { return p[0] | (p[1] << 8); }
 static uint32_t rd32(const unsigned char *p) { return rd16(p) | (rd16(p + 2) << 16); }
 
 static size_t g_block = 0xff00;
-static size_t g_slot = 65536;
 static int g_frame = HD_FRAME_BGZF;
+
+/* compress: the reader thread fills pinned batches straight from stdin and submits
+ * them, the main thread takes the finished batches (one contiguous run of members
+ * each) in order and writes them; three batches are in flight on the device side */
+static hipdeflate_pipe *g_pipe;
+static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+static int g_submitted, g_reader_done, g_reader_err;
 
 static void *reader_main(void *arg)
 {
 	(void)arg;
-	for (int k = 0;; k ^= 1) {
-		pthread_mutex_lock(&mu);
-		while (state[k] != 0)
-			pthread_cond_wait(&cv, &mu);
-		pthread_mutex_unlock(&mu);
-		struct job *j = &jobs[k];
-		j->in_bytes = fread(j->in, 1, HD_BATCH * g_block, stdin);
-		j->nb = (uint32_t)((j->in_bytes + g_block - 1) / g_block);
-		j->eof = j->in_bytes < HD_BATCH * g_block;
-		for (uint32_t i = 0; i < j->nb; i++) {
-			j->off[i] = (uint64_t)i * g_block;
-			j->len[i] = (uint32_t)(i + 1 < j->nb ? g_block : j->in_bytes - j->off[i]);
+	for (;;) {
+		size_t cap = 0, got = 0;
+		unsigned char *buf = hipdeflate_pipe_input(g_pipe, &cap);
+		int err = buf == NULL;
+		while (!err && got < cap) {
+			ssize_t r = read(0, buf + got, cap - got);
+			if (r < 0 && errno == EINTR)
+				continue;
+			if (r <= 0) {
+				err = r < 0 ? 2 : 0;
+				break;
+			}
+			got += (size_t)r;
 		}
+		if (!err && hipdeflate_pipe_submit(g_pipe, got))
+			err = 1;
 		pthread_mutex_lock(&mu);
-		state[k] = 1;
+		if (err)
+			g_reader_err = err;
+		else
+			g_submitted++;
+		if (err || got < cap)
+			g_reader_done = 1;
 		pthread_cond_broadcast(&cv);
 		pthread_mutex_unlock(&mu);
-		if (j->eof)
+		if (err || got < cap)
 			return NULL;
 	}
 }
 
-static int alloc_jobs(size_t in_per, size_t out_per)
+static int write_all(const unsigned char *p, size_t n)
 {
-	for (int k = 0; k < 2; k++) {
-		struct job *j = &jobs[k];
-		j->in = malloc(HD_BATCH * in_per);
-		j->out = malloc(HD_BATCH * out_per);
-		j->off = malloc(HD_BATCH * 8);
-		j->ooff = malloc(HD_BATCH * 8);
-		j->len = malloc(HD_BATCH * 4);
-		j->olen = malloc(HD_BATCH * 4);
-		j->ocap = malloc(HD_BATCH * 4);
-		j->st = malloc(HD_BATCH * 4);
-		if (!j->in || !j->out || !j->off || !j->ooff || !j->len || !j->olen || !j->ocap || !j->st)
+	while (n) {
+		ssize_t w = write(1, p, n);
+		if (w < 0 && errno == EINTR)
+			continue;
+		if (w <= 0)
 			return 1;
+		p += w;
+		n -= (size_t)w;
 	}
 	return 0;
 }
 
 static int do_compress(int level)
 {
-	if (alloc_jobs(g_block, g_slot))
+	g_pipe = hipdeflate_pipe_open(level, g_frame, (uint32_t)g_block, g_frame == HD_FRAME_MIGZ ? (uint32_t)((HD_PIPE_BATCH * (size_t)0xff00 + g_block - 1) / g_block) : HD_PIPE_BATCH, 4);
+	if (!g_pipe) {
+		fprintf(stderr, "hip_deflate: cannot open the device pipeline\n");
 		return 1;
+	}
 	pthread_t rd;
 	pthread_create(&rd, NULL, reader_main, NULL);
-	int total_blocks = 0, chk = 64;
-	for (int k = 0;; k ^= 1) {
+	int total_blocks = 0, chk = 64, fetched = 0, ret = 0;
+	for (;;) {
 		pthread_mutex_lock(&mu);
-		while (state[k] != 1)
+		while (fetched == g_submitted && !g_reader_done)
 			pthread_cond_wait(&cv, &mu);
+		int more = fetched < g_submitted, err = g_reader_err;
 		pthread_mutex_unlock(&mu);
-		struct job *j = &jobs[k];
-		if (j->nb) {
-			int r = hipdeflate_batch_deflate(j->in, j->off, j->len, j->nb, level, g_frame, j->out, g_slot,
-							 (uint32_t)g_slot, j->olen, NULL, j->st);
-			if (r) {
-				fprintf(stderr, "hip_deflate %d\n", r);
-				return 1;
+		if (!more) {
+			if (err) {
+				fprintf(stderr, err == 2 ? "read error\n" : "hip_deflate: submit failed\n");
+				ret = 1;
 			}
-			for (uint32_t i = 0; i < j->nb; i++) {
-				if (j->st[i]) {
-					fprintf(stderr, "hip_deflate %d\n", j->st[i]);   /* applet/7bgzf.c:228-254 */
-					return 1;
-				}
-				fwrite(j->out + (size_t)i * g_slot, 1, j->olen[i], stdout);
-			}
-			total_blocks += (int)j->nb;
-			while (total_blocks >= chk) {                 /* progress as applet/7bgzf.c:278-281 */
-				fprintf(stderr, "%d\r", chk);
-				chk += 64;
-			}
-		}
-		int eof = j->eof;
-		pthread_mutex_lock(&mu);
-		state[k] = 0;
-		pthread_cond_broadcast(&cv);
-		pthread_mutex_unlock(&mu);
-		if (eof)
 			break;
+		}
+		const uint8_t *data;
+		size_t nbytes;
+		uint32_t nb;
+		int r = hipdeflate_pipe_result(g_pipe, &data, &nbytes, &nb);
+		if (r) {
+			fprintf(stderr, "hip_deflate %d\n", r);                      /* applet/7bgzf.c:228-254 */
+			ret = 1;
+			break;
+		}
+		fetched++;
+		if (write_all(data, nbytes)) {
+			fprintf(stderr, "write error\n");
+			ret = 1;
+			break;
+		}
+		total_blocks += (int)nb;
+		while (total_blocks >= chk) {                     /* progress as applet/7bgzf.c:278-281 */
+			fprintf(stderr, "%d\r", chk);
+			chk += 64;
+		}
 	}
+	if (ret)
+		_exit(1);                                         /* the reader may sit in read(): do not join it */
 	pthread_join(rd, NULL);
-	if (g_frame == HD_FRAME_BGZF)
-		fwrite(eof_member, 1, 28, stdout);                    /* applet/7bgzf.c:283-289 */
+	hipdeflate_pipe_close(g_pipe);
+	if (g_frame == HD_FRAME_BGZF && write_all(eof_member, 28))            /* applet/7bgzf.c:283-289 */
+		return 1;
 	fprintf(stderr, "%d done.\n", total_blocks);
 	return 0;
 }
@@ -279,7 +284,6 @@ int main(int argc, char **argv)
 	}
 	if (g_frame == HD_FRAME_MIGZ) {
 		g_block = (size_t)bsize * 1024;
-		g_slot = (g_block + g_block / 8 + 4096 + 15) & ~(size_t)15;
 	}
 	if (hipdeflate_init(-1))
 		return 1;

@@ -140,6 +140,35 @@ int hipdeflate_compact_dev(const void *slots, uint64_t stride,
 			   const void *out_len, const void *dst_off,
 			   uint32_t nblocks, void *dst, void *stream);
 
+/* ---- streaming encoder: the host pipeline either side of the kernels ------------
+ * Role of the read / compress / write loop of applet/7bgzf.c:159-293 (7migz.c:130-244)
+ * for a stream of fixed-size blocks (the last may be short).  `depth` batches are in
+ * flight: the caller fills PINNED input memory directly (no staging copy), H2D copy,
+ * kernels and D2H copy of different batches overlap on their own streams, and a
+ * result is ONE contiguous run of finished members in block order (the device
+ * gathers them), so writing it out is a single write().  Calls on one pipe may come
+ * from two threads: one doing input()/submit(), one doing result().
+ *
+ *   p   = hipdeflate_pipe_open(level, HD_FRAME_BGZF, 0xff00, 4096, 3);
+ *   buf = hipdeflate_pipe_input(p, &cap);  n = read(0, buf, cap);  hipdeflate_pipe_submit(p, n);
+ *   hipdeflate_pipe_result(p, &data, &nbytes, &nblocks);  write(1, data, nbytes);
+ */
+typedef struct hipdeflate_pipe hipdeflate_pipe;
+/* block_bytes must be a multiple of 16 (0xff00, 0x10000 and b * 1024 are); depth >= 2 */
+hipdeflate_pipe *hipdeflate_pipe_open(int level, int frame, uint32_t block_bytes,
+				      uint32_t blocks_per_batch, int depth);
+/* pinned buffer for the next batch, *cap = block_bytes * blocks_per_batch; waits for
+ * a free slot (one whose result has been fetched and released); NULL on error */
+uint8_t *hipdeflate_pipe_input(hipdeflate_pipe *p, size_t *cap);
+/* enqueue the batch just filled (nbytes <= cap, 0 allowed); returns at once */
+int hipdeflate_pipe_submit(hipdeflate_pipe *p, size_t nbytes);
+/* the oldest submitted batch: waits for it.  *data stays valid until the next call of
+ * hipdeflate_pipe_result on this pipe.  Returns 0; 1 if a block did not fit its slot
+ * (cannot happen for BGZF/MiGz block sizes); HD_E_*; HD_E_ARG when nothing is pending */
+int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nbytes,
+			   uint32_t *nblocks);
+void hipdeflate_pipe_close(hipdeflate_pipe *p);
+
 /* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level<=1);
  * the library keeps its own grow-only scratch, this is informational */
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level);

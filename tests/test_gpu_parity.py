@@ -136,6 +136,25 @@ def test_encode_zlib_and_gzip_frames(pkg, level):
         assert zl.hex() == g["rfc1950"]["bytes"] and gz.hex() == g["rfc1952"]["bytes"]
 
 
+@pytest.mark.parametrize("level,frame,block", [(1, "bgzf", 0xff00), (3, "bgzf", 0xff00), (6, "migz", 1 << 16),
+                                               (1, "raw_flush", 4096)])
+def test_streaming_pipe_matches_batch_api(pkg, level, frame, block):
+    """hipdeflate_pipe_*: several batches in flight on their own streams (the dynamic levels share the
+    library's token slabs and must take turns) == the members the batch API gives, in order."""
+    syn = hdtest.synth()
+    data = syn.fastq_like(37 * block + 1234).tobytes()[: 37 * block + 1234]      # 38 blocks, ragged tail
+    fr = {"bgzf": pkg.FRAME_BGZF, "migz": pkg.FRAME_MIGZ, "raw_flush": pkg.FRAME_RAW_FLUSH}[frame]
+    offs = list(range(0, len(data), block))
+    lens = [min(block, len(data) - o) for o in offs]
+    members, _, st = pkg.batch_deflate(data, offs, lens, level, fr)
+    assert not any(st)
+    want = b"".join(members)
+    for per_batch, depth in ((5, 2), (8, 3), (64, 4)):
+        got = pkg.pipe_compress(data, level, fr, block, per_batch, depth)
+        assert got == want, (per_batch, depth, len(got), len(want))
+    assert pkg.pipe_compress(b"", level, fr, block, 4, 2) == b""
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
