@@ -157,3 +157,41 @@ def corpus_small():
         "mixed": bytes(fq[:20000]) + bytes(rnd[:20000]) + bytes(20000) + bytes(tx[:5280]),
         "bytes_0_255_x4": bytes(range(256)) * 4,
     }
+
+
+def corpus_fuzz(seed, count):
+    """Seeded structured-random blocks that lean on the corners of the parse: runs and periodic
+    data (8-byte-capped matches, extension across steps, lengths around 258), copies at distances
+    around every window size, literal stretches, low-entropy alphabets (static vs dynamic vs
+    stored decisions), lengths around step / piece / block boundaries."""
+    rng = np.random.default_rng(seed)
+    edges = [0, 1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 127, 128, 129, 255, 256, 257, 258, 259, 322, 1023, 1024, 1025,
+             4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385, 32768, 65279, 65280, 65281, 65535, 65536, 70001]
+    out = []
+    for k in range(count):
+        n = int(edges[k % len(edges)]) if k < 2 * len(edges) else int(rng.integers(0, 70000))
+        parts, have = [], 0
+        while have < n:
+            kind = int(rng.integers(0, 6))
+            m = int(min(n - have, rng.choice([1, 3, 9, 40, 258, 300, 1000, 5000])))
+            if kind == 0:                                  # literals, full alphabet
+                seg = rng.integers(0, 256, m, dtype=np.uint8)
+            elif kind == 1:                                # a run
+                seg = np.full(m, int(rng.integers(0, 256)), dtype=np.uint8)
+            elif kind == 2:                                # periodic, period 1..9
+                per = rng.integers(0, 256, int(rng.integers(1, 10)), dtype=np.uint8)
+                seg = np.tile(per, m // len(per) + 1)[:m]
+            elif kind == 3 and have > 8:                   # copy from a distance near a window edge
+                cat = np.concatenate(parts)
+                d = int(rng.choice([1, 2, 3, 4, 8, 64, 4095, 4096, 4097, 8191, 8192, 8193, 16384, 32768]))
+                d = min(d, have)
+                src = cat[have - d:have - d + m] if d >= m else np.tile(cat[have - d:], m // d + 1)[:m]
+                seg = src.copy()
+            elif kind == 4:                                # four-letter alphabet
+                seg = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), m)
+            else:                                          # text-ish, skewed
+                seg = rng.choice(np.frombuffer(b"etaoin shrdlu\n", dtype=np.uint8), m)
+            parts.append(np.ascontiguousarray(seg, dtype=np.uint8))
+            have += len(seg)
+        out.append(np.concatenate(parts).tobytes()[:n] if parts else b"")
+    return out

@@ -155,6 +155,26 @@ def test_streaming_pipe_matches_batch_api(pkg, level, frame, block):
     assert pkg.pipe_compress(b"", level, fr, block, 4, 2) == b""
 
 
+@pytest.mark.parametrize("level", [1, 3, 6, 9])
+def test_encode_fuzz_blocks_match_twin(pkg, level):
+    """160 seeded structured-random blocks per level (hdtest.corpus_fuzz), unaligned starts included:
+    kernel bytes == twin bytes, and zlib inflates them back."""
+    blocks = hdtest.corpus_fuzz(1000 + level, 160)
+    blob, offs, lens = bytearray(), [], []
+    for i, d in enumerate(blocks):
+        blob += bytes((i * 7) % 16 if i % 3 == 0 else -len(blob) % 16)      # every third start is unaligned
+        offs.append(len(blob))
+        lens.append(len(d))
+        blob += d
+    members, crc, st = pkg.batch_deflate(bytes(blob), offs, lens, level, pkg.FRAME_RAW)
+    for i, d in enumerate(blocks):
+        assert st[i] == 0, i
+        r, twin = hdtest.oracle_twin(d, level)
+        assert r == 0 and members[i] == twin, (i, len(d), level, len(members[i]), len(twin))
+        assert zlib.decompress(members[i], -15) == d, i
+        assert int(crc[i]) == hdtest.oracle_crc32(d), i
+
+
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
@@ -442,3 +462,38 @@ def test_device_resident_pipeline_properties(pkg):
         r, twin = hdtest.oracle_twin(chunk, 1, cap=65536 - 26)
         assert m[18:-8] == twin
         assert int.from_bytes(m[-8:-4], "little") == zlib.crc32(chunk)
+
+
+def test_decode_fuzz_zlib_streams_and_truncations(pkg):
+    """Streams made on the spot by the box's zlib from the structured-random blocks -- every level
+    and strategy (stored, fixed codes, Huffman-only, RLE with distance-1 runs, filtered) -- must
+    inflate bit-exactly with the right CRC; the same streams cut short or with the wrong capacity must
+    get the oracle's verdict (whose rules are pinned against libdeflate, test_oracle_vs_ref.py)."""
+    blocks = hdtest.corpus_fuzz(77, 120)
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]
+    streams, caps, want = [], [], []
+    for i, d in enumerate(blocks):
+        c = zlib.compressobj([0, 1, 6, 9][i % 4], zlib.DEFLATED, -15, 1 + i % 9, strategies[i % 5])
+        z = c.compress(d) + c.flush()
+        streams.append(z + bytes(8))                       # trailing bytes are ignored (applet/7bgzf.c:328)
+        caps.append(len(d))
+        want.append(d)
+    outs, crc, st = pkg.batch_inflate(streams, caps)
+    for i, d in enumerate(want):
+        assert st[i] == 0 and outs[i] == d, (i, len(d), int(st[i]))
+        assert int(crc[i]) == hdtest.oracle_crc32(d), i
+    # verdict parity on damaged calls
+    bad_streams, bad_caps = [], []
+    rng = np.random.default_rng(5)
+    for i, d in enumerate(want):
+        z = streams[i][:-8]
+        if len(z) > 2:
+            bad_streams.append(z[: int(rng.integers(1, len(z)))])        # truncated
+            bad_caps.append(len(d))
+        if len(d) > 0:
+            bad_streams.append(z)                                          # capacity one short
+            bad_caps.append(len(d) - 1)
+    _, _, st = pkg.batch_inflate(bad_streams, bad_caps, want_crc=False)
+    for i, z in enumerate(bad_streams):
+        r, _ = hdtest.oracle_inflate(z, bad_caps[i])
+        assert int(st[i]) == r and r != 0, (i, int(st[i]), r)
