@@ -43,7 +43,8 @@ EXPORTS = [
     "hipdeflate_batch_deflate_dev", "hipdeflate_batch_inflate_dev", "hipdeflate_scan_sizes_dev",
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
     "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
-    "hipdeflate_pipe_close",
+    "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
+    "hipdeflate_unpipe_result", "hipdeflate_unpipe_close",
 ]
 
 
@@ -108,6 +109,14 @@ def lib():
     L.hipdeflate_pipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p, ctypes.POINTER(ctypes.c_uint32)]
     L.hipdeflate_pipe_close.restype = None
     L.hipdeflate_pipe_close.argtypes = [_vp]
+    L.hipdeflate_unpipe_open.restype = _vp
+    L.hipdeflate_unpipe_open.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    L.hipdeflate_unpipe_input.restype = _vp
+    L.hipdeflate_unpipe_input.argtypes = [_vp, sz_p]
+    L.hipdeflate_unpipe_submit.argtypes = [_vp, _vp, _vp, _vp, ctypes.c_uint32]
+    L.hipdeflate_unpipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p]
+    L.hipdeflate_unpipe_close.restype = None
+    L.hipdeflate_unpipe_close.argtypes = [_vp]
     _lib = L
     return L
 
@@ -307,6 +316,56 @@ def bgzf_scan(blob):
         out.append((p + 18, total - 18, isize))
         p += total
     return out
+
+
+def unpipe_decompress(blob, members_per_batch=16, depth=3):
+    """BGZF bytes through the streaming decoder (hipdeflate_unpipe_*), `members_per_batch` members per
+    batch, as many batches in flight as the pipe allows.  -> (status of the first failing batch or 0, output)."""
+    L = lib()
+    blob = bytes(blob)
+    tbl = bgzf_scan(blob)
+    groups = [tbl[i:i + members_per_batch] for i in range(0, len(tbl), members_per_batch)] or [[]]
+    in_cap = max([g[-1][0] + g[-1][1] - (g[0][0] - 18) for g in groups if g] + [64])
+    out_cap = max([sum(m[2] for m in g) for g in groups] + [64])
+    p = L.hipdeflate_unpipe_open(members_per_batch, in_cap, out_cap, depth)
+    if not p:
+        raise HipDeflateError("hipdeflate_unpipe_open failed")
+    out, inflight, status = [], 0, 0
+
+    def fetch():
+        nonlocal status
+        d, n = ctypes.c_void_p(), ctypes.c_size_t()
+        r = L.hipdeflate_unpipe_result(p, ctypes.byref(d), ctypes.byref(n))
+        if r and not status:
+            status = r
+        out.append(ctypes.string_at(d, n.value) if not r else b"")
+
+    try:
+        for g in groups:
+            if inflight == depth - 1:
+                fetch()
+                inflight -= 1
+            cap = ctypes.c_size_t()
+            buf = L.hipdeflate_unpipe_input(p, ctypes.byref(cap))
+            if not buf:
+                raise HipDeflateError("hipdeflate_unpipe_input failed")
+            base = g[0][0] - 18 if g else 0
+            end = g[-1][0] + g[-1][1] if g else 0
+            if end > base:
+                ctypes.memmove(buf, blob[base:end], end - base)
+            ioff = np.array([m[0] - base for m in g], dtype=np.uint64)
+            ilen = np.array([m[1] for m in g], dtype=np.uint32)
+            osz = np.array([m[2] for m in g], dtype=np.uint32)
+            if L.hipdeflate_unpipe_submit(p, _p(ioff) if len(g) else None, _p(ilen) if len(g) else None,
+                                          _p(osz) if len(g) else None, len(g)):
+                raise HipDeflateError("hipdeflate_unpipe_submit failed")
+            inflight += 1
+        while inflight:
+            fetch()
+            inflight -= 1
+    finally:
+        L.hipdeflate_unpipe_close(p)
+    return status, b"".join(out)
 
 
 def bgzf_decompress_bytes(blob, verify=True):

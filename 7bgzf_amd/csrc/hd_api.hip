@@ -76,8 +76,12 @@ struct Ctx {
 	std::mutex mu_dev;
 	Buf d_tok;
 	Buf d_tiles;
-	hipEvent_t ev_tok = nullptr;     // last launch that used d_tok: the next one waits for it
+	hipEvent_t ev_tok = nullptr;     // last launch that used d_tok: a launch on ANOTHER stream waits for it
+	hipStream_t st_tok = nullptr;
+	bool tok_used = false;
 	hipEvent_t ev_tiles = nullptr;   // the same for d_tiles
+	hipStream_t st_tiles = nullptr;
+	bool tiles_used = false;
 };
 
 Ctx g;
@@ -262,11 +266,14 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 		// the slabs are shared by every launch: launches on different streams take turns
 		if (!g.ev_tok)
 			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
-		else
+		if (g.tok_used && g.st_tok != (hipStream_t)stream)          // same stream: already in order
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
 		r = launch_deflate(a, level, (hipStream_t)stream);
-		if (!r)
+		if (!r) {
 			HD_CHECK(hipEventRecord(g.ev_tok, (hipStream_t)stream));
+			g.st_tok = (hipStream_t)stream;
+			g.tok_used = true;
+		}
 		return r;
 	}
 	return launch_deflate(a, level, (hipStream_t)stream);
@@ -323,7 +330,7 @@ int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t ba
 	hipStream_t st = (hipStream_t)stream;
 	if (!g.ev_tiles)
 		HD_CHECK(hipEventCreateWithFlags(&g.ev_tiles, hipEventDisableTiming));
-	else
+	if (g.tiles_used && g.st_tiles != st)                               // same stream: already in order
 		HD_CHECK(hipStreamWaitEvent(st, g.ev_tiles, 0));
 	hipLaunchKernelGGL(hd::k_scan_tile_sums, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)out_len, nblocks, tiles);
 	hipLaunchKernelGGL(hd::k_scan_tiles, dim3(1), dim3(256), 0, st, tiles, ntiles, base, (uint64_t *)total);
@@ -331,6 +338,8 @@ int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t ba
 			   (uint64_t *)dst_off);
 	HD_CHECK(hipGetLastError());
 	HD_CHECK(hipEventRecord(g.ev_tiles, st));
+	g.st_tiles = st;
+	g.tiles_used = true;
 	return 0;
 }
 
@@ -694,8 +703,188 @@ void hipdeflate_pipe_close(hipdeflate_pipe *p)
 		s.d_meta.release();
 		s.d_slots.release();
 		s.d_packed.release();
-		if (s.st)
+		if (s.st) {
+			// everything on the stream has finished: nobody needs to wait for its events any more
+			std::lock_guard<std::mutex> lk(g.mu_dev);
+			if (g.st_tiles == s.st)
+				g.tiles_used = false;
+			if (g.st_tok == s.st)
+				g.tok_used = false;
 			(void)hipStreamDestroy(s.st);
+		}
+	}
+	delete p;
+}
+
+/* ---- streaming decoder ---------------------------------------------------------- */
+
+struct hipdeflate_unpipe {
+	int depth;
+	uint32_t max_members;
+	size_t in_cap, out_cap;
+	std::vector<PipeSlot> slots;
+	std::mutex mu;
+	std::condition_variable cv;
+	uint64_t n_in = 0, n_sub = 0, n_out = 0;
+	int held = -1;
+};
+
+hipdeflate_unpipe *hipdeflate_unpipe_open(uint32_t max_members, size_t in_cap, size_t out_cap, int depth)
+{
+	if (ensure() || bind_device())
+		return nullptr;
+	if (!max_members || !in_cap || !out_cap || depth < 2 || depth > 16 || in_cap > 0xffff0000ull)
+		return nullptr;
+	hipdeflate_unpipe *p = new hipdeflate_unpipe;
+	p->depth = depth;
+	p->max_members = max_members;
+	p->in_cap = in_cap;
+	p->out_cap = out_cap;
+	p->slots.resize(depth);
+	const size_t meta = (size_t)max_members * (8 + 8 + 4 + 4 + 4 + 4 + 4) + 64;
+	for (PipeSlot &s : p->slots) {
+		if (s.h_in.reserve(in_cap) || s.d_in.reserve(in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
+		    s.d_slots.reserve(out_cap + 16) || s.h_out.reserve(out_cap + 16) ||
+		    hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+			hipdeflate_unpipe_close(p);
+			return nullptr;
+		}
+	}
+	return p;
+}
+
+uint8_t *hipdeflate_unpipe_input(hipdeflate_unpipe *p, size_t *cap)
+{
+	if (!p)
+		return nullptr;
+	std::unique_lock<std::mutex> lk(p->mu);
+	PipeSlot &s = p->slots[p->n_in % p->depth];
+	if (s.state == 1)
+		return nullptr;
+	p->cv.wait(lk, [&] { return s.state == 0; });
+	s.state = 1;
+	if (cap)
+		*cap = p->in_cap;
+	return (uint8_t *)s.h_in.p;
+}
+
+int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const uint32_t *in_len,
+			     const uint32_t *out_size, uint32_t nmembers)
+{
+	if (!p || nmembers > p->max_members || (nmembers && (!in_off || !in_len || !out_size)))
+		return HD_E_ARG;
+	PipeSlot *sp;
+	{
+		std::lock_guard<std::mutex> lk(p->mu);
+		sp = &p->slots[p->n_in % p->depth];
+		if (sp->state != 1)
+			return HD_E_ARG;
+	}
+	PipeSlot &s = *sp;
+	int r = bind_device();
+	if (r)
+		return r;
+	// pinned table: ioff[n] ooff[n] (u64) | ilen[n] ocap[n] (u32); results olen[n] crc[n] st[n] behind it
+	const uint32_t n = nmembers;
+	uint64_t *h_ioff = (uint64_t *)s.h_meta.p, *h_ooff = h_ioff + n;
+	uint32_t *h_ilen = (uint32_t *)(h_ooff + n), *h_ocap = h_ilen + n;
+	size_t in_end = 0, osum = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		h_ioff[i] = in_off[i];
+		h_ilen[i] = in_len[i];
+		h_ooff[i] = osum;
+		h_ocap[i] = out_size[i];
+		osum += out_size[i];
+		if (in_off[i] + in_len[i] > in_end)
+			in_end = (size_t)(in_off[i] + in_len[i]);
+	}
+	if (in_end > p->in_cap || osum > p->out_cap)
+		return HD_E_ARG;
+	s.nb = n;
+	s.nbytes = osum;
+	if (n) {
+		uint8_t *dm = (uint8_t *)s.d_meta.p;
+		uint64_t *d_ioff = (uint64_t *)dm, *d_ooff = d_ioff + n;
+		uint32_t *d_ilen = (uint32_t *)(d_ooff + n), *d_ocap = d_ilen + n, *d_olen = d_ocap + n;
+		int32_t *d_st = (int32_t *)(d_olen + n);
+		HD_CHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, in_end, hipMemcpyHostToDevice, s.st));
+		HD_CHECK(hipMemcpyAsync(dm, s.h_meta.p, (size_t)n * 24, hipMemcpyHostToDevice, s.st));
+		if ((r = hipdeflate_batch_inflate_dev(s.d_in.p, d_ioff, d_ilen, n, s.d_slots.p, d_ooff, d_ocap, d_olen, nullptr,
+						      d_st, s.st)))
+			return r;
+		HD_CHECK(hipMemcpyAsync((uint8_t *)s.h_meta.p + (size_t)n * 24, d_olen, (size_t)n * 8, hipMemcpyDeviceToHost,
+					s.st));
+		if (osum)
+			HD_CHECK(hipMemcpyAsync(s.h_out.p, s.d_slots.p, osum, hipMemcpyDeviceToHost, s.st));
+	}
+	std::lock_guard<std::mutex> lk(p->mu);
+	s.state = 2;
+	p->n_in++;
+	p->n_sub++;
+	p->cv.notify_all();
+	return 0;
+}
+
+int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t *nbytes)
+{
+	if (!p || !data || !nbytes)
+		return HD_E_ARG;
+	PipeSlot *sp;
+	{
+		std::unique_lock<std::mutex> lk(p->mu);
+		if (p->held >= 0) {
+			p->slots[p->held].state = 0;
+			p->held = -1;
+			p->cv.notify_all();
+		}
+		if (p->n_out == p->n_sub)
+			return HD_E_ARG;
+		sp = &p->slots[p->n_out % p->depth];
+	}
+	PipeSlot &s = *sp;
+	int r = bind_device();
+	if (r)
+		return r;
+	int verdict = 0;
+	if (s.nb) {
+		HD_CHECK(hipStreamSynchronize(s.st));
+		const uint32_t n = s.nb;
+		const uint32_t *h_ocap = (const uint32_t *)((const uint8_t *)s.h_meta.p + (size_t)n * 20);
+		const uint32_t *h_olen = h_ocap + n;
+		const int32_t *h_st = (const int32_t *)(h_olen + n);
+		for (uint32_t i = 0; i < n && !verdict; i++)
+			verdict = h_st[i] ? h_st[i] : (h_olen[i] != h_ocap[i] ? HD_INSUFFICIENT_SPACE : 0);
+	}
+	*data = (const uint8_t *)s.h_out.p;
+	*nbytes = s.nbytes;
+	std::lock_guard<std::mutex> lk(p->mu);
+	s.state = 3;
+	p->held = (int)(p->n_out % p->depth);
+	p->n_out++;
+	return verdict;
+}
+
+void hipdeflate_unpipe_close(hipdeflate_unpipe *p)
+{
+	if (!p)
+		return;
+	(void)hipDeviceSynchronize();
+	for (PipeSlot &s : p->slots) {
+		s.h_in.release();
+		s.h_out.release();
+		s.h_meta.release();
+		s.d_in.release();
+		s.d_meta.release();
+		s.d_slots.release();
+		if (s.st) {
+			// everything on the stream has finished: nobody needs to wait for its events any more
+			std::lock_guard<std::mutex> lk(g.mu_dev);
+			if (g.st_tiles == s.st)
+				g.tiles_used = false;
+			if (g.st_tok == s.st)
+				g.tok_used = false;
+			(void)hipStreamDestroy(s.st);
+		}
 	}
 	delete p;
 }

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// instructions per token on it, so it is written out: 4 SALU + 2 branches
 			// + 1 v_readlane per token.  It stops in front of the first token the window
 			// cannot take (long codeword, end of block); that one goes to the scalar loop.
-			const uint32_t walk = tokbits | ((slow || kind == K_EOB) ? 64u : 0u);
+			// (a zero-bit token cannot come out of a well-formed table; if it ever did, the walk would
+			// not advance, so it counts as a stop too and the fully checked scalar path decides)
+			const uint32_t walk = tokbits | ((slow || kind == K_EOB || tokbits == 0) ? 64u : 0u);
 			uint32_t b, wm;
 			uint64_t real;
 			// (a lane select written by the SALU needs no wait states before v_readlane,

@@ -169,6 +169,24 @@ int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nby
 			   uint32_t *nblocks);
 void hipdeflate_pipe_close(hipdeflate_pipe *p);
 
+/* ---- streaming decoder: the same pipeline in the other direction -----------------
+ * Role of the read / inflate / write loop of applet/7bgzf.c:295-365.  The caller reads
+ * compressed bytes into pinned memory, pre-scans the member headers there (the serial
+ * BSIZE walk of _read_gz_header, applet/7bgzf.c:81-131) and submits the table; a
+ * result is the batch's output as ONE contiguous run (member i at the exclusive
+ * prefix sum of out_size[]).  Threading as for hipdeflate_pipe. */
+typedef struct hipdeflate_unpipe hipdeflate_unpipe;
+hipdeflate_unpipe *hipdeflate_unpipe_open(uint32_t max_members, size_t in_cap, size_t out_cap, int depth);
+uint8_t *hipdeflate_unpipe_input(hipdeflate_unpipe *p, size_t *cap);
+/* member i: raw DEFLATE at in_off[i] .. +in_len[i] of the buffer (trailing bytes allowed),
+ * inflating to exactly out_size[i] bytes (the ISIZE of its trailer); sum(out_size) <= out_cap */
+int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const uint32_t *in_len,
+			     const uint32_t *out_size, uint32_t nmembers);
+/* oldest submitted batch; returns 0, or the first member's non-zero inflate status
+ * (1 bad data / 3 does not fit, also used when a member is shorter than out_size), or HD_E_* */
+int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t *nbytes);
+void hipdeflate_unpipe_close(hipdeflate_unpipe *p);
+
 /* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level<=1);
  * the library keeps its own grow-only scratch, this is informational */
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level);

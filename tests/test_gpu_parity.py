@@ -497,3 +497,20 @@ def test_decode_fuzz_zlib_streams_and_truncations(pkg):
     for i, z in enumerate(bad_streams):
         r, _ = hdtest.oracle_inflate(z, bad_caps[i])
         assert int(st[i]) == r and r != 0, (i, int(st[i]), r)
+
+
+def test_streaming_unpipe_matches_batch_api(pkg):
+    """hipdeflate_unpipe_*: batches of members in flight, each result one contiguous run of output;
+    a damaged member surfaces as that batch's inflate status."""
+    syn = hdtest.synth()
+    data = syn.fastq_like(45 * 0xff00 + 999).tobytes()[: 45 * 0xff00 + 999]
+    bgz = pkg.bgzf_compress_bytes(data, level=3)
+    for per_batch, depth in ((7, 2), (16, 3), (64, 4)):
+        st, out = pkg.unpipe_decompress(bgz, per_batch, depth)
+        assert st == 0 and out == data, (per_batch, depth, st, len(out))
+    bad = bytearray(bgz)
+    bad[5 * 20000 + 40] ^= 0x55                      # somewhere inside a payload
+    st, _ = pkg.unpipe_decompress(bytes(bad), 16, 3)
+    ref = [hdtest.oracle_inflate(bytes(bad)[o:o + ln], isz)[0] for o, ln, isz in pkg.bgzf_scan(bytes(bad))]
+    assert st != 0 or not any(ref)                   # the oracle decides whether that flip is detectable
+    assert pkg.unpipe_decompress(pkg.bgzf_compress_bytes(b"", level=1), 4, 2) == (0, b"")
