@@ -432,6 +432,14 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 		return HD_E_NOMEM;
 	HD_CHECK(hipMemcpyAsync(g.h_out.p, g.d_packed.p, total, hipMemcpyDeviceToHost, g.stream));
 	HD_CHECK(hipStreamSynchronize(g.stream));
+	{
+		// our stream is drained: launches on other streams need not wait for its events
+		std::lock_guard<std::mutex> lk2(g.mu_dev);
+		if (g.st_tiles == g.stream)
+			g.tiles_used = false;
+		if (g.st_tok == g.stream)
+			g.tok_used = false;
+	}
 	const uint8_t *hp = (const uint8_t *)g.h_out.p;
 	const uint32_t *h_crc = h_olen + nblocks;
 	const int32_t *h_st = (const int32_t *)(h_crc + nblocks);

@@ -220,6 +220,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
 	__shared__ DynLds L;
+	// token queue: < 64 waiting + <= 64 of one step.  (No dump slots for the lanes without a token as in
+	// the level-1 kernel: LDS is granted in 1280-byte units and levels 2-4 must stay within 12 of them
+	// for 10 waves per CU.)
+	constexpr uint32_t TOKQ = 128;
+	__shared__ uint32_t tokq[TOKQ];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 	const uint32_t lane = threadIdx.x;
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
@@ -263,7 +268,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		uint4 pre = load_slot(src, n, 0, lane, aligned);
 		uint32_t bitpos = 8 * hdr, flushed = 0;
 		const uint32_t paybase = 8 * hdr;
-		uint32_t ntok = 0;
+		uint32_t ntok = 0;                   // tokens of the open DEFLATE block: in the slab + still queued
+		uint32_t ntok_slab = 0, qhead = 0, qtail = 0;
 
 		auto put = [&](uint32_t code, uint32_t nbits, uint32_t bp) {
 			if (nbits) {
@@ -469,10 +475,10 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
 			}
 			// ---- pass 2: the tokens -------------------------------------------
-			for (uint32_t base = 0; base < ntok; base += 64) {
+			for (uint32_t base = 0; base < ntok_slab; base += 64) {
 				const uint32_t k = base + lane;
 				uint32_t ca = 0, na = 0, cb = 0, nb = 0;
-				if (k < ntok) {
+				if (k < ntok_slab) {
 					const uint32_t tk = tok[k];
 					if (tk & HD_TOKEN_MATCH) {
 						uint32_t ls, leb, lev, ds, deb, dev;
@@ -505,7 +511,27 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			if (lane < 32)
 				L.df[lane] = 0;
 			ntok = 0;
+			ntok_slab = 0;
 			return true;
+		};
+
+		// queued tokens -> slab (one coalesced 4 B/lane store) + symbol histograms (ds_add_u32)
+		auto drain_tokens = [&](uint32_t count) {
+			const uint32_t t = tokq[(qhead + lane) & (TOKQ - 1)];
+			qhead += count;
+			if (lane < count) {
+				tok[ntok_slab + lane] = t;
+				if (t & HD_TOKEN_MATCH) {
+					uint32_t ls, leb, lev, ds, deb, dev;
+					len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
+					off_slot((t & 0xffff) + 1, ds, deb, dev);
+					atomicAdd(&L.lf[257 + ls], 1u);
+					atomicAdd(&L.df[ds], 1u);
+				} else {
+					atomicAdd(&L.lf[t & 0xff], 1u);
+				}
+			}
+			ntok_slab += count;
 		};
 
 		// ---- pass 1: the parse ------------------------------------------------
@@ -602,24 +628,23 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				const bool is_lit = is_start && !ok && lane < lanes;
 				carry = (lanes == 64 && E > 64) ? E - 64 : 0;
 
-				// tokens -> slab (compacted in lane order), symbols -> histograms
+				// tokens -> LDS queue (compacted in lane order); the slab store and the
+				// histogram updates cost the same for 1 or 64 tokens, so they wait for 64
 				const bool is_tok = is_match || is_lit;
 				const uint64_t tm = __ballot(is_tok);
-				const uint32_t at = ntok + __popcll(tm & ((1ull << lane) - 1));
-				if (is_match) {
-					uint32_t ls, leb, lev, ds, deb, dev;
-					len_slot(mylen, ls, leb, lev);
-					off_slot(dist, ds, deb, dev);
-					tok[at] = HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1);
-					atomicAdd(&L.lf[257 + ls], 1u);
-					atomicAdd(&L.df[ds], 1u);
-				} else if (is_lit) {
-					tok[at] = cv0 & 0xff;
-					atomicAdd(&L.lf[cv0 & 0xff], 1u);
-				}
-				ntok += __popcll(tm);
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32),
+										 __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
+				if (is_tok)
+					tokq[(qtail + rank) & (TOKQ - 1)] =
+						is_match ? (HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1)) : (cv0 & 0xff);
+				qtail += (uint32_t)__popcll(tm);
+				if (qtail - qhead >= 64)
+					drain_tokens(64);
 			}
+			ntok = ntok_slab + (qtail - qhead);          // tokens of the open block, queued ones included
 			if (ntok >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
+				if (qtail != qhead)
+					drain_tokens(qtail - qhead);
 				// our own token stores must be visible to our own loads
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -638,6 +663,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			}
 		}
 		if (alive) {
+			if (qtail != qhead)
+				drain_tokens(qtail - qhead);
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			alive = flush_block(true);
