@@ -56,3 +56,38 @@ def test_migz_framing_roundtrip():
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err
+
+
+def test_ld_preload_hook_takes_over_an_htslib_shaped_writer(tmp_path):
+    """The product's headline use (readme.md:9-14): `BGZF_METHOD=hip1 LD_PRELOAD=libhipdeflate.so samtools ...`.
+    The image has no htslib, so tests/native/fakehts.c stands in for libhts.so: an exported default
+    bgzf_compress() and a threaded BGZF writer in the same shared object calling it through the PLT.
+    Without the preload the stand-in's stored-block members come out; with it every member must be
+    OUR level-1 member (payload == CPU twin), produced by the micro-batching hook under 8 threads."""
+    import zlib
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
+    so, exe = str(tmp_path / "libfakehts.so"), str(tmp_path / "hts_client")
+    subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(here, "fakehts.c")], check=True)
+    subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(here, "hts_client.c"), "-L" + str(tmp_path), "-lfakehts",
+                    "-Wl,-rpath," + str(tmp_path), "-pthread"], check=True)
+    data = bytes(hdtest.synth().fastq_like(40 * 0xff00 + 321))[: 40 * 0xff00 + 321]
+    env = dict(os.environ)
+    plain = subprocess.run([exe, "8"], input=data, capture_output=True, env=env, check=True).stdout
+    assert plain[18] == 1 and len(plain) > len(data)                 # the stand-in's stored blocks
+    env.update(LD_PRELOAD=hdtest.pkg().LIB_PATH, BGZF_METHOD="hip1", HIPDEFLATE_BATCH_US="1000")
+    p = subprocess.run([exe, "8"], input=data, capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-400:]
+    out = p.stdout
+    assert out.endswith(hdtest.pkg().BGZF_EOF) and len(out) < len(data) * 0.6
+    pos, i = 0, 0
+    while pos < len(out) - 28:
+        total = int.from_bytes(out[pos + 16:pos + 18], "little") + 1
+        member = out[pos:pos + total]
+        chunk = data[i * 0xff00:(i + 1) * 0xff00]
+        r, twin = hdtest.oracle_twin(chunk, 1, cap=65536 - 26)
+        assert r == 0 and member[18:-8] == twin, i
+        assert int.from_bytes(member[-8:-4], "little") == zlib.crc32(chunk) and \
+            int.from_bytes(member[-4:], "little") == len(chunk), i
+        pos += total
+        i += 1
+    assert i == 41 and pos == len(out) - 28
