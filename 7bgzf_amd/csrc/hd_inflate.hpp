@@ -325,10 +325,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			if (pos - flushed >= HD_PIECE)
 				flush_pieces();
 			const uint32_t d0 = B >> 5;
-			if (!(d0 + 5 <= dw_safe && pos + WIN_OUT_BUDGET + HD_MAX_MATCH <= cap))
+			if (!(d0 + 7 <= dw_safe && pos + WIN_OUT_BUDGET + HD_MAX_MATCH <= cap))
 				break;
 			// the stream bits come from an LDS copy of the pieces around d0 (every lane
-			// reads its own three dwords: no scalar gather)
+			// reads its own dwords: no scalar gather)
 			const uint32_t p0 = d0 >> 6;
 			if (p0 != lds_p0) {
 				if (p0 != lds_p0 + 1)
@@ -336,97 +336,136 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				L.comp[(((p0 + 1) & 3) << 6) + lane] = load_piece(p0 + 1);
 				lds_p0 = p0;
 			}
-			const uint32_t bl = (B & 31) + lane;          // 0..94
-			const uint32_t di = d0 + (bl >> 5);
-			const uint32_t lo = L.comp[di & 255], mid = L.comp[(di + 1) & 255], hi = L.comp[(di + 2) & 255];
-			const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
-			const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
-			// litlen
-			const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
-			const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
-			const uint32_t length = (e >> 16) + ((a >> len1) & ((1u << eb) - 1));
-			const uint32_t t1 = len1 + eb;                 // <= 9 + 5
-			const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
-			const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
-			const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
-			const uint32_t offset = (dd >> 16) + ((rest >> dlen) & ((1u << deb) - 1));
-			const bool is_len = kind == K_LEN;
-			const bool slow = kind == K_SLOW || (is_len && ((dd >> 8) & 3) == K_SLOW);
-			const uint32_t tokbits = is_len ? t1 + dlen + deb : len1;
-			const uint32_t outlen = kind == K_LIT ? 1u : is_len ? length : 0u;
+			// A window is 128 bits: every lane decodes the token that would start at bit
+			// B + lane ("lo") and the one at B + 64 + lane ("hi").  Twice the tokens per
+			// window halve the scalar glue per token, which is what bounds this kernel.
+			struct Spec {
+				uint32_t e, length, offset, outlen, walk;
+				bool is_len, is_lit;
+			};
+			auto spec = [&](uint32_t bl) -> Spec {                // bl = bit offset from dword d0
+				Spec r;
+				const uint32_t di = d0 + (bl >> 5);
+				const uint32_t lo = L.comp[di & 255], mid = L.comp[(di + 1) & 255], hi = L.comp[(di + 2) & 255];
+				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
+				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
+				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
+				const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
+				r.e = e;
+				r.length = (e >> 16) + ((a >> len1) & ((1u << eb) - 1));
+				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
+				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
+				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
+				const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
+				r.offset = (dd >> 16) + ((rest >> dlen) & ((1u << deb) - 1));
+				r.is_len = kind == K_LEN;
+				r.is_lit = kind == K_LIT;
+				const bool slow = kind == K_SLOW || (r.is_len && ((dd >> 8) & 3) == K_SLOW);
+				const uint32_t tokbits = r.is_len ? t1 + dlen + deb : len1;
+				r.outlen = r.is_lit ? 1u : r.is_len ? r.length : 0u;
+				// bit 6 = the walk stops in front of this token (long codeword, end of block; a
+				// zero-bit token cannot come out of a well-formed table, but it would not advance)
+				r.walk = tokbits | ((slow || kind == K_EOB || tokbits == 0) ? 64u : 0u);
+				return r;
+			};
+			const Spec s0 = spec((B & 31) + lane), s1 = spec((B & 31) + lane + 64);
 
 			// The real chain from bit 0 of the window.  This walk is the hottest scalar
 			// code of the kernel (the CU has one scalar ALU) and the compiler spends ~20
 			// instructions per token on it, so it is written out: 4 SALU + 2 branches
-			// + 1 v_readlane per token.  It stops in front of the first token the window
-			// cannot take (long codeword, end of block); that one goes to the scalar loop.
-			// (a zero-bit token cannot come out of a well-formed table; if it ever did, the walk would
-			// not advance, so it counts as a stop too and the fully checked scalar path decides)
-			const uint32_t walk = tokbits | ((slow || kind == K_EOB || tokbits == 0) ? 64u : 0u);
+			// + 1 v_readlane per token (the lane select of v_readlane and s_bitset1 take
+			// the low 6 bits, so the second half runs on b itself).  It stops in front of
+			// the first token the window cannot take; that one goes to the scalar loop.
+			// (A lane select written by the SALU needs no wait states before v_readlane,
+			// only one written by the VALU does.)
 			uint32_t b, wm;
-			uint64_t real;
-			// (a lane select written by the SALU needs no wait states before v_readlane,
-			// only one written by the VALU does)
+			uint64_t real0, real1;
 			asm volatile("s_mov_b32 %0, 0\n\t"
-				     "s_mov_b64 %1, 0\n"
-				     "Lhd_walk_%=:\n\t"
-				     "v_readlane_b32 %2, %3, %0\n\t"
-				     "s_bitcmp1_b32 %2, 6\n\t"
+				     "s_mov_b64 %1, 0\n\t"
+				     "s_mov_b64 %2, 0\n"
+				     "Lhd_walk0_%=:\n\t"
+				     "v_readlane_b32 %3, %4, %0\n\t"
+				     "s_bitcmp1_b32 %3, 6\n\t"
 				     "s_cbranch_scc1 Lhd_walk_done_%=\n\t"
 				     "s_bitset1_b64 %1, %0\n\t"
-				     "s_add_u32 %0, %0, %2\n\t"
+				     "s_add_u32 %0, %0, %3\n\t"
 				     "s_cmp_lt_u32 %0, 64\n\t"
-				     "s_cbranch_scc1 Lhd_walk_%=\n"
+				     "s_cbranch_scc1 Lhd_walk0_%=\n"
+				     "Lhd_walk1_%=:\n\t"
+				     "v_readlane_b32 %3, %5, %0\n\t"
+				     "s_bitcmp1_b32 %3, 6\n\t"
+				     "s_cbranch_scc1 Lhd_walk_done_%=\n\t"
+				     "s_bitset1_b64 %2, %0\n\t"
+				     "s_add_u32 %0, %0, %3\n\t"
+				     "s_cmp_lt_u32 %0, 128\n\t"
+				     "s_cbranch_scc1 Lhd_walk1_%=\n"
 				     "Lhd_walk_done_%=:"
-				     : "=&s"(b), "=&s"(real), "=&s"(wm)
-				     : "v"(walk)
+				     : "=&s"(b), "=&s"(real0), "=&s"(real1), "=&s"(wm)
+				     : "v"(s0.walk), "v"(s1.walk)
 				     : "scc");
-			// cut in front of the first token that would overrun the output budget
-			const uint32_t incl = wave_incl_scan(((real >> lane) & 1) ? outlen : 0u);
-			const uint64_t over = __ballot(((real >> lane) & 1) && incl > WIN_OUT_BUDGET);
-			if (over) {
-				b = (uint32_t)__ffsll((unsigned long long)over) - 1;
-				real &= (1ull << b) - 1;
+			// output positions; cut in front of the first token that would overrun the budget
+			const uint32_t incl0 = wave_incl_scan(((real0 >> lane) & 1) ? s0.outlen : 0u);
+			const uint32_t incl1 = wave_incl_scan(((real1 >> lane) & 1) ? s1.outlen : 0u) + readlane(incl0, 63);
+			const uint64_t over0 = __ballot(((real0 >> lane) & 1) && incl0 > WIN_OUT_BUDGET);
+			const uint64_t over1 = __ballot(((real1 >> lane) & 1) && incl1 > WIN_OUT_BUDGET);
+			if (over0 | over1) {
+				if (over0) {
+					b = (uint32_t)__ffsll((unsigned long long)over0) - 1;
+					real0 &= (1ull << b) - 1;
+					real1 = 0;
+				} else {
+					const uint32_t f = (uint32_t)__ffsll((unsigned long long)over1) - 1;
+					real1 &= (1ull << f) - 1;
+					b = 64 + f;
+				}
 			}
-			if (real == 0)
+			if (real0 == 0)
 				break;                                     // the token at B is not for a window: scalar loop
-			const uint32_t cum = readlane(incl, 63 - (uint32_t)__clzll((long long)real));
-			const bool mine = (real >> lane) & 1;
-			const uint32_t opos = pos + incl - outlen;     // valid where `mine`
-			if (mine && kind == K_LIT)
-				L.ring[opos & (INF_RING - 1)] = (uint8_t)(e >> 16);
+			const uint32_t cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
+						   : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
+			const bool mine0 = (real0 >> lane) & 1, mine1 = (real1 >> lane) & 1;
+			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid where mine
+			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
+			if (mine0 && s0.is_lit)
+				L.ring[opos0 & (INF_RING - 1)] = (uint8_t)(s0.e >> 16);
+			if (mine1 && s1.is_lit)
+				L.ring[opos1 & (INF_RING - 1)] = (uint8_t)(s1.e >> 16);
 			const uint32_t wend = pos + cum;
-			// per-lane verdicts for the matches, so that the scalar loop below only dispatches
-			const bool my_match = mine && is_len;
-			const uint32_t srcl = opos - offset;                         // wraps when offset > opos
-			if (__ballot(my_match && offset > opos)) {                   // decompress_template.h:724
+			// per-lane verdicts for the matches, so that the scalar loops below only dispatch
+			const bool match0 = mine0 && s0.is_len, match1 = mine1 && s1.is_len;
+			const uint32_t srcl0 = opos0 - s0.offset, srcl1 = opos1 - s1.offset;   // wrap when offset > opos
+			if (__ballot((match0 && s0.offset > opos0) || (match1 && s1.offset > opos1))) {   // decompress_template.h:724
 				st_out = HD_BAD_DATA;
 				result = 2;
 				break;
 			}
-			const bool in_ring = wend - srcl <= INF_RING - 64;
 			// "simple": source wholly in the ring and wholly in front of this window's output,
 			// at most 64 bytes.  Nothing in the window feeds them, so they go first, in a
 			// loop with no exec juggling (lanes past the length write to a dump slot behind
 			// the ring); whatever else there is follows in stream order.
-			const uint32_t opos_rel = incl - outlen;
-			const uint64_t simple = __ballot(my_match && in_ring && offset >= opos_rel + length && length <= 64);
-			uint64_t sm = simple;
-			while (sm) {
+			const uint64_t simple0 = __ballot(match0 && wend - srcl0 <= INF_RING - 64 &&
+							  s0.offset >= rel0 + s0.length && s0.length <= 64);
+			const uint64_t simple1 = __ballot(match1 && wend - srcl1 <= INF_RING - 64 &&
+							  s1.offset >= rel1 + s1.length && s1.length <= 64);
+			for (uint64_t sm = simple0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				sm &= sm - 1;
-				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
+				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
-			uint64_t mm = __ballot(my_match) & ~simple;
-			while (mm) {
-				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
-				mm &= mm - 1;
-				const uint32_t mlen = readlane(outlen, m), P = readlane(opos, m), srcp = readlane(srcl, m);
+			for (uint64_t sm = simple1; sm;) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
+				sm &= sm - 1;
+				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
+				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
+				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
+			}
+			auto copy_general = [&](uint32_t mlen, uint32_t P, uint32_t srcp) {
 				const uint32_t moff = P - srcp;
 				if (wend - srcp <= INF_RING - 64) {
-					// source still in the ring (the literals of the whole window are already in)
+					// source still in the ring (the literals and the simple matches of the whole
+					// window are already in)
 					if (moff >= mlen) {
 						for (uint32_t i = lane; i < mlen; i += 64)
 							L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + i) & (INF_RING - 1)];
@@ -446,6 +485,16 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					for (uint32_t i = lane; i < mlen; i += 64)
 						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
 				}
+			};
+			for (uint64_t mm = __ballot(match0) & ~simple0; mm;) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
+				mm &= mm - 1;
+				copy_general(readlane(s0.outlen, m), readlane(opos0, m), readlane(srcl0, m));
+			}
+			for (uint64_t mm = __ballot(match1) & ~simple1; mm;) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
+				mm &= mm - 1;
+				copy_general(readlane(s1.outlen, m), readlane(opos1, m), readlane(srcl1, m));
 			}
 			pos = wend;
 			B += b;
