@@ -11,8 +11,8 @@
 // One wavefront per block, persistent over a grid-stride loop so that every
 // workgroup owns one token slab in HBM:
 //   pass 1  parse (same 64-position step, prefix-scan greedy, optional one-lane
-//           lazy deferral), tokens -> slab (coalesced 4 B/lane), symbol
-//           histograms -> LDS (ds_add_u32)
+//           lazy deferral), tokens -> LDS queue -> slab (64 at a time, coalesced
+//           4 B/lane), symbol histograms -> LDS (ds_add_u32)
 //   build   litlen/offset/precode code lengths: rank sort by all lanes, then the
 //           two-queue merge, depth, overflow and RLE steps on lane 0
 //   pass 2  tokens read back 64 at a time, codes looked up in LDS, <= 48 bits

@@ -10,15 +10,21 @@
 // The parse is wave64-native (oracle/hd_deflate_twin.c is its serial twin and
 // must produce the same bytes):
 //   lanes stand on 64 consecutive positions S..S+63; each hashes its 4 bytes,
-//   reads the candidate from the LDS hash table, then publishes itself with
-//   ds_max_u32; candidates are verified against the LDS ring window; a ballot
-//   gives the match-start mask, a scalar loop takes matches left to right and
-//   extends each one cooperatively (64 bytes per ballot); literal / match codes
-//   are placed with a DPP prefix scan of their bit lengths and OR-ed into an
-//   LDS staging ring that is flushed to HBM as whole dwords.
+//   reads the candidate from the 16-bit LDS hash table, then publishes itself
+//   (conflicts inside a step are re-written until the largest position holds the
+//   slot); candidates are verified against the LDS ring window, 8 bytes per lane;
+//   the greedy choice of token starts is a DPP prefix scan over 8-state
+//   transition functions (two v_perm_b32 per composition); the rare matches whose
+//   8 bytes all agree are extended cooperatively, 64 bytes per ballot; the step's
+//   tokens are compacted into an LDS queue, and once 64 wait there one pass turns
+//   them into static-Huffman codes, places them with a DPP prefix scan of their
+//   bit lengths and ORs them into an LDS staging ring that leaves as 512-byte
+//   stores.
 //
 // HBM traffic per block: input read once (16 B/lane pieces), output written
-// once.  LDS per wave: ring 2^WIN_BITS + table 4*2^HASH_BITS + 512 B staging.
+// once.  LDS per wave: ring 2^WIN_BITS + table 2*2^HASH_BITS + 1 KiB staging +
+// 768 B token queue = 9.8 KiB at level 1: 8 of the 1280-byte units LDS is granted
+// in, 16 waves per CU.
 #pragma once
 #include "hd_device.hpp"
 
