@@ -8,9 +8,14 @@
 // behaviour and result codes follow libdeflate (oracle/hd_inflate.c lists the
 // rules with their file:line); the structure does not:
 //
-//   * the compressed stream is pulled in 256-byte coalesced pieces (one dword
-//     per lane); the bit buffer lives in SGPRs and is refilled with v_readlane,
-//     so the symbol loop never waits on memory;
+//   * tokens are decoded speculatively by the vector units: in a 128-bit window every
+//     lane decodes the tokens that would start at its two bit offsets, a short
+//     scalar walk (written out in ISA) follows the real chain, literals and most
+//     matches are then placed without any per-token scalar work;
+//   * around that, a fully checked scalar token loop takes what a window cannot
+//     (stream edges, long codewords, end of block): the compressed stream is pulled
+//     in 256-byte coalesced pieces (one dword per lane), the bit buffer lives in
+//     SGPRs and is refilled with v_readlane;
 //   * Huffman tables are built by all 64 lanes (ballot ranks per code length)
 //     into LDS: 2^9-entry litlen and 2^8-entry offset tables; longer codewords
 //     take a canonical bit-serial slow path instead of subtables;
