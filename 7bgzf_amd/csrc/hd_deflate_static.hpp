@@ -26,6 +26,7 @@
 // 768 B token queue = 9.8 KiB at level 1: 8 of the 1280-byte units LDS is granted
 // in, 16 waves per CU.
 #pragma once
+#include <type_traits>
 #include "hd_device.hpp"
 
 namespace hd {
@@ -280,25 +281,34 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	struct Fetched {
 		uint32_t v, vh, c;           // own bytes [p,p+4), [p+4,p+8); candidate position + 1 (0 = none)
 	};
-	auto fetch = [&](uint32_t S_) -> Fetched {
+	// INNER: every lane of the step has >= 9 bytes left and the block is shorter than
+	// 2^16 (all BGZF blocks; all but their last steps), so the end-of-block and the
+	// 16-bit wrap-around handling drop out at compile time
+	auto fetch = [&](auto inner_tag, uint32_t S_) -> Fetched {
+		constexpr bool INNER = decltype(inner_tag)::value;
 		Fetched f;
 		const uint32_t p = S_ + lane;
 		const uint32_t *w = &ring32[(p >> 2) & W4M];
 		const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
 		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
-		const bool can = p + HD_MIN_MATCH <= n;
+		const bool can = INNER || p + HD_MIN_MATCH <= n;
 		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
 		const uint16_t mine = (uint16_t)(p + 1);
 		const uint32_t e = table[h];
 		table[h] = mine;
-		// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
-		const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
-		f.c = (can && e && back) ? p + 1 - back : 0u;
+		if (INNER) {
+			f.c = e;                                         // position + 1 itself: nothing has wrapped
+		} else {
+			// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
+			const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
+			f.c = (can && e && back) ? p + 1 - back : 0u;
+		}
 		// settle publish conflicts inside this step (positions differ by < 64)
 		for (;;) {
 			const uint16_t now = table[h];
-			const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;   // mine > now (mod 2^16)
+			const bool again = INNER ? mine > now
+						 : can && (uint16_t)(mine - now) - 1u < 0x7fffu;   // mine > now (mod 2^16)
 			if (!__ballot(again))
 				break;
 			if (again)
@@ -362,27 +372,29 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	Probed q0 = { 0, 0, 0 };
 	if (use_static && n) {
 		fill_piece();
-		f0 = fetch(0);
+		f0 = fetch(std::false_type{}, 0);
 		q0 = probe(f0.c);
-		f1 = fetch(64);
+		f1 = fetch(std::false_type{}, 64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
-	for (uint32_t S = 0; S < n && use_static; S += 64) {
+	// one step; false = the static stream was abandoned
+	auto step = [&](auto inner_tag, uint32_t S) -> bool {
+		constexpr bool INNER = decltype(inner_tag)::value;
 		if (filled < n && filled < S + HD_LOOKAHEAD)
 			fill_piece();
 		const uint32_t lo = filled > W ? filled - W : 0;
-		const uint32_t lanes = n - S < 64 ? n - S : 64;
+		const uint32_t lanes = INNER ? 64u : (n - S < 64 ? n - S : 64);
 
 		// stage 2 of step k+1 and stage 1 of step k+2 go out first
 		const Fetched fc = f0;
 		const Probed qc = q0;
 		f0 = f1;
 		q0 = probe(f1.c);                  // harmless beyond n: every index is masked into the ring
-		f1 = fetch(S + 128);
+		f1 = fetch(inner_tag, S + 128);
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
 		const uint32_t p = S + lane;
-		const bool can = p + HD_MIN_MATCH <= n;
+		const bool can = INNER || p + HD_MIN_MATCH <= n;
 		const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
 		const bool had = can && fc.c != 0 && cp >= lo;
 		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
@@ -392,11 +404,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t x = cvh ^ cvh0;
 		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
 		const uint32_t room = n - p;                  // >= 4 where ok
-		uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
+		uint32_t mylen = INNER ? 4 + eqb : (4 + eqb < room ? 4 + eqb : room);
 
 		if (carry >= lanes) {                // the whole step lies inside the last match
 			carry -= lanes;
-			continue;
+			return true;
 		}
 
 		// ---- 4. greedy resolution as a wave prefix scan ---------------------
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// whose first 8 bytes all agree ("capped") are rare; when the scan
 		// takes one it is extended cooperatively and the scan is redone for
 		// the lanes behind it.
-		const bool capped = ok && eqb == 4 && room > 8;
+		const bool capped = ok && eqb == 4 && (INNER || room > 8);
 		const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;   // token length as the scan sees it
 		uint64_t starts;
 		{
@@ -465,8 +477,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t E = last + (readlane(ok ? mylen : 1u, last));
 		const bool is_start = (starts >> lane) & 1;
 		const bool is_match = is_start && ok;
-		const bool is_lit = is_start && !ok && lane < lanes;
-		carry = (lanes == 64 && E > 64) ? E - 64 : 0;   // tail step: matches are clipped to n
+		const bool is_lit = is_start && !ok && (INNER || lane < lanes);
+		carry = ((INNER || lanes == 64) && E > 64) ? E - 64 : 0;   // tail step: matches are clipped to n
 
 		// ---- 5. queue the step's tokens in position order -------------------
 		// token word: literal byte, or HD_TOKEN_MATCH | (len - 3) << 16 | (dist - 1).
@@ -483,8 +495,16 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		}
 		if (qtail - qhead >= 64 && !emit_tokens(64)) {
 			use_static = false;
-			break;
+			return false;
 		}
+		return true;
+	};
+	// fetch runs two steps ahead: a step is INNER when the lanes of step S + 128 still have 9 bytes
+	const bool small = n < 65536;
+	for (uint32_t S = 0; S < n && use_static; S += 64) {
+		const bool ok_step = (small && S + 192 + 8 <= n) ? step(std::true_type{}, S) : step(std::false_type{}, S);
+		if (!ok_step)
+			break;
 	}
 	if (use_static && qtail != qhead && !emit_tokens(qtail - qhead))
 		use_static = false;
