@@ -179,7 +179,7 @@ int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
 	if (level <= 1) {
 		hd::DeflateArgs b = a;
 		b.level = level;
-		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS>), dim3(a.nblocks), dim3(64), 0, st, b);
+		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false>), dim3(a.nblocks), dim3(64), 0, st, b);
 	} else {
 		int r = hd::launch_deflate_dynamic(a, level, st);
 		if (r)
@@ -252,6 +252,9 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	a.status = (int32_t *)status;
 	a.ct = g.d_ct;
 	a.scratch = nullptr;
+	a.first = 0;
+	a.count = 0;
+	a.skip_small = 0;
 	if (level >= 2) {
 		// token slabs for the dynamic levels: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);

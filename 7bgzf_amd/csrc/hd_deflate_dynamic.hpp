@@ -37,11 +37,22 @@ inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 	return nblocks < slots ? nblocks : slots;
 }
 
+// level 2: blocks per parse + emit launch pair (their tokens wait in HBM in between: 255 KiB each)
+constexpr uint32_t SPLIT_SUB_BATCH = 16384;
+
+inline uint64_t fused_scratch_bytes(uint32_t nblocks, int level)
+{
+	return (uint64_t)dynamic_grid(nblocks, level) * DYN_SLAB_TOKENS * 4;
+}
+
 inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t, int level)
 {
 	if (level < 2)
 		return 0;
-	return (uint64_t)dynamic_grid(nblocks, level) * DYN_SLAB_TOKENS * 4;
+	uint64_t bytes = fused_scratch_bytes(nblocks, level);
+	if (level == 2)
+		bytes += (uint64_t)(nblocks < SPLIT_SUB_BATCH ? nblocks : SPLIT_SUB_BATCH) * SPLIT_BLOCK_BYTES;
+	return bytes;
 }
 
 struct HuffScratch {
@@ -201,7 +212,10 @@ struct DynBuild {
 
 __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
 
-template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY>
+// EMIT = 1: emit-only mode, the second half of the level-2 split path: tokens, histograms and
+// CRC of blocks [a.first, a.first + a.count) are in the scratch (written by k_deflate_static<.., true>),
+// this kernel builds the codes and writes the members exactly as the fused mode would have.
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT>
 __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -211,28 +225,31 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	constexpr uint32_t FLUSH_DW = 128;
 
 	__shared__ __attribute__((aligned(16))) union {
-		uint32_t ring[W / 4 + 4];
+		uint32_t ring[EMIT ? 4 : W / 4 + 4];
 		DynBuild build;
 	} U;
-	static_assert(sizeof(DynBuild) <= sizeof(uint32_t) * (W / 4 + 4), "code-construction scratch must fit under the ring");
+	// (the union is as large as the larger of the two: at level 2 the 4 KiB ring sits inside the scratch)
 	uint32_t *const ring32 = U.ring;
 	DynBuild &Bd = U.build;
-	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
+	__shared__ __attribute__((aligned(16))) uint16_t table[EMIT ? 8 : HS + 8];
 	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
 	__shared__ DynLds L;
 	// token queue: < 64 waiting + <= 64 of one step.  (No dump slots for the lanes without a token as in
 	// the level-1 kernel: LDS is granted in 1280-byte units and levels 2-4 must stay within 12 of them
 	// for 10 waves per CU.)
 	constexpr uint32_t TOKQ = 128;
-	__shared__ uint32_t tokq[TOKQ];
+	__shared__ uint32_t tokq[EMIT ? 1 : TOKQ];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 	const uint32_t lane = threadIdx.x;
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
 
-	for (uint32_t b = blockIdx.x; b < a.nblocks; b += gridDim.x) {
+	const uint32_t b_end = EMIT ? (a.first + a.count < a.nblocks ? a.first + a.count : a.nblocks) : a.nblocks;
+	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
+		if (EMIT ? n > SPLIT_MAX_BLOCK : (a.skip_small && n <= SPLIT_MAX_BLOCK))
+			continue;                            // the other path's block
 		const bool aligned = (((uintptr_t)src) & 15) == 0;
 		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 
@@ -251,21 +268,23 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const uint64_t limit_bits = 8ull * limit;
 
 		// ---- init LDS ---------------------------------------------------
-		for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
-			((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+		if (!EMIT) {
+			for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
+				((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+			for (uint32_t i = lane; i < 288; i += 64)
+				L.lf[i] = 0;
+			if (lane < 32)
+				L.df[lane] = 0;
+		}
 		for (uint32_t i = lane; i < STG; i += 64)
 			stage[i] = 0;
-		for (uint32_t i = lane; i < 288; i += 64)
-			L.lf[i] = 0;
-		if (lane < 32)
-			L.df[lane] = 0;
 		if (lane < 4 && hdr)
 			stage[lane] = frame_hdr_word(a.frame, lane);
 
 		CrcLanes crc;
 		crc.init(lane, n);
 		uint32_t filled = 0;
-		uint4 pre = load_slot(src, n, 0, lane, aligned);
+		uint4 pre = EMIT ? make_uint4(0, 0, 0, 0) : load_slot(src, n, 0, lane, aligned);
 		uint32_t bitpos = 8 * hdr, flushed = 0;
 		const uint32_t paybase = 8 * hdr;
 		uint32_t ntok = 0;                   // tokens of the open DEFLATE block: in the slab + still queued
@@ -534,6 +553,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			ntok_slab += count;
 		};
 
+		uint32_t crcv;
+		if constexpr (!EMIT) {
 		// ---- pass 1: the parse ------------------------------------------------
 		Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
 		Probed q0 = { 0, 0, 0 };
@@ -678,7 +699,26 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				pre = load_slot(src, n, piece + 1, lane, aligned);
 			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
 		}
-		const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
+		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
+		} else {
+			// the parse has been done: one flush per recorded DEFLATE block
+			const uint32_t bi = b - a.first;
+			const SplitMeta *m = split_meta(a.scratch, bi);
+			const uint32_t ndb = m->ndb;
+			crcv = m->crc;
+			uint32_t t0 = 0;
+			for (uint32_t k = 0; k < ndb && alive; k++) {
+				const uint32_t *h = split_hist(a.scratch, bi, k);
+				for (uint32_t i = lane; i < 288; i += 64)
+					L.lf[i] = h[i];
+				if (lane < 32)
+					L.df[lane] = h[288 + lane];
+				tok = split_slab(a.scratch, bi) + t0;
+				ntok_slab = m->ntok[k];
+				alive = flush_block(k + 1 == ndb);
+				t0 += m->ntok[k];
+			}
+		}
 
 		if (!alive) {
 			write_stored_member(a, b, src, n, crcv, lane);
@@ -717,14 +757,31 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t grid = dynamic_grid(a.nblocks, level);
-	if (level <= 4)
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0>), dim3(grid), dim3(64),
+	if (level == 2) {
+		// blocks <= 64 KiB: parse at level-1 occupancy, tokens + histograms through HBM, then the
+		// emit-only kernel (14 waves per CU); larger blocks: the fused kernel.  Same bytes either way.
+		DeflateArgs s = a;
+		s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
+		for (uint32_t first = 0; first < a.nblocks; first += SPLIT_SUB_BATCH) {
+			s.first = first;
+			s.count = a.nblocks - first < SPLIT_SUB_BATCH ? a.nblocks - first : SPLIT_SUB_BATCH;
+			hipLaunchKernelGGL((k_deflate_static<HD_L2_WIN_BITS, HD_L2_HASH_BITS, true>), dim3(s.count), dim3(64), 0, st, s);
+			const uint32_t eg = s.count < 256u * 14u ? s.count : 256u * 14u;
+			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64),
+					   0, st, s);
+		}
+		DeflateArgs f = a;
+		f.skip_small = 1;
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 0>), dim3(grid), dim3(64),
+				   0, st, f);
+	} else if (level <= 4)
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, 0>), dim3(grid), dim3(64),
 				   0, st, a);
 	else if (level <= 6)
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1>), dim3(grid), dim3(64),
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, 0>), dim3(grid), dim3(64),
 				   0, st, a);
 	else
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1>), dim3(grid), dim3(64),
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, 0>), dim3(grid), dim3(64),
 				   0, st, a);
 	return 0;
 }

@@ -46,6 +46,9 @@ struct DeflateArgs {
 	int32_t *status;
 	const CrcTables *ct;
 	uint8_t *scratch;               // token slabs of the dynamic levels
+	uint32_t first;                 // split path: first block of this sub-batch (grid index 0)
+	uint32_t count;                 // split path: blocks in this sub-batch
+	uint32_t skip_small;            // fused dynamic kernel: leave blocks <= SPLIT_MAX_BLOCK to the split path
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -170,7 +173,35 @@ __device__ __forceinline__ uint4 load_slot(const uint8_t *src, uint32_t n, uint3
 	return make_uint4(w0, w1, w2, w3);
 }
 
-template <int WIN_BITS, int HASH_BITS>
+// ---- level 2, blocks <= 64 KiB: parse kernel -> HBM -> emit kernel ------------
+// Per block of a sub-batch the scratch holds the member's tokens (at most one per
+// input byte), the symbol histograms of its DEFLATE blocks (a block closes at the
+// first step boundary with >= HD_DYN_BLOCK_TOKENS tokens: at most 3 per member)
+// and a small record.  The parse is this file's kernel with TOK = true: the same
+// steps, but the token queue drains into the slab and the histograms instead of
+// into static-Huffman bits.  hd_deflate_dynamic.hpp's kernel in its emit-only mode
+// turns that into the bytes the fused kernel would have written.
+constexpr uint32_t SPLIT_MAX_BLOCK = 65536;
+constexpr uint32_t SPLIT_SLAB_TOK = SPLIT_MAX_BLOCK + 64;
+constexpr uint32_t SPLIT_MAX_DB = 4;
+struct SplitMeta {
+	uint32_t ndb, crc, ntok[SPLIT_MAX_DB], pad[2];
+};
+constexpr uint64_t SPLIT_BLOCK_BYTES = (uint64_t)SPLIT_SLAB_TOK * 4 + sizeof(SplitMeta) + SPLIT_MAX_DB * 320 * 4;
+__device__ __forceinline__ uint32_t *split_slab(uint8_t *scratch, uint32_t i)
+{
+	return (uint32_t *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES);
+}
+__device__ __forceinline__ SplitMeta *split_meta(uint8_t *scratch, uint32_t i)
+{
+	return (SplitMeta *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES + (uint64_t)SPLIT_SLAB_TOK * 4);
+}
+__device__ __forceinline__ uint32_t *split_hist(uint8_t *scratch, uint32_t i, uint32_t db)
+{
+	return (uint32_t *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES + (uint64_t)SPLIT_SLAB_TOK * 4 + sizeof(SplitMeta)) + db * 320;
+}
+
+template <int WIN_BITS, int HASH_BITS, bool TOK>
 __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -185,17 +216,21 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
 	// (position + 1) mod 2^16, 0 = empty; slot HS is a dump for lanes with nothing to publish
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
-	__shared__ __attribute__((aligned(16))) uint32_t stage[STG];
+	// TOK: no bits are made here, the staging ring's place is taken by the symbol histograms
+	// (litlen [0,288), offset [288,320)), and the queue has no dump slots (8 LDS units = 16 waves)
+	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? 320 : STG];
 	// tokens waiting for the emit pass; [TOKQ, TOKQ + 64) = dump slots of lanes without one
-	__shared__ uint32_t tokbuf[TOKQ + 64];
+	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 64];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 
 	const uint32_t lane = threadIdx.x;
-	const uint32_t b = blockIdx.x;
+	const uint32_t b = a.first + blockIdx.x;
 	if (b >= a.nblocks)
 		return;
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
+	if (TOK && n > SPLIT_MAX_BLOCK)
+		return;                              // the fused kernel takes the large blocks
 	const bool aligned = (((uintptr_t)src) & 15) == 0;
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 	const CrcTables *ct = a.ct;
@@ -211,17 +246,20 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t limit = stored - 1;
 	const bool flush = a.frame == HD_FRAME_RAW_FLUSH;
 	const uint32_t sfx = frame_sfx_bytes(a.frame);
-	bool use_static = a.level >= 1 && cap >= hdr + trl + sfx + 2;   // level 0: stored only
-	if (use_static && cap - hdr - trl - sfx < limit)
+	bool use_static = TOK || (a.level >= 1 && cap >= hdr + trl + sfx + 2);   // level 0: stored only
+	if (!TOK && use_static && cap - hdr - trl - sfx < limit)
 		limit = cap - hdr - trl - sfx;
 
 	// ---- init LDS -------------------------------------------------------
 	for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
 		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
-	for (uint32_t i = lane; i < STG; i += 64)
+	for (uint32_t i = lane; i < (TOK ? 320u : STG); i += 64)
 		stage[i] = 0;
-	if (lane < 4 && hdr)
+	if (!TOK && lane < 4 && hdr)
 		stage[lane] = frame_hdr_word(a.frame, lane);
+	// TOK: where this block's tokens, histograms and record go
+	uint32_t *const slab = TOK ? split_slab(a.scratch, blockIdx.x) : nullptr;
+	uint32_t ntok_slab = 0, db_start = 0, ndb = 0;       // tokens stored; first token / index of the open DEFLATE block
 
 	Fn8Ident fid;
 	fid.init(lane);
@@ -335,6 +373,23 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	auto emit_tokens = [&](uint32_t count) -> bool {
 		const uint32_t t = tokbuf[(qhead + lane) & (TOKQ - 1)];
 		qhead += count;
+		if (TOK) {
+			// queued tokens -> slab (one coalesced 4 B/lane store) + symbol histograms
+			if (lane < count) {
+				slab[ntok_slab + lane] = t;
+				if (t & HD_TOKEN_MATCH) {
+					uint32_t ls, leb, lev, ds, deb, dev;
+					len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
+					off_slot((t & 0xffff) + 1, ds, deb, dev);
+					atomicAdd(&stage[257 + ls], 1u);
+					atomicAdd(&stage[288 + ds], 1u);
+				} else {
+					atomicAdd(&stage[t & 0xff], 1u);
+				}
+			}
+			ntok_slab += count;
+			return true;
+		}
 		const bool is_match = (t & HD_TOKEN_MATCH) != 0;
 		uint32_t code, nbits;
 		{
@@ -366,7 +421,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	};
 
 	// BFINAL = 1 (0 in flush form), BTYPE = 01
-	put(flush ? 2u : 3u, lane == 0 ? 3u : 0u, 3u, 3u);
+	if (!TOK)
+		put(flush ? 2u : 3u, lane == 0 ? 3u : 0u, 3u, 3u);
 
 	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
 	Probed q0 = { 0, 0, 0 };
@@ -489,8 +545,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const bool is_tok = is_match || is_lit;
 			const uint64_t tm = __ballot(is_tok);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
-			tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + lane] =
-				is_match ? (HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1)) : (cv0 & 0xff);
+			const uint32_t tw = is_match ? (HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1)) : (cv0 & 0xff);
+			if (TOK) {
+				if (is_tok)
+					tokbuf[(qtail + rank) & (TOKQ - 1)] = tw;
+			} else {
+				tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + lane] = tw;
+			}
 			qtail += (uint32_t)__popcll(tm);
 		}
 		if (qtail - qhead >= 64 && !emit_tokens(64)) {
@@ -501,10 +562,28 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	};
 	// fetch runs two steps ahead: a step is INNER when the lanes of step S + 128 still have 9 bytes
 	const bool small = n < 65536;
+	// TOK: the open DEFLATE block's histograms leave for HBM and start again from zero
+	auto close_deflate_block = [&]() {
+		uint32_t *h = split_hist(a.scratch, blockIdx.x, ndb);
+		for (uint32_t i = lane; i < 320; i += 64) {
+			h[i] = stage[i];
+			stage[i] = 0;
+		}
+		if (lane == 0)
+			split_meta(a.scratch, blockIdx.x)->ntok[ndb] = ntok_slab - db_start;
+		db_start = ntok_slab;
+		ndb++;
+	};
 	for (uint32_t S = 0; S < n && use_static; S += 64) {
 		const bool ok_step = (small && S + 192 + 8 <= n) ? step(std::true_type{}, S) : step(std::false_type{}, S);
 		if (!ok_step)
 			break;
+		// a DEFLATE block closes at the first step boundary with >= 32768 tokens (as the fused kernel)
+		if (TOK && ntok_slab + (qtail - qhead) - db_start >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
+			if (qtail != qhead)
+				emit_tokens(qtail - qhead);
+			close_deflate_block();
+		}
 	}
 	if (use_static && qtail != qhead && !emit_tokens(qtail - qhead))
 		use_static = false;
@@ -520,6 +599,15 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	}
 	const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 
+	if (TOK) {
+		close_deflate_block();
+		if (lane == 0) {
+			SplitMeta *m = split_meta(a.scratch, blockIdx.x);
+			m->ndb = ndb;
+			m->crc = crcv;
+		}
+		return;
+	}
 	if (use_static && (uint64_t)(bitpos - paybase) + 7 > 8ull * limit)
 		use_static = false;
 	if (!use_static) {

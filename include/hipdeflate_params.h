@@ -13,7 +13,8 @@
  * reference, where a level selects matchfinder + parser + Huffman mode):
  *   0      stored blocks only          (store_deflate, lib/zlibutil.c:302)
  *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like")
- *   2..4   greedy parse, dynamic Huffman
+ *   2      greedy parse, dynamic Huffman, level-1 window (fast on DNA-like data)
+ *   3..4   greedy parse, dynamic Huffman, 8 KiB window
  *   5..6   lazy parse (one-lane lookahead), dynamic Huffman (config 5,
  *          "level-6-like")
  *   7..9   the same with a larger window and hash table
@@ -31,11 +32,19 @@
 #define HD_L1_WIN_BITS     12          /* 4 KiB LDS ring window (occupancy)  */
 #define HD_L1_HASH_BITS    11          /* 2048 x u32 = 8 KiB LDS            */
 
-/* levels 2..4: greedy parse, dynamic Huffman; tokens buffered in a per-wave
- * scratch slab in HBM between the parse and the emit pass */
-#define HD_L2_WIN_BITS     13          /* 8 KiB ring                         */
+/* level 2: greedy parse, dynamic Huffman, in the level-1 geometry (4 KiB ring, 2^11 table).
+ * On DNA-like data the window size hardly matters (same ratio as level 3), and the small LDS
+ * footprint lets the parse run at level-1 occupancy: blocks <= 64 KiB go through a parse kernel
+ * and an emit kernel (hd_deflate_static.hpp / hd_deflate_dynamic.hpp), larger ones through the
+ * fused kernel; the bytes are the same either way */
+#define HD_L2_WIN_BITS     12
 #define HD_L2_HASH_BITS    11
 #define HD_L2_MIN_LEN      4
+/* levels 3..4: the same with an 8 KiB ring; tokens buffered in a per-wave scratch slab in HBM
+ * between the parse and the emit pass */
+#define HD_L3_WIN_BITS     13
+#define HD_L3_HASH_BITS    11
+#define HD_L3_MIN_LEN      4
 /* levels 5..6: one-lane-lookahead lazy parse, dynamic Huffman, in the level-2 window
  * with twice the table: 19 KiB of LDS, 8 waves per CU */
 #define HD_L5_WIN_BITS     13

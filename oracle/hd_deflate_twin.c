@@ -639,9 +639,12 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return write_stored(dest, destLen, source, sourceLen, flush);   /* level 0 = the stored branch */
 	if (level == 1)
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
-	if (level <= 4)
+	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
 				       HD_L2_MIN_LEN, 0, flush);
+	if (level <= 4)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
+				       HD_L3_MIN_LEN, 0, flush);
 	if (level <= 6)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
 				       HD_L5_MIN_LEN, 1, flush);

@@ -143,19 +143,22 @@ def test_kernel_resource_budgets():
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/\w+\])?: (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
-    dyn = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k}
+    emit = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k and k.endswith("ELi1EEEvNS_11DeflateArgsE")}
+    dyn = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k and k not in emit}
     sta = {k: v for k, v in kernels.items() if "k_deflate_static" in k}
     inf = {k: v for k, v in kernels.items() if "k_inflate" in k}
-    assert len(dyn) == 3 and len(sta) == 1 and len(inf) == 1, list(kernels)
+    assert len(dyn) == 4 and len(emit) == 1 and len(sta) == 2 and len(inf) == 1, list(kernels)
     for k, v in kernels.items():
         assert v["ScratchSize"] == 0, (k, v)
     for k, v in dyn.items():
         assert v["VGPRs"] <= 168, (k, v)
         # LDS is granted in 1280-byte units (measured: 10 waves of 15584 B do not fit a CU, of 15328 B do)
         units = -(-v["LDS Size"] // 1280)
-        want = 12 if "Li13ELi11E" in k else 16 if "Li13ELi12E" in k else 28
+        want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else 16 if "Li13ELi12E" in k else 28
         assert units <= want, (k, v)                 # 10 / 8 / 4 waves per CU: dynamic_grid()
-    (v,) = sta.values()
-    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 10240, v       # 16 waves per CU
+    (v,) = emit.values()
+    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 9 * 1280, v    # 14 waves per CU: launch_deflate_dynamic()
+    for v in sta.values():                                       # level 1 and the level-2 parse
+        assert v["VGPRs"] <= 128 and v["LDS Size"] <= 10240, v   # 16 waves per CU
     (v,) = inf.values()
     assert v["VGPRs"] <= 96 and v["LDS Size"] <= 7424, v         # 20+ waves per CU

@@ -41,7 +41,7 @@ def test_selftest(pkg):
 # ---- encode ----------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("level", [0, 1, 3, 6, 9])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 6, 9])
 def test_encode_matches_twin_small_corpus(pkg, level):
     corpus = hdtest.corpus_small()
     names = list(corpus)
@@ -63,7 +63,7 @@ def test_encode_matches_twin_small_corpus(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(data), k
 
 
-@pytest.mark.parametrize("level", [0, 1, 3, 6])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 6])
 def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
     """HD_FRAME_RAW_FLUSH: kernel bytes == twin bytes; chunks concatenate; and through the
     per-block entry point hip_deflate_flush (what 7dictzip/7razf would call)."""
@@ -94,7 +94,7 @@ def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
         assert r != 0, k
 
 
-@pytest.mark.parametrize("level", [0, 1, 3, 6])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 6])
 def test_encode_zlib_and_gzip_frames(pkg, level):
     """HD_FRAME_ZLIB / HD_FRAME_GZIP: member == the oracle's wrapper (pinned against the reference's
     zlibutil_buffer_code bytes) around the twin's payload; Adler-32 and CRC-32 come from the device."""
@@ -136,7 +136,7 @@ def test_encode_zlib_and_gzip_frames(pkg, level):
         assert zl.hex() == g["rfc1950"]["bytes"] and gz.hex() == g["rfc1952"]["bytes"]
 
 
-@pytest.mark.parametrize("level,frame,block", [(1, "bgzf", 0xff00), (3, "bgzf", 0xff00), (6, "migz", 1 << 16),
+@pytest.mark.parametrize("level,frame,block", [(1, "bgzf", 0xff00), (2, "bgzf", 0xff00), (3, "bgzf", 0xff00), (6, "migz", 1 << 16),
                                                (1, "raw_flush", 4096)])
 def test_streaming_pipe_matches_batch_api(pkg, level, frame, block):
     """hipdeflate_pipe_*: several batches in flight on their own streams (the dynamic levels share the
@@ -155,7 +155,7 @@ def test_streaming_pipe_matches_batch_api(pkg, level, frame, block):
     assert pkg.pipe_compress(b"", level, fr, block, 4, 2) == b""
 
 
-@pytest.mark.parametrize("level", [1, 3, 6, 9])
+@pytest.mark.parametrize("level", [1, 2, 3, 6, 9])
 def test_encode_fuzz_blocks_match_twin(pkg, level):
     """160 seeded structured-random blocks per level (hdtest.corpus_fuzz), unaligned starts included:
     kernel bytes == twin bytes, and zlib inflates them back."""
@@ -175,7 +175,7 @@ def test_encode_fuzz_blocks_match_twin(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(d), i
 
 
-@pytest.mark.parametrize("level", [1, 3, 6])
+@pytest.mark.parametrize("level", [1, 2, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
     member holds several DEFLATE blocks (one per 32768 tokens), positions exceed 16 bits
