@@ -221,8 +221,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
 	constexpr uint32_t HS = 1u << HASH_BITS;
-	constexpr uint32_t STG = 256;
-	constexpr uint32_t FLUSH_DW = 128;
+	// staging ring (dwords) and flush granule.  An emit call adds at most 64 dwords (<= 32 bits per lane)
+	// to fewer than FLUSH_DW pending ones, so twice the granule is enough; the emit-only kernel takes the
+	// small ring: 8 LDS units instead of 9, 16 waves per CU instead of 14
+	constexpr uint32_t STG = EMIT ? 128 : 256;
+	constexpr uint32_t FLUSH_DW = STG / 2;
 
 	__shared__ __attribute__((aligned(16))) union {
 		uint32_t ring[EMIT ? 4 : W / 4 + 4];
@@ -300,10 +303,17 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		};
 		auto flush_ready = [&]() {
 			if ((bitpos >> 5) - flushed >= FLUSH_DW) {
-				const uint32_t i = (flushed & (STG - 1)) + 2 * lane;
-				const uint2 v = *(const uint2 *)&stage[i];
-				*(uint2 *)&stage[i] = make_uint2(0, 0);
-				*(uint2 *)&dst32[flushed + 2 * lane] = v;
+				if (FLUSH_DW == 128) {
+					const uint32_t i = (flushed & (STG - 1)) + 2 * lane;   // flushed is a multiple of FLUSH_DW
+					const uint2 v = *(const uint2 *)&stage[i];
+					*(uint2 *)&stage[i] = make_uint2(0, 0);
+					*(uint2 *)&dst32[flushed + 2 * lane] = v;
+				} else {
+					const uint32_t i = (flushed & (STG - 1)) + lane;
+					const uint32_t v = stage[i];
+					stage[i] = 0;
+					dst32[flushed + lane] = v;
+				}
 				flushed += FLUSH_DW;
 			}
 		};
@@ -759,14 +769,14 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 	const uint32_t grid = dynamic_grid(a.nblocks, level);
 	if (level == 2) {
 		// blocks <= 64 KiB: parse at level-1 occupancy, tokens + histograms through HBM, then the
-		// emit-only kernel (14 waves per CU); larger blocks: the fused kernel.  Same bytes either way.
+		// emit-only kernel (16 waves per CU); larger blocks: the fused kernel.  Same bytes either way.
 		DeflateArgs s = a;
 		s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
 		for (uint32_t first = 0; first < a.nblocks; first += SPLIT_SUB_BATCH) {
 			s.first = first;
 			s.count = a.nblocks - first < SPLIT_SUB_BATCH ? a.nblocks - first : SPLIT_SUB_BATCH;
 			hipLaunchKernelGGL((k_deflate_static<HD_L2_WIN_BITS, HD_L2_HASH_BITS, true>), dim3(s.count), dim3(64), 0, st, s);
-			const uint32_t eg = s.count < 256u * 14u ? s.count : 256u * 14u;
+			const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64),
 					   0, st, s);
 		}
