@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dec -- python3 b
 grep '^{' $OUT/bench_kt_dec.log > $OUT/bench_line_dec.json || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l6 -- python3 bench.py --steps 2 --warmup 1 --level 6 --no-cpu > $OUT/bench_kt_l6.log 2>&1
 grep '^{' $OUT/bench_kt_l6.log > $OUT/bench_line_l6.json || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l2 -- python3 bench.py --steps 2 --warmup 1 --level 2 --no-cpu > $OUT/bench_kt_l2.log 2>&1
+grep '^{' $OUT/bench_kt_l2.log > $OUT/bench_line_l2.json || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l3 -- python3 bench.py --steps 2 --warmup 1 --level 3 --no-cpu > $OUT/bench_kt_l3.log 2>&1
 grep '^{' $OUT/bench_kt_l3.log > $OUT/bench_line_l3.json || true
 python3 - $OUT <<'PY'
