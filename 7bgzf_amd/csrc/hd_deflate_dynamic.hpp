@@ -49,10 +49,8 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t, int level)
 {
 	if (level < 2)
 		return 0;
-	uint64_t bytes = fused_scratch_bytes(nblocks, level);
-	if (level == 2)
-		bytes += (uint64_t)(nblocks < SPLIT_SUB_BATCH ? nblocks : SPLIT_SUB_BATCH) * SPLIT_BLOCK_BYTES;
-	return bytes;
+	return fused_scratch_bytes(nblocks, level) +
+	       (uint64_t)(nblocks < SPLIT_SUB_BATCH ? nblocks : SPLIT_SUB_BATCH) * SPLIT_BLOCK_BYTES;
 }
 
 struct HuffScratch {
@@ -764,35 +762,37 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	}
 }
 
+// Blocks <= 64 KiB: parse kernel (the level-1 kernel with this level's parse parameters, at the
+// occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
+// then the one emit-only kernel (16 waves per CU).  Larger blocks: the fused kernel.  Same bytes.
+template <int W, int H, int MINLEN, int LAZY>
+inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
+{
+	DeflateArgs s = a;
+	s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
+	for (uint32_t first = 0; first < a.nblocks; first += SPLIT_SUB_BATCH) {
+		s.first = first;
+		s.count = a.nblocks - first < SPLIT_SUB_BATCH ? a.nblocks - first : SPLIT_SUB_BATCH;
+		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY>), dim3(s.count), dim3(64), 0, st, s);
+		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
+		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
+				   st, s);
+	}
+	DeflateArgs f = a;
+	f.skip_small = 1;
+	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
+}
+
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
-	const uint32_t grid = dynamic_grid(a.nblocks, level);
-	if (level == 2) {
-		// blocks <= 64 KiB: parse at level-1 occupancy, tokens + histograms through HBM, then the
-		// emit-only kernel (16 waves per CU); larger blocks: the fused kernel.  Same bytes either way.
-		DeflateArgs s = a;
-		s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
-		for (uint32_t first = 0; first < a.nblocks; first += SPLIT_SUB_BATCH) {
-			s.first = first;
-			s.count = a.nblocks - first < SPLIT_SUB_BATCH ? a.nblocks - first : SPLIT_SUB_BATCH;
-			hipLaunchKernelGGL((k_deflate_static<HD_L2_WIN_BITS, HD_L2_HASH_BITS, true>), dim3(s.count), dim3(64), 0, st, s);
-			const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
-			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64),
-					   0, st, s);
-		}
-		DeflateArgs f = a;
-		f.skip_small = 1;
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 0>), dim3(grid), dim3(64),
-				   0, st, f);
-	} else if (level <= 4)
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, 0>), dim3(grid), dim3(64),
-				   0, st, a);
+	if (level == 2)
+		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0>(a, level, st);
+	else if (level <= 4)
+		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0>(a, level, st);
 	else if (level <= 6)
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, 0>), dim3(grid), dim3(64),
-				   0, st, a);
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1>(a, level, st);
 	else
-		hipLaunchKernelGGL((k_deflate_dynamic<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, 0>), dim3(grid), dim3(64),
-				   0, st, a);
+		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1>(a, level, st);
 	return 0;
 }
 

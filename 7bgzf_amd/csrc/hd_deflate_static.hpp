@@ -201,7 +201,8 @@ __device__ __forceinline__ uint32_t *split_hist(uint8_t *scratch, uint32_t i, ui
 	return (uint32_t *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES + (uint64_t)SPLIT_SLAB_TOK * 4 + sizeof(SplitMeta)) + db * 320;
 }
 
-template <int WIN_BITS, int HASH_BITS, bool TOK>
+// MINLEN / LAZY: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
+template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0>
 __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -455,12 +456,19 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const bool had = can && fc.c != 0 && cp >= lo;
 		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
 		const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
-		const bool ok = had && cv == cv0;
-		const uint32_t dist = ok ? p - cp : 1u;
 		const uint32_t x = cvh ^ cvh0;
 		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
 		const uint32_t room = n - p;                  // >= 4 where ok
 		uint32_t mylen = INNER ? 4 + eqb : (4 + eqb < room ? 4 + eqb : room);
+		bool ok = had && cv == cv0 && (MINLEN <= HD_MIN_MATCH || mylen >= (uint32_t)MINLEN);
+		if (LAZY) {
+			// a candidate steps aside when its right neighbour's 8-byte length is longer
+			const uint32_t l8 = ok ? (mylen < 8 ? mylen : 8u) : 0u;
+			const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l8, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+			const bool defer = ok && lane + 1 < lanes && nx > l8;
+			ok = ok && !defer;
+		}
+		const uint32_t dist = ok ? p - cp : 1u;
 
 		if (carry >= lanes) {                // the whole step lies inside the last match
 			carry -= lanes;
