@@ -255,10 +255,11 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	a.first = 0;
 	a.count = 0;
 	a.skip_small = 0;
+	a.split_max = hd::split_max_block(out_stride, out_cap);
 	if (level >= 2) {
 		// token slabs for the dynamic levels: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);
-		const uint64_t need = hd::dynamic_scratch_bytes(nblocks, 0, level);
+		const uint64_t need = hd::dynamic_scratch_bytes(nblocks, a.split_max, level);
 		if (g.d_tok.cap < need) {
 			// a re-allocation must not pull the rug from under launches in flight
 			HD_CHECK(hipDeviceSynchronize());

@@ -37,20 +37,47 @@ inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 	return nblocks < slots ? nblocks : slots;
 }
 
-// level 2: blocks per parse + emit launch pair (their tokens wait in HBM in between: 255 KiB per block, 8.2 GiB of scratch; measured on 16 GiB: 16384 -> 148, 32768 -> 154, 131072 -> 158 GB/s)
-constexpr uint32_t SPLIT_SUB_BATCH = 32768;
+// Split path: the tokens of a sub-batch wait in HBM between the parse and the emit launch (4 bytes per
+// input byte of the largest block the launch admits, + histograms).  Sub-batches are as large as this
+// budget allows (measured on 16 GiB of 0xff00-byte blocks at level 2: 4.1 GiB -> 148, 8.2 GiB -> 154,
+// 33 GiB -> 158 GB/s), at most 32768 blocks.
+constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)8448 << 20;
+constexpr uint32_t SPLIT_SUB_BATCH_MAX = 32768;
+
+inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max)
+{
+	const uint64_t per = split_layout(split_max).bytes;
+	uint64_t sub = SPLIT_SCRATCH_BUDGET / per;
+	if (sub > SPLIT_SUB_BATCH_MAX)
+		sub = SPLIT_SUB_BATCH_MAX;
+	if (sub > nblocks)
+		sub = nblocks;
+	// a parse launch should fill the chip (4096 waves at level 2): with blocks so large that the budget
+	// holds fewer (1 MiB MiGz blocks: 4.8 MB of scratch each) the fused kernel, whose persistent grid
+	// needs no scratch per block, is the faster way (measured: level 3 75 vs 59 GB/s)
+	if (sub < 4096 && sub < nblocks)
+		sub = 0;
+	return (uint32_t)sub;                                // 0: fused kernel only
+}
+
+// largest block a launch can hold: it must fit its slot at least as stored blocks
+inline uint32_t split_max_block(uint64_t out_stride, uint32_t out_cap)
+{
+	const uint64_t cap = out_stride < out_cap ? out_stride : out_cap;
+	return cap > 0x7fffffffu ? 0x7fffffffu : (uint32_t)cap;
+}
 
 inline uint64_t fused_scratch_bytes(uint32_t nblocks, int level)
 {
 	return (uint64_t)dynamic_grid(nblocks, level) * DYN_SLAB_TOKENS * 4;
 }
 
-inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t, int level)
+inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int level)
 {
 	if (level < 2)
 		return 0;
 	return fused_scratch_bytes(nblocks, level) +
-	       (uint64_t)(nblocks < SPLIT_SUB_BATCH ? nblocks : SPLIT_SUB_BATCH) * SPLIT_BLOCK_BYTES;
+	       (uint64_t)split_sub_batch(nblocks, split_max) * split_layout(split_max).bytes;
 }
 
 struct HuffScratch {
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
-		if (EMIT ? n > SPLIT_MAX_BLOCK : (a.skip_small && n <= SPLIT_MAX_BLOCK))
+		if (EMIT ? n > a.split_max : (a.skip_small && n <= a.split_max))
 			continue;                            // the other path's block
 		const bool aligned = (((uintptr_t)src) & 15) == 0;
 		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
@@ -711,20 +738,23 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		} else {
 			// the parse has been done: one flush per recorded DEFLATE block
 			const uint32_t bi = b - a.first;
-			const SplitMeta *m = split_meta(a.scratch, bi);
-			const uint32_t ndb = m->ndb;
-			crcv = m->crc;
+			const SplitLayout lay = split_layout(a.split_max);
+			const uint8_t *rec = split_block(a.scratch, a.split_max, bi);
+			const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
+			const uint32_t *nt = (const uint32_t *)(rec + lay.off_ntok);
+			const uint32_t ndb = m[0];
+			crcv = m[1];
 			uint32_t t0 = 0;
 			for (uint32_t k = 0; k < ndb && alive; k++) {
-				const uint32_t *h = split_hist(a.scratch, bi, k);
+				const uint32_t *h = (const uint32_t *)(rec + lay.off_hist) + k * 320;
 				for (uint32_t i = lane; i < 288; i += 64)
 					L.lf[i] = h[i];
 				if (lane < 32)
 					L.df[lane] = h[288 + lane];
-				tok = split_slab(a.scratch, bi) + t0;
-				ntok_slab = m->ntok[k];
+				tok = (uint32_t *)rec + t0;
+				ntok_slab = nt[k];
 				alive = flush_block(k + 1 == ndb);
-				t0 += m->ntok[k];
+				t0 += nt[k];
 			}
 		}
 
@@ -762,24 +792,26 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	}
 }
 
-// Blocks <= 64 KiB: parse kernel (the level-1 kernel with this level's parse parameters, at the
+// Blocks up to a.split_max: parse kernel (the level-1 kernel with this level's parse parameters, at the
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
-// then the one emit-only kernel (16 waves per CU).  Larger blocks: the fused kernel.  Same bytes.
+// then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
+// than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
 template <int W, int H, int MINLEN, int LAZY>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
+	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max);
 	DeflateArgs s = a;
 	s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
-	for (uint32_t first = 0; first < a.nblocks; first += SPLIT_SUB_BATCH) {
+	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
-		s.count = a.nblocks - first < SPLIT_SUB_BATCH ? a.nblocks - first : SPLIT_SUB_BATCH;
+		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
 		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY>), dim3(s.count), dim3(64), 0, st, s);
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
 				   st, s);
 	}
 	DeflateArgs f = a;
-	f.skip_small = 1;
+	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }
 

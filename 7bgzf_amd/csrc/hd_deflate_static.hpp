@@ -48,7 +48,8 @@ struct DeflateArgs {
 	uint8_t *scratch;               // token slabs of the dynamic levels
 	uint32_t first;                 // split path: first block of this sub-batch (grid index 0)
 	uint32_t count;                 // split path: blocks in this sub-batch
-	uint32_t skip_small;            // fused dynamic kernel: leave blocks <= SPLIT_MAX_BLOCK to the split path
+	uint32_t skip_small;            // fused dynamic kernel: leave blocks <= split_max to the split path
+	uint32_t split_max;             // split path: largest block it takes (sizes the scratch layout)
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -173,32 +174,34 @@ __device__ __forceinline__ uint4 load_slot(const uint8_t *src, uint32_t n, uint3
 	return make_uint4(w0, w1, w2, w3);
 }
 
-// ---- level 2, blocks <= 64 KiB: parse kernel -> HBM -> emit kernel ------------
+// ---- dynamic levels: parse kernel -> HBM -> emit kernel ------------------------
 // Per block of a sub-batch the scratch holds the member's tokens (at most one per
 // input byte), the symbol histograms of its DEFLATE blocks (a block closes at the
-// first step boundary with >= HD_DYN_BLOCK_TOKENS tokens: at most 3 per member)
-// and a small record.  The parse is this file's kernel with TOK = true: the same
-// steps, but the token queue drains into the slab and the histograms instead of
-// into static-Huffman bits.  hd_deflate_dynamic.hpp's kernel in its emit-only mode
-// turns that into the bytes the fused kernel would have written.
-constexpr uint32_t SPLIT_MAX_BLOCK = 65536;
-constexpr uint32_t SPLIT_SLAB_TOK = SPLIT_MAX_BLOCK + 64;
-constexpr uint32_t SPLIT_MAX_DB = 4;
-struct SplitMeta {
-	uint32_t ndb, crc, ntok[SPLIT_MAX_DB], pad[2];
+// first step boundary with >= HD_DYN_BLOCK_TOKENS tokens) and a small record.  The
+// parse is this file's kernel with TOK = true: the same steps, but the token queue
+// drains into the slab and the histograms instead of into static-Huffman bits.
+// hd_deflate_dynamic.hpp's kernel in its emit-only mode turns that into the bytes
+// the fused kernel would have written.  The layout is sized by the largest block
+// the launch admits (a.split_max: the slot stride bounds it); larger blocks, if
+// any, are left to the fused kernel.
+//   [ tokens: (max + 64) x u32 | ndb, crc, pad, pad | ntok[max_db] | hist[max_db][320] ]
+struct SplitLayout {
+	uint32_t max_db;
+	uint64_t off_rec, off_ntok, off_hist, bytes;
 };
-constexpr uint64_t SPLIT_BLOCK_BYTES = (uint64_t)SPLIT_SLAB_TOK * 4 + sizeof(SplitMeta) + SPLIT_MAX_DB * 320 * 4;
-__device__ __forceinline__ uint32_t *split_slab(uint8_t *scratch, uint32_t i)
+__host__ __device__ inline SplitLayout split_layout(uint32_t max_block)
 {
-	return (uint32_t *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES);
+	SplitLayout l;
+	l.max_db = max_block / HD_DYN_BLOCK_TOKENS + 2;
+	l.off_rec = ((uint64_t)max_block + 64) * 4;
+	l.off_ntok = l.off_rec + 16;
+	l.off_hist = (l.off_ntok + (uint64_t)l.max_db * 4 + 15) & ~(uint64_t)15;
+	l.bytes = l.off_hist + (uint64_t)l.max_db * 320 * 4;
+	return l;
 }
-__device__ __forceinline__ SplitMeta *split_meta(uint8_t *scratch, uint32_t i)
+__device__ __forceinline__ uint8_t *split_block(uint8_t *scratch, uint32_t max_block, uint32_t i)
 {
-	return (SplitMeta *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES + (uint64_t)SPLIT_SLAB_TOK * 4);
-}
-__device__ __forceinline__ uint32_t *split_hist(uint8_t *scratch, uint32_t i, uint32_t db)
-{
-	return (uint32_t *)(scratch + (uint64_t)i * SPLIT_BLOCK_BYTES + (uint64_t)SPLIT_SLAB_TOK * 4 + sizeof(SplitMeta)) + db * 320;
+	return scratch + (uint64_t)i * split_layout(max_block).bytes;
 }
 
 // MINLEN / LAZY: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		return;
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
-	if (TOK && n > SPLIT_MAX_BLOCK)
+	if (TOK && n > a.split_max)
 		return;                              // the fused kernel takes the large blocks
 	const bool aligned = (((uintptr_t)src) & 15) == 0;
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (!TOK && lane < 4 && hdr)
 		stage[lane] = frame_hdr_word(a.frame, lane);
 	// TOK: where this block's tokens, histograms and record go
-	uint32_t *const slab = TOK ? split_slab(a.scratch, blockIdx.x) : nullptr;
+	const SplitLayout lay = split_layout(TOK ? a.split_max : 0);
+	uint8_t *const rec = TOK ? split_block(a.scratch, a.split_max, blockIdx.x) : nullptr;
+	uint32_t *const slab = (uint32_t *)rec;
 	uint32_t ntok_slab = 0, db_start = 0, ndb = 0;       // tokens stored; first token / index of the open DEFLATE block
 
 	Fn8Ident fid;
@@ -572,13 +577,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const bool small = n < 65536;
 	// TOK: the open DEFLATE block's histograms leave for HBM and start again from zero
 	auto close_deflate_block = [&]() {
-		uint32_t *h = split_hist(a.scratch, blockIdx.x, ndb);
+		uint32_t *h = (uint32_t *)(rec + lay.off_hist) + ndb * 320;
 		for (uint32_t i = lane; i < 320; i += 64) {
 			h[i] = stage[i];
 			stage[i] = 0;
 		}
 		if (lane == 0)
-			split_meta(a.scratch, blockIdx.x)->ntok[ndb] = ntok_slab - db_start;
+			((uint32_t *)(rec + lay.off_ntok))[ndb] = ntok_slab - db_start;
 		db_start = ntok_slab;
 		ndb++;
 	};
@@ -610,9 +615,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (TOK) {
 		close_deflate_block();
 		if (lane == 0) {
-			SplitMeta *m = split_meta(a.scratch, blockIdx.x);
-			m->ndb = ndb;
-			m->crc = crcv;
+			uint32_t *m = (uint32_t *)(rec + lay.off_rec);
+			m[0] = ndb;
+			m[1] = crcv;
 		}
 		return;
 	}
