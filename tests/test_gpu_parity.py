@@ -175,6 +175,23 @@ def test_encode_fuzz_blocks_match_twin(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(d), i
 
 
+@pytest.mark.parametrize("level", [2, 6])
+def test_encode_many_small_blocks_across_sub_batches(pkg, level):
+    """40000 blocks of 1000 bytes: more than one parse + emit launch pair of the split path (at most
+    32768 blocks each), with a 2 KiB slot stride that sizes the scratch layout; every member == twin."""
+    syn = hdtest.synth()
+    nb, bs = 40000, 1000
+    data = syn.fastq_like(nb * bs).tobytes()[: nb * bs]
+    offs = [i * bs for i in range(nb)]
+    lens = [bs] * nb
+    members, crc, st = pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_RAW, slot=2048)
+    assert not st.any()
+    for i in list(range(0, nb, 97)) + [32767, 32768, nb - 1]:
+        r, twin = hdtest.oracle_twin(data[i * bs:(i + 1) * bs], level)
+        assert r == 0 and members[i] == twin, (i, level)
+    assert zlib.decompress(members[32768], -15) == data[32768 * bs:32769 * bs]
+
+
 @pytest.mark.parametrize("level", [1, 2, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
