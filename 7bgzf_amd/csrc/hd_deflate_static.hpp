@@ -218,11 +218,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
 	// unaligned 8-byte read never wrap
 	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
-	// (position + 1) mod 2^16, 0 = empty; slot HS is a dump for lanes with nothing to publish
-	__shared__ __attribute__((aligned(16))) uint16_t table[HS + 8];
+	// (position + 1) mod 2^16, 0 = empty
+	__shared__ __attribute__((aligned(16))) uint16_t table[HS];
 	// TOK: no bits are made here, the staging ring's place is taken by the symbol histograms
-	// (litlen [0,288), offset [288,320)), and the queue has no dump slots (8 LDS units = 16 waves)
-	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? 320 : STG];
+	// (litlen [0,286), offset [286,316): every byte counts, LDS is granted in 1280-byte units and the level-3
+	// parse is 11 of them to the byte), and the queue has no dump slots
+	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? 316 : STG];
 	// tokens waiting for the emit pass; [TOKQ, TOKQ + 64) = dump slots of lanes without one
 	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 64];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		limit = cap - hdr - trl - sfx;
 
 	// ---- init LDS -------------------------------------------------------
-	for (uint32_t i = lane; i < HS / 8 + 1; i += 64)
+	for (uint32_t i = lane; i < HS / 8; i += 64)
 		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
-	for (uint32_t i = lane; i < (TOK ? 320u : STG); i += 64)
+	for (uint32_t i = lane; i < (TOK ? 316u : STG); i += 64)
 		stage[i] = 0;
 	if (!TOK && lane < 4 && hdr)
 		stage[lane] = frame_hdr_word(a.frame, lane);
@@ -337,10 +338,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const bool can = INNER || p + HD_MIN_MATCH <= n;
-		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
+		// (a lane past the end of the block publishes nothing; it reads slot 0, harmlessly)
+		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : 0u;
 		const uint16_t mine = (uint16_t)(p + 1);
 		const uint32_t e = table[h];
-		table[h] = mine;
+		if (can)
+			table[h] = mine;
 		if (INNER) {
 			f.c = e;                                         // position + 1 itself: nothing has wrapped
 		} else {
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
 					off_slot((t & 0xffff) + 1, ds, deb, dev);
 					atomicAdd(&stage[257 + ls], 1u);
-					atomicAdd(&stage[288 + ds], 1u);
+					atomicAdd(&stage[286 + ds], 1u);
 				} else {
 					atomicAdd(&stage[t & 0xff], 1u);
 				}
@@ -578,9 +581,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// TOK: the open DEFLATE block's histograms leave for HBM and start again from zero
 	auto close_deflate_block = [&]() {
 		uint32_t *h = (uint32_t *)(rec + lay.off_hist) + ndb * 320;
+		// HBM layout: litlen [0,288), offset [288,320)
 		for (uint32_t i = lane; i < 320; i += 64) {
-			h[i] = stage[i];
-			stage[i] = 0;
+			const uint32_t j = i < 286 ? i : i - 2;          // LDS index of litlen i / offset i - 288
+			const bool used = i < 286 || (i >= 288 && i < 318);
+			h[i] = used ? stage[j] : 0u;
+			if (used)
+				stage[j] = 0;
 		}
 		if (lane == 0)
 			((uint32_t *)(rec + lay.off_ntok))[ndb] = ntok_slab - db_start;
