@@ -246,10 +246,10 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
 	constexpr uint32_t HS = 1u << HASH_BITS;
-	// staging ring (dwords) and flush granule.  An emit call adds at most 64 dwords (<= 32 bits per lane)
-	// to fewer than FLUSH_DW pending ones, so twice the granule is enough; the emit-only kernel takes the
-	// small ring: 8 LDS units instead of 9, 16 waves per CU instead of 14
-	constexpr uint32_t STG = EMIT ? 128 : 256;
+	// staging ring (dwords) and flush granule: the token loop adds up to 64 x 48 bits = 96 dwords to
+	// fewer than FLUSH_DW pending ones before it flushes one granule, so 128 + 96 <= 256 is what it takes
+	// (a 128-dword ring would do for typical data and overflow on 48-bit tokens)
+	constexpr uint32_t STG = 256;
 	constexpr uint32_t FLUSH_DW = STG / 2;
 
 	__shared__ __attribute__((aligned(16))) union {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 
 // Blocks up to a.split_max: parse kernel (the level-1 kernel with this level's parse parameters, at the
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
-// then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
+// then the one emit-only kernel (14 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
 template <int W, int H, int MINLEN, int LAZY>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
@@ -806,7 +806,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
 		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY>), dim3(s.count), dim3(64), 0, st, s);
-		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
+		const uint32_t eg = s.count < 256u * 14u ? s.count : 256u * 14u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
 				   st, s);
 	}
