@@ -192,6 +192,24 @@ def test_encode_many_small_blocks_across_sub_batches(pkg, level):
     assert zlib.decompress(members[32768], -15) == data[32768 * bs:32769 * bs]
 
 
+@pytest.mark.parametrize("level", [1, 2, 6])
+def test_encode_and_decode_one_8mib_block(pkg, level):
+    """A single 8 MiB block: the 16-bit hash table wraps 128 times, the dynamic levels close ~60 DEFLATE
+    blocks inside one member, the split path sizes its scratch for a 12 MiB slot; kernel bytes == twin,
+    and the decoder takes the 8 MiB member back in one stream."""
+    syn = hdtest.synth()
+    n = 8 << 20
+    data = (syn.fastq_like(3 << 20).tobytes()[: 3 << 20] + syn.text_like(3 << 20).tobytes()[: 3 << 20] +
+            syn.random_bytes(1 << 20).tobytes() + bytes(1 << 20))[:n]
+    members, crc, st = pkg.batch_deflate(data, [0], [n], level, pkg.FRAME_RAW)
+    assert st[0] == 0
+    r, twin = hdtest.oracle_twin(data, level)
+    assert r == 0 and members[0] == twin, (level, len(members[0]), len(twin))
+    assert int(crc[0]) == zlib.crc32(data)
+    outs, dcrc, dst = pkg.batch_inflate([members[0]], [n])
+    assert dst[0] == 0 and outs[0] == data and int(dcrc[0]) == zlib.crc32(data)
+
+
 @pytest.mark.parametrize("level", [1, 2, 3, 6])
 def test_encode_migz_1mib_blocks_match_twin(pkg, level):
     """BASELINE config 5 shape: 1 MiB MiGz blocks of enwik-like text.  At levels >= 2 a
