@@ -221,9 +221,15 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// (position + 1) mod 2^16, 0 = empty
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS];
 	// TOK: no bits are made here, the staging ring's place is taken by the symbol histograms
-	// (litlen [0,286), offset [286,316): every byte counts, LDS is granted in 1280-byte units and the level-3
-	// parse is 11 of them to the byte), and the queue has no dump slots
-	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? 316 : STG];
+	// (316 counters: litlen [0,286), offset [286,316).  LDS is granted in 1280-byte units, every byte counts:
+	// where it buys another wave per CU -- the level 5-6 geometry -- the counters are 16 bits wide, two to a
+	// dword; a DEFLATE block holds fewer than 2^16 tokens, so none can carry into its neighbour.  Elsewhere
+	// they stay 32 bits wide: packed ones measured 4 % slower), and the queue has no dump slots
+	constexpr uint32_t LDS_REST = (W + 16) + 2 * HS + 4 * TOKQ;      // ring + table + token queue
+	constexpr uint32_t WAVES32 = 163840 / (((LDS_REST + 1264 + 1279) / 1280) * 1280);
+	constexpr uint32_t WAVES16 = 163840 / (((LDS_REST + 632 + 1279) / 1280) * 1280);
+	constexpr bool PACK16 = TOK && WAVES16 > WAVES32;
+	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? (PACK16 ? 158 : 316) : STG];
 	// tokens waiting for the emit pass; [TOKQ, TOKQ + 64) = dump slots of lanes without one
 	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 64];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// ---- init LDS -------------------------------------------------------
 	for (uint32_t i = lane; i < HS / 8; i += 64)
 		((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
-	for (uint32_t i = lane; i < (TOK ? 316u : STG); i += 64)
+	for (uint32_t i = lane; i < (TOK ? (PACK16 ? 158u : 316u) : STG); i += 64)
 		stage[i] = 0;
 	if (!TOK && lane < 4 && hdr)
 		stage[lane] = frame_hdr_word(a.frame, lane);
@@ -379,6 +385,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// (straight-line: both forms computed, one selected); false = the static
 	// stream no longer fits under `limit`
 	uint32_t qhead = 0, qtail = 0;
+	auto count_symbol = [&](uint32_t c) {                             // TOK only
+		if (PACK16)
+			atomicAdd(&stage[c >> 1], 1u << (16 * (c & 1)));
+		else
+			atomicAdd(&stage[c], 1u);
+	};
 	auto emit_tokens = [&](uint32_t count) -> bool {
 		const uint32_t t = tokbuf[(qhead + lane) & (TOKQ - 1)];
 		qhead += count;
@@ -390,10 +402,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					uint32_t ls, leb, lev, ds, deb, dev;
 					len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
 					off_slot((t & 0xffff) + 1, ds, deb, dev);
-					atomicAdd(&stage[257 + ls], 1u);
-					atomicAdd(&stage[286 + ds], 1u);
+					count_symbol(257 + ls);
+					count_symbol(286 + ds);
 				} else {
-					atomicAdd(&stage[t & 0xff], 1u);
+					count_symbol(t & 0xff);
 				}
 			}
 			ntok_slab += count;
@@ -581,14 +593,14 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// TOK: the open DEFLATE block's histograms leave for HBM and start again from zero
 	auto close_deflate_block = [&]() {
 		uint32_t *h = (uint32_t *)(rec + lay.off_hist) + ndb * 320;
-		// HBM layout: litlen [0,288), offset [288,320)
+		// HBM layout: u32 litlen [0,288), offset [288,320)
 		for (uint32_t i = lane; i < 320; i += 64) {
-			const uint32_t j = i < 286 ? i : i - 2;          // LDS index of litlen i / offset i - 288
+			const uint32_t j = i < 286 ? i : i - 2;          // counter of litlen i / offset i - 288
 			const bool used = i < 286 || (i >= 288 && i < 318);
-			h[i] = used ? stage[j] : 0u;
-			if (used)
-				stage[j] = 0;
+			h[i] = !used ? 0u : PACK16 ? (stage[j >> 1] >> (16 * (j & 1))) & 0xffffu : stage[j];
 		}
+		for (uint32_t i = lane; i < (PACK16 ? 158u : 316u); i += 64)
+			stage[i] = 0;
 		if (lane == 0)
 			((uint32_t *)(rec + lay.off_ntok))[ndb] = ntok_slab - db_start;
 		db_start = ntok_slab;
