@@ -529,30 +529,33 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
 			}
 			// ---- pass 2: the tokens -------------------------------------------
+			// straight-line: both forms are computed and one is selected; a token's two fields
+			// (litlen code + extra bits, offset code + extra bits: <= 20 + 28 bits) go out as
+			// one 64-bit OR over up to three dwords
 			for (uint32_t base = 0; base < ntok_slab; base += 64) {
 				const uint32_t k = base + lane;
-				uint32_t ca = 0, na = 0, cb = 0, nb = 0;
-				if (k < ntok_slab) {
-					const uint32_t tk = tok[k];
-					if (tk & HD_TOKEN_MATCH) {
-						uint32_t ls, leb, lev, ds, deb, dev;
-						len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
-						off_slot((tk & 0xffff) + 1, ds, deb, dev);
-						const uint32_t lc = Bd.lcode[257 + ls], dc = Bd.dcode[ds];
-						ca = (lc & 0xffff) | (lev << (lc >> 16));
-						na = (lc >> 16) + leb;
-						cb = (dc & 0xffff) | (dev << (dc >> 16));
-						nb = (dc >> 16) + deb;
-					} else {
-						const uint32_t lc = Bd.lcode[tk & 0xff];
-						ca = lc & 0xffff;
-						na = lc >> 16;
-					}
-				}
-				const uint32_t incl = wave_incl_scan(na + nb);
-				const uint32_t at = bitpos + incl - (na + nb);
-				put(ca, na, at);
-				put(cb, nb, at + na);
+				const bool valid = k < ntok_slab;
+				const uint32_t tk = valid ? tok[k] : 0u;
+				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
+				uint32_t ls, leb, lev, ds, deb, dev;
+				len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
+				off_slot((tk & 0xffff) + 1, ds, deb, dev);
+				const uint32_t lc = Bd.lcode[is_match ? 257 + ls : (tk & 0xff)];
+				const uint32_t dc = Bd.dcode[ds];
+				const uint32_t ca = (lc & 0xffff) | (is_match ? lev << (lc >> 16) : 0u);
+				const uint32_t na = (lc >> 16) + (is_match ? leb : 0u);
+				const uint32_t cb = (dc & 0xffff) | (dev << (dc >> 16));
+				const uint32_t nb = is_match ? (dc >> 16) + deb : 0u;
+				const uint32_t nbits = valid ? na + nb : 0u;
+				const uint64_t code = valid ? ((uint64_t)ca | ((uint64_t)(is_match ? cb : 0u) << na)) : 0ull;
+				const uint32_t incl = wave_incl_scan(nbits);
+				const uint32_t at = bitpos + incl - nbits;
+				const uint32_t sh = at & 31, i = (at >> 5) & (STG - 1);
+				const uint64_t lo = code << sh;                      // bits [0, 64) of the shifted field
+				const uint32_t hi = sh ? (uint32_t)(code >> (64 - sh)) : 0u;   // and what a 48-bit field spills beyond
+				atomicOr(&stage[i], (uint32_t)lo);
+				atomicOr(&stage[(i + 1) & (STG - 1)], (uint32_t)(lo >> 32));
+				atomicOr(&stage[(i + 2) & (STG - 1)], hi);
 				bitpos += readlane(incl, 63);
 				flush_ready();
 			}
