@@ -230,8 +230,12 @@ struct DynLds {
 // ring is re-read from HBM after a non-final block; 7 KiB less LDS per wave).
 struct DynBuild {
 	HuffScratch hs;
-	uint16_t items[288 + 32];          // RLE of the code lengths: symbol | extra << 8
-	uint8_t lens[288 + 32];
+	// The RLE of the code lengths (items: symbol | extra << 8) and the lengths themselves are written
+	// after the litlen and offset codes are built and read until the header is out; in between only the
+	// 19-symbol precode is built, which touches the first 38 nodes of hs.nf -- so they live further up in
+	// that array instead of costing 960 bytes of their own (the emit-only kernel: 8 LDS units, 16 waves)
+	__device__ __forceinline__ uint16_t *items() { return (uint16_t *)&hs.nf[64]; }       // 320 x u16
+	__device__ __forceinline__ uint8_t *lens() { return (uint8_t *)&hs.nf[64 + 160]; }    // 320 x u8
 	uint32_t lcode[288], dcode[32];    // code | len << 16: live from the construction to the end of the emit pass
 };
 
@@ -416,42 +420,42 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				while (hdist > 1 && (Bd.dcode[hdist - 1] >> 16) == 0)
 					hdist--;
 				for (uint32_t i = 0; i < hlit; i++)
-					Bd.lens[i] = (uint8_t)(Bd.lcode[i] >> 16);
+					Bd.lens()[i] = (uint8_t)(Bd.lcode[i] >> 16);
 				for (uint32_t i = 0; i < hdist; i++)
-					Bd.lens[hlit + i] = (uint8_t)(Bd.dcode[i] >> 16);
+					Bd.lens()[hlit + i] = (uint8_t)(Bd.dcode[i] >> 16);
 				const uint32_t total = hlit + hdist;
 				uint32_t ni = 0, i = 0;
 				while (i < total) {
-					const uint32_t v = Bd.lens[i];
+					const uint32_t v = Bd.lens()[i];
 					uint32_t run = 1;
-					while (i + run < total && Bd.lens[i + run] == v)
+					while (i + run < total && Bd.lens()[i + run] == v)
 						run++;
 					i += run;
 					if (v == 0) {
 						while (run >= 11) {
 							const uint32_t r = run < 138 ? run : 138;
-							Bd.items[ni++] = (uint16_t)(18 | ((r - 11) << 8));
+							Bd.items()[ni++] = (uint16_t)(18 | ((r - 11) << 8));
 							L.pfreq[18]++;
 							run -= r;
 						}
 						if (run >= 3) {
-							Bd.items[ni++] = (uint16_t)(17 | ((run - 3) << 8));
+							Bd.items()[ni++] = (uint16_t)(17 | ((run - 3) << 8));
 							L.pfreq[17]++;
 							run = 0;
 						}
 					} else {
-						Bd.items[ni++] = (uint16_t)v;
+						Bd.items()[ni++] = (uint16_t)v;
 						L.pfreq[v]++;
 						run--;
 						while (run >= 3) {
 							const uint32_t r = run < 6 ? run : 6;
-							Bd.items[ni++] = (uint16_t)(16 | ((r - 3) << 8));
+							Bd.items()[ni++] = (uint16_t)(16 | ((r - 3) << 8));
 							L.pfreq[16]++;
 							run -= r;
 						}
 					}
 					while (run--) {
-						Bd.items[ni++] = (uint16_t)v;
+						Bd.items()[ni++] = (uint16_t)v;
 						L.pfreq[v]++;
 					}
 				}
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			for (uint32_t base = 0; base < ni; base += 64) {
 				const uint32_t k = base + lane;
 				if (k < ni) {
-					const uint32_t sym = Bd.items[k] & 31;
+					const uint32_t sym = Bd.items()[k] & 31;
 					dyn += (L.pcode[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
 				}
 			}
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 					const uint32_t k = base + lane;
 					uint32_t cc = 0, nn = 0;
 					if (k < ni) {
-						const uint32_t it = Bd.items[k], sym = it & 31;
+						const uint32_t it = Bd.items()[k], sym = it & 31;
 						const uint32_t pc = L.pcode[sym];
 						cc = (pc & 0xffff) | ((it >> 8) << (pc >> 16));
 						nn = (pc >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 
 // Blocks up to a.split_max: parse kernel (the level-1 kernel with this level's parse parameters, at the
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
-// then the one emit-only kernel (14 waves per CU).  Larger blocks (none, unless a block is larger
+// then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
 template <int W, int H, int MINLEN, int LAZY>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
@@ -809,7 +813,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
 		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY>), dim3(s.count), dim3(64), 0, st, s);
-		const uint32_t eg = s.count < 256u * 14u ? s.count : 256u * 14u;
+		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
 				   st, s);
 	}

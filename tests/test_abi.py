@@ -157,7 +157,7 @@ def test_kernel_resource_budgets():
         want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else 16 if "Li13ELi12E" in k else 28
         assert units <= want, (k, v)                 # 10 / 8 / 4 waves per CU: dynamic_grid()
     (v,) = emit.values()
-    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 9 * 1280, v    # 14 waves per CU: launch_level()
+    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
     for k, v in sta.items():                                     # level 1 and the parse kernels of levels 2-9
         assert v["VGPRs"] <= 128, (k, v)
         units = -(-v["LDS Size"] // 1280)
