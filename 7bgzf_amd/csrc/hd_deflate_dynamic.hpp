@@ -133,36 +133,65 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 		h.blc[lane] = 0;
 		h.next[lane] = 0;
 	}
+	// The serial parts run on lane 0 against LDS, ~100 cycles a round trip, so they are written to keep
+	// as few loads as possible on the critical path (same algorithm and results as the twin's loops).
 	if (lane == 0) {
-		// two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2
+		// two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2.  The heads of both
+		// queues are held in registers (the leaf queue one element ahead), a node's weight is the
+		// sum of two register values, and a freshly made node that is the internal head is taken
+		// from the register it was computed in.
 		uint32_t i = 0, j = nu, k = nu;
+		uint32_t lv = h.nf[0], lv2 = nu > 1 ? h.nf[1] : 0u;     // leaf head and the one behind it
+		uint32_t iv = 0;                                      // internal head, valid while j < k
 		while (k < 2 * nu - 1) {
-			uint32_t pick[2];
+			uint32_t sum = 0;
 #pragma unroll
 			for (int t = 0; t < 2; t++) {
-				if (i < nu && (j >= k || h.nf[i] <= h.nf[j]))
-					pick[t] = i++;
-				else
-					pick[t] = j++;
+				if (i < nu && (j >= k || lv <= iv)) {
+					sum += lv;
+					h.parent[i] = (uint16_t)k;
+					i++;
+					lv = lv2;
+					lv2 = i + 1 < nu ? h.nf[i + 1] : 0u;
+				} else {
+					sum += iv;
+					h.parent[j] = (uint16_t)k;
+					j++;
+					iv = j < k ? h.nf[j] : 0u;
+				}
 			}
-			h.nf[k] = h.nf[pick[0]] + h.nf[pick[1]];
-			h.parent[pick[0]] = (uint16_t)k;
-			h.parent[pick[1]] = (uint16_t)k;
+			h.nf[k] = sum;
+			if (j == k)
+				iv = sum;
 			k++;
 		}
+		// depths of the internal nodes, root first (a parent has the larger index); the next
+		// node's parent index is loaded while this one's depth is on its way
 		h.depth[2 * nu - 2] = 0;
-		for (int x = (int)(2 * nu - 3); x >= 0; x--)
-			h.depth[x] = (uint8_t)(h.depth[h.parent[x]] + 1);
-		// level counts, overflow pushed up the tree
-		int overflow = 0;
-		for (uint32_t x = 0; x < nu; x++) {
-			uint32_t d = h.depth[x];
-			if (d > maxbits) {
-				d = maxbits;
-				overflow++;
+		if (nu > 2) {
+			uint32_t pn = h.parent[2 * nu - 3];
+			for (int x = (int)(2 * nu - 3); x >= (int)nu; x--) {
+				const uint32_t pc = pn;
+				if (x > (int)nu)
+					pn = h.parent[x - 1];
+				h.depth[x] = (uint8_t)(h.depth[pc] + 1);
 			}
-			h.blc[d]++;
 		}
+	}
+	// leaves: depth and level counts by all lanes
+	uint32_t over = 0;
+	for (uint32_t base = 0; base < nu; base += 64) {
+		const uint32_t x = base + lane;
+		uint32_t d = 0;
+		if (x < nu) {
+			d = (uint32_t)h.depth[h.parent[x]] + 1;
+			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+		}
+		over += (uint32_t)__popcll(__ballot(x < nu && d > maxbits));
+	}
+	if (lane == 0) {
+		// overflow pushed up the tree
+		int overflow = (int)over;
 		while (overflow > 0) {
 			uint32_t bits = maxbits - 1;
 			while (h.blc[bits] == 0)
