@@ -115,18 +115,31 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 		}
 		nu = 2;
 	}
-	// rank sort: r = number of used symbols ordered before s
-	for (uint32_t base = 0; base < nsyms; base += 64) {
-		const uint32_t s = base + lane;
-		const uint32_t fs = s < nsyms ? h.freq[s] : 0;
-		uint32_t r = 0;
-		for (uint32_t t = 0; t < nsyms; t++) {
-			const uint32_t ft = h.freq[t];
-			r += (ft != 0 && (ft < fs || (ft == fs && t < s))) ? 1u : 0u;
+	// rank sort by (frequency, symbol) over the USED symbols only: they are first compacted, in symbol
+	// order, into keys freq << 9 | symbol (all distinct), and a key's rank is the number of smaller keys
+	// -- nu * ceil(nu / 64) compares instead of nsyms * ceil(nsyms / 64).  The keys borrow the upper
+	// half of the node-weight array, which the merge only reaches when it has consumed them.
+	uint32_t *const keys = &h.nf[288];
+	{
+		uint32_t at = 0;
+		for (uint32_t base = 0; base < nsyms; base += 64) {
+			const uint32_t s = base + lane;
+			const uint32_t fs = s < nsyms ? h.freq[s] : 0;
+			const uint64_t m = __ballot(fs != 0);
+			if (fs)
+				keys[at + __popcll(m & ((1ull << lane) - 1))] = (fs << 9) | s;
+			at += (uint32_t)__popcll(m);
 		}
-		if (fs) {
-			h.order[r] = (uint16_t)s;
-			h.nf[r] = fs;
+	}
+	for (uint32_t base = 0; base < nu; base += 64) {
+		const uint32_t x = base + lane;
+		const uint32_t mine = x < nu ? keys[x] : 0xffffffffu;
+		uint32_t r = 0;
+		for (uint32_t t = 0; t < nu; t++)
+			r += keys[t] < mine ? 1u : 0u;
+		if (x < nu) {
+			h.order[r] = (uint16_t)(mine & 511);
+			h.nf[r] = mine >> 9;
 		}
 	}
 	if (lane < 16) {
