@@ -210,12 +210,19 @@ void hipdeflate_shutdown(void)
 	if (!g.ready)
 		return;
 	(void)hipSetDevice(g.device);
-	(void)hipStreamSynchronize(g.stream);
+	(void)hipDeviceSynchronize();                        // launches on callers' streams may still use our scratch
 	for (Buf *b : { &g.d_in, &g.d_meta, &g.d_slots, &g.d_packed, &g.d_scratch, &g.d_scan, &g.h_in, &g.h_meta,
 			&g.h_out, &g.d_tok, &g.d_tiles })
 		b->release();
 	(void)hipFree(g.d_ct);
 	(void)hipStreamDestroy(g.stream);
+	if (g.ev_tok)
+		(void)hipEventDestroy(g.ev_tok);
+	if (g.ev_tiles)
+		(void)hipEventDestroy(g.ev_tiles);
+	g.ev_tok = g.ev_tiles = nullptr;
+	g.st_tok = g.st_tiles = nullptr;
+	g.tok_used = g.tiles_used = false;
 	g.d_ct = nullptr;
 	g.stream = nullptr;
 	g.ready = false;
