@@ -263,6 +263,7 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	a.count = 0;
 	a.skip_small = 0;
 	a.split_max = hd::split_max_block(out_stride, out_cap);
+	a.split_ovf = nullptr;
 	if (level >= 2) {
 		// token slabs for the dynamic levels: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);

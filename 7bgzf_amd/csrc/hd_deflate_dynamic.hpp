@@ -37,25 +37,39 @@ inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 	return nblocks < slots ? nblocks : slots;
 }
 
-// Split path: the tokens of a sub-batch wait in HBM between the parse and the emit launch (4 bytes per
+// Split path: the tokens of a sub-batch wait in HBM between the parse and the emit launch (2 bytes per
 // input byte of the largest block the launch admits, + histograms).  Sub-batches are as large as this
-// budget allows (measured on 16 GiB of 0xff00-byte blocks at level 2: 4.1 GiB -> 148, 8.2 GiB -> 154,
-// 33 GiB -> 158 GB/s), at most 32768 blocks.
+// budget allows (measured on 16 GiB of 0xff00-byte blocks at level 2, 4 B per byte: 4.1 GiB -> 148,
+// 8.2 GiB -> 154, 33 GiB -> 158 GB/s), at most 65536 blocks.
 constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)8448 << 20;
-constexpr uint32_t SPLIT_SUB_BATCH_MAX = 32768;
+constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 
-inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max)
+// resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
+inline uint32_t parse_slots(int level)
+{
+	return 256u * (level == 2 ? 16u : level <= 4 ? 11u : level <= 6 ? 9u : 4u);
+}
+
+inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)
 {
 	const uint64_t per = split_layout(split_max).bytes;
 	uint64_t sub = SPLIT_SCRATCH_BUDGET / per;
 	if (sub > SPLIT_SUB_BATCH_MAX)
 		sub = SPLIT_SUB_BATCH_MAX;
-	if (sub > nblocks)
-		sub = nblocks;
-	// a parse launch should fill the chip (4096 waves at level 2): with blocks so large that the budget
-	// holds fewer (1 MiB MiGz blocks: 4.8 MB of scratch each) the fused kernel, whose persistent grid
-	// needs no scratch per block, is the faster way (measured: level 3 75 vs 59 GB/s)
-	if (sub < 4096 && sub < nblocks)
+	// Large blocks (1 MiB MiGz members: 40 ms of one wave's time each, ~33 DEFLATE blocks to build one
+	// after the other in the emit launch) are better off in the fused kernel, whose persistent grid
+	// overlaps all phases of different blocks: measured with 1 MiB text blocks, level 3 72 vs 80 GB/s,
+	// level 6 53 vs 66 GB/s.
+	if (split_max > (256u << 10) + 65536u)
+		return 0;
+	if (sub >= nblocks)
+		return nblocks;
+	// launches are whole rounds of the resident parse waves where the budget allows one; when it allows
+	// less than half a round the fused kernel is the faster way again
+	const uint32_t slots = parse_slots(level);
+	if (sub >= slots)
+		sub -= sub % slots;
+	else if (sub < slots / 2)
 		sub = 0;
 	return (uint32_t)sub;                                // 0: fused kernel only
 }
@@ -76,8 +90,8 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int 
 {
 	if (level < 2)
 		return 0;
-	return fused_scratch_bytes(nblocks, level) +
-	       (uint64_t)split_sub_batch(nblocks, split_max) * split_layout(split_max).bytes;
+	return fused_scratch_bytes(nblocks, level) + (uint64_t)nblocks * 4 +                 // + the overflow flags
+	       (uint64_t)split_sub_batch(nblocks, split_max, level) * split_layout(split_max).bytes + 16;
 }
 
 struct HuffScratch {
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
-		if (EMIT ? n > a.split_max : (a.skip_small && n <= a.split_max))
+		if (EMIT ? a.split_ovf[b] != 0 : (a.skip_small && a.split_ovf[b] == 0))
 			continue;                            // the other path's block
 		const bool aligned = (((uintptr_t)src) & 15) == 0;
 		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
@@ -848,9 +862,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 template <int W, int H, int MINLEN, int LAZY>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
-	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max);
+	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max, level);
 	DeflateArgs s = a;
-	s.scratch = a.scratch + fused_scratch_bytes(a.nblocks, level);
+	// scratch: [ fused slabs | overflow flags, one u32 per block | split records of one sub-batch ]
+	s.split_ovf = (uint32_t *)(a.scratch + fused_scratch_bytes(a.nblocks, level));
+	s.scratch = (uint8_t *)s.split_ovf + (((uint64_t)a.nblocks * 4 + 15) & ~(uint64_t)15);
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
@@ -860,6 +876,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 				   st, s);
 	}
 	DeflateArgs f = a;
+	f.split_ovf = s.split_ovf;
 	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }

@@ -50,6 +50,7 @@ struct DeflateArgs {
 	uint32_t count;                 // split path: blocks in this sub-batch
 	uint32_t skip_small;            // fused dynamic kernel: leave blocks <= split_max to the split path
 	uint32_t split_max;             // split path: largest block it takes (sizes the scratch layout)
+	uint32_t *split_ovf;            // split path: per block, 1 = left to the fused kernel (too many tokens)
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -182,18 +183,22 @@ __device__ __forceinline__ uint4 load_slot(const uint8_t *src, uint32_t n, uint3
 // drains into the slab and the histograms instead of into static-Huffman bits.
 // hd_deflate_dynamic.hpp's kernel in its emit-only mode turns that into the bytes
 // the fused kernel would have written.  The layout is sized by the largest block
-// the launch admits (a.split_max: the slot stride bounds it); larger blocks, if
-// any, are left to the fused kernel.
-//   [ tokens: (max + 64) x u32 | ndb, crc, pad, pad | ntok[max_db] | hist[max_db][320] ]
+// the launch admits (a.split_max: the slot stride bounds it) and holds one token
+// per TWO input bytes: compressible data stays well below that (DNA-like 0.2,
+// text 0.35 tokens per byte); a block that does not (noise) sets its flag in
+// a.split_ovf and is taken by the fused kernel afterwards, as are blocks larger
+// than split_max, if any.
+//   [ tokens: cap_tok x u32 | ndb, crc, pad, pad | ntok[max_db] | hist[max_db][320] ]
 struct SplitLayout {
-	uint32_t max_db;
+	uint32_t cap_tok, max_db;
 	uint64_t off_rec, off_ntok, off_hist, bytes;
 };
 __host__ __device__ inline SplitLayout split_layout(uint32_t max_block)
 {
 	SplitLayout l;
-	l.max_db = max_block / HD_DYN_BLOCK_TOKENS + 2;
-	l.off_rec = ((uint64_t)max_block + 64) * 4;
+	l.cap_tok = max_block / 2 + 128;
+	l.max_db = l.cap_tok / HD_DYN_BLOCK_TOKENS + 2;
+	l.off_rec = (uint64_t)l.cap_tok * 4;
 	l.off_ntok = l.off_rec + 16;
 	l.off_hist = (l.off_ntok + (uint64_t)l.max_db * 4 + 15) & ~(uint64_t)15;
 	l.bytes = l.off_hist + (uint64_t)l.max_db * 320 * 4;
@@ -240,8 +245,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		return;
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
-	if (TOK && n > a.split_max)
+	if (TOK && n > a.split_max) {
+		if (lane == 0)
+			a.split_ovf[b] = 1;
 		return;                              // the fused kernel takes the large blocks
+	}
 	const bool aligned = (((uintptr_t)src) & 15) == 0;
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 	const CrcTables *ct = a.ct;
@@ -396,6 +404,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		qhead += count;
 		if (TOK) {
 			// queued tokens -> slab (one coalesced 4 B/lane store) + symbol histograms
+			if (ntok_slab + count > lay.cap_tok)
+				return false;                        // more tokens than the slab holds: the fused kernel's block
 			if (lane < count) {
 				slab[ntok_slab + lane] = t;
 				if (t & HD_TOKEN_MATCH) {
@@ -612,8 +622,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			break;
 		// a DEFLATE block closes at the first step boundary with >= 32768 tokens (as the fused kernel)
 		if (TOK && ntok_slab + (qtail - qhead) - db_start >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
-			if (qtail != qhead)
-				emit_tokens(qtail - qhead);
+			if (qtail != qhead && !emit_tokens(qtail - qhead)) {
+				use_static = false;
+				break;
+			}
 			close_deflate_block();
 		}
 	}
@@ -632,11 +644,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 
 	if (TOK) {
-		close_deflate_block();
+		if (use_static)
+			close_deflate_block();
 		if (lane == 0) {
 			uint32_t *m = (uint32_t *)(rec + lay.off_rec);
-			m[0] = ndb;
+			m[0] = use_static ? ndb : 0xffffffffu;       // use_static false here: the slab overflowed
 			m[1] = crcv;
+			a.split_ovf[b] = use_static ? 0u : 1u;
 		}
 		return;
 	}
