@@ -177,19 +177,20 @@ def test_encode_fuzz_blocks_match_twin(pkg, level):
 
 @pytest.mark.parametrize("level", [2, 6])
 def test_encode_many_small_blocks_across_sub_batches(pkg, level):
-    """40000 blocks of 1000 bytes: more than one parse + emit launch pair of the split path (at most
-    32768 blocks each), with a 2 KiB slot stride that sizes the scratch layout; every member == twin."""
+    """70000 blocks of 1000 bytes: more than one parse + emit launch pair of the split path (at most
+    65536 blocks each, in whole rounds of the resident parse waves), with a small slot stride that sizes
+    the scratch layout; sampled members, the ones around the launch boundaries included, == twin."""
     syn = hdtest.synth()
-    nb, bs = 40000, 1000
+    nb, bs = 70000, 1000
     data = syn.fastq_like(nb * bs).tobytes()[: nb * bs]
     offs = [i * bs for i in range(nb)]
     lens = [bs] * nb
     members, crc, st = pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_RAW, slot=2048)
     assert not st.any()
-    for i in list(range(0, nb, 97)) + [32767, 32768, nb - 1]:
+    for i in list(range(0, nb, 173)) + [64511, 64512, 65535, 65536, nb - 1]:
         r, twin = hdtest.oracle_twin(data[i * bs:(i + 1) * bs], level)
         assert r == 0 and members[i] == twin, (i, level)
-    assert zlib.decompress(members[32768], -15) == data[32768 * bs:32769 * bs]
+    assert zlib.decompress(members[65536], -15) == data[65536 * bs:65537 * bs]
 
 
 @pytest.mark.parametrize("level", [1, 2, 6])
