@@ -187,8 +187,10 @@ int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const
 int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t *nbytes);
 void hipdeflate_unpipe_close(hipdeflate_unpipe *p);
 
-/* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level<=1);
- * the library keeps its own grow-only scratch, this is informational */
+/* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level <= 1): the token slabs of the
+ * fused kernel plus, for blocks up to 256 KiB (max_block = the slot stride), the tokens and histograms of one
+ * sub-batch of the parse + emit kernel pair -- at most 8.25 GiB however large the batch.  The library keeps
+ * its own grow-only scratch; this is informational. */
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level);
 
 /* ---- LD_PRELOAD hook ----------------------------------------------------- */
