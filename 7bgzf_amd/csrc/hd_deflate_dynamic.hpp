@@ -300,7 +300,7 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // EMIT = 1: emit-only mode, the second half of the level-2 split path: tokens, histograms and
 // CRC of blocks [a.first, a.first + a.count) are in the scratch (written by k_deflate_static<.., true>),
 // this kernel builds the codes and writes the members exactly as the fused mode would have.
-template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT>
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0>
 __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -438,6 +438,11 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			table[h] = mine;
 			const uint32_t back = (p + 1 - e) & 0xffffu;
 			f.c = (can && e && back) ? p + 1 - back : 0u;
+			if (INTRA) {
+				// a nearer occurrence inside the step replaces the table's candidate
+				const uint32_t d = intra_step_distance<INTRA>(f.v, lane);
+				f.c = (can && d) ? p + 1 - d : f.c;
+			}
 			for (;;) {
 				const uint16_t now = table[h];
 				const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
 // then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
-template <int W, int H, int MINLEN, int LAZY>
+template <int W, int H, int MINLEN, int LAZY, int INTRA>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max, level);
@@ -870,7 +875,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
-		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY>), dim3(s.count), dim3(64), 0, st, s);
+		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY, INTRA>), dim3(s.count), dim3(64), 0, st, s);
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
 				   st, s);
@@ -878,19 +883,19 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	DeflateArgs f = a;
 	f.split_ovf = s.split_ovf;
 	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
-	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
+	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }
 
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
 	if (level == 2)
-		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0>(a, level, st);
+		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 0>(a, level, st);
 	else if (level <= 4)
-		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0>(a, level, st);
+		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	else if (level <= 6)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1>(a, level, st);
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	else
-		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1>(a, level, st);
+		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	return 0;
 }
 

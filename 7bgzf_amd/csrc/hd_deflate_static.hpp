@@ -209,8 +209,8 @@ __device__ __forceinline__ uint8_t *split_block(uint8_t *scratch, uint32_t max_b
 	return scratch + (uint64_t)i * split_layout(max_block).bytes;
 }
 
-// MINLEN / LAZY: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
-template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0>
+// MINLEN / LAZY / INTRA: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
+template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0, int INTRA = 0>
 __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -364,6 +364,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
 			const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
 			f.c = (can && e && back) ? p + 1 - back : 0u;
+		}
+		if (INTRA) {
+			// a nearer occurrence inside the step replaces the table's candidate
+			const uint32_t d = intra_step_distance<INTRA>(f.v, lane);
+			f.c = (can && d) ? p + 1 - d : f.c;
 		}
 		// settle publish conflicts inside this step (positions differ by < 64)
 		for (;;) {

@@ -214,6 +214,21 @@ struct CrcLanes {
 	}
 };
 
+// Candidates inside a step (levels >= 3, HD_INTRA_DIST): the nearest of the DIST lanes before this one
+// that holds the same four bytes `v`, as a distance (0 = none).  wave_shr:1 chains hand every lane the
+// value of lane - d; lanes below d see filler and are masked.
+template <int DIST>
+__device__ __forceinline__ uint32_t intra_step_distance(uint32_t v, uint32_t lane)
+{
+	uint32_t sh = v, best = 0;
+#pragma unroll
+	for (int d = 1; d <= DIST; d++) {
+		sh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+		best = (best == 0 && sh == v && lane >= (uint32_t)d) ? (uint32_t)d : best;
+	}
+	return best;
+}
+
 // ---- Adler-32 (RFC 1950) ----------------------------------------------------
 // a = 1 + sum d_i, b = n + sum (n - i) d_i (mod 65521): every lane keeps the plain and
 // the index-weighted byte sum of its 16-byte slots (v_sad_u8 / v_dot4_u32_u8); bytes a

@@ -119,6 +119,7 @@ typedef struct {
 	unsigned hash_bits;
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
+	unsigned intra;       /* levels >= 3: candidates at distances 1..intra inside the step */
 } mf_t;
 
 typedef struct {
@@ -160,6 +161,15 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 		 * that is simply e */
 		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
 		cand[l] = (e && back) ? (uint32_t)(p + 1 - back) : 0;
+		/* The table only knows earlier steps, and DNA-like data is full of repeats a few bytes
+		 * apart (quality strings).  Levels >= 3: a lane also looks at the lanes just before it
+		 * in the same step; the nearest one with the same four bytes is the latest occurrence
+		 * and replaces the table's candidate (the kernel compares DPP-shifted copies). */
+		for (unsigned d = 1; d <= mf->intra && d <= l; d++)
+			if (load32(in + p - d) == v) {
+				cand[l] = (uint32_t)(p - d + 1);
+				break;
+			}
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 2. publish */
 		size_t p = S + l;
@@ -237,7 +247,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0 };
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
@@ -581,13 +591,13 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
 }
 
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, int flush)
+			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush)
 {
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + 64 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0 };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, intra };
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
 	step_t st;
@@ -641,15 +651,15 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, flush);
+				       HD_L2_MIN_LEN, 0, 0, flush);
 	if (level <= 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
-				       HD_L3_MIN_LEN, 0, flush);
+				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush);
 	if (level <= 6)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, flush);
+				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush);
 	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-			       HD_L7_MIN_LEN, 1, flush);
+			       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,

@@ -143,7 +143,8 @@ def test_kernel_resource_budgets():
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/\w+\])?: (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
-    emit = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k and k.endswith("ELi1EEEvNS_11DeflateArgsE")}
+    # k_deflate_dynamic<W, H, MINLEN, LAZY, EMIT, INTRA>: the emit-only instantiation has EMIT = 1
+    emit = {k: v for k, v in kernels.items() if re.search(r"k_deflate_dynamicILi\d+ELi\d+ELi\d+ELi\d+ELi1ELi\d+EEEv", k)}
     dyn = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k and k not in emit}
     sta = {k: v for k, v in kernels.items() if "k_deflate_static" in k}
     inf = {k: v for k, v in kernels.items() if "k_inflate" in k}
