@@ -205,28 +205,29 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			}
 		}
 	}
-	// leaves: depth and level counts by all lanes
-	uint32_t over = 0;
+	// leaves: depth and level counts by all lanes; leaves deeper than maxbits are cut back to maxbits
 	for (uint32_t base = 0; base < nu; base += 64) {
 		const uint32_t x = base + lane;
-		uint32_t d = 0;
 		if (x < nu) {
-			d = (uint32_t)h.depth[h.parent[x]] + 1;
+			const uint32_t d = (uint32_t)h.depth[h.parent[x]] + 1;
 			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
 		}
-		over += (uint32_t)__popcll(__ballot(x < nu && d > maxbits));
 	}
 	if (lane == 0) {
-		// overflow pushed up the tree
-		int overflow = (int)over;
-		while (overflow > 0) {
+		// The cut leaves the code over-subscribed by `excess` codewords of length maxbits (Kraft sum in
+		// units of 2^-maxbits); every pass gives one back: a leaf moves one level down, a maxbits leaf
+		// becomes its sibling.  (Counting the cut leaves is only right for leaves at maxbits + 1.)
+		int32_t excess = -(int32_t)(1u << maxbits);
+		for (uint32_t bits = 1; bits <= maxbits; bits++)
+			excess += (int32_t)(h.blc[bits] << (maxbits - bits));
+		while (excess > 0) {
 			uint32_t bits = maxbits - 1;
 			while (h.blc[bits] == 0)
 				bits--;
 			h.blc[bits]--;
 			h.blc[bits + 1] += 2;
 			h.blc[maxbits]--;
-			overflow -= 2;
+			excess--;
 		}
 		// canonical first codes
 		uint32_t code = 0;
@@ -889,7 +890,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
 	if (level == 2)
-		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 0>(a, level, st);
+		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	else if (level <= 4)
 		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	else if (level <= 6)

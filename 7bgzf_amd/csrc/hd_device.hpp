@@ -214,7 +214,7 @@ struct CrcLanes {
 	}
 };
 
-// Candidates inside a step (levels >= 3, HD_INTRA_DIST): the nearest of the DIST lanes before this one
+// Candidates inside a step (HD_INTRA_DIST): the nearest of the DIST lanes before this one
 // that holds the same four bytes `v`, as a distance (0 = none).  wave_shr:1 chains hand every lane the
 // value of lane - d; lanes below d see filler and are masked.
 template <int DIST>

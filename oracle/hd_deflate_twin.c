@@ -119,7 +119,7 @@ typedef struct {
 	unsigned hash_bits;
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
-	unsigned intra;       /* levels >= 3: candidates at distances 1..intra inside the step */
+	unsigned intra;       /* candidates at distances 1..intra inside the step (HD_INTRA_DIST) */
 } mf_t;
 
 typedef struct {
@@ -162,9 +162,9 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
 		cand[l] = (e && back) ? (uint32_t)(p + 1 - back) : 0;
 		/* The table only knows earlier steps, and DNA-like data is full of repeats a few bytes
-		 * apart (quality strings).  Levels >= 3: a lane also looks at the lanes just before it
-		 * in the same step; the nearest one with the same four bytes is the latest occurrence
-		 * and replaces the table's candidate (the kernel compares DPP-shifted copies). */
+		 * apart (quality strings).  A lane also looks at the lane(s) just before it in the same
+		 * step; the nearest one with the same four bytes is the latest occurrence and replaces
+		 * the table's candidate (the kernel compares DPP-shifted copies). */
 		for (unsigned d = 1; d <= mf->intra && d <= l; d++)
 			if (load32(in + p - d) == v) {
 				cand[l] = (uint32_t)(p - d + 1);
@@ -247,7 +247,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0 };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, HD_INTRA_DIST };
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
@@ -364,24 +364,24 @@ static void build_code(const uint32_t *freq_in, unsigned nsyms, unsigned maxbits
 	depth[2 * nu - 2] = 0;
 	for (int x = (int)(2 * nu - 3); x >= 0; x--)
 		depth[x] = (uint8_t)(depth[parent[x]] + 1);
-	/* level counts, overflow pushed up */
-	int overflow = 0;
-	for (unsigned x = 0; x < nu; x++) {
-		unsigned d = depth[x];
-		if (d > maxbits) {
-			d = maxbits;
-			overflow++;
-		}
-		blc[d]++;
-	}
-	while (overflow > 0) {
+	/* level counts: leaves deeper than maxbits are cut back to maxbits, which leaves the code
+	 * over-subscribed by `excess` codewords of length maxbits (Kraft sum in units of 2^-maxbits);
+	 * every pass below gives one of them back: a leaf moves one level down, a maxbits leaf becomes
+	 * its sibling.  (Counting the cut leaves, as deflate's gen_bitlen does after clamping depths
+	 * on the way down, is only right for leaves at maxbits + 1: a deeper one frees less.) */
+	for (unsigned x = 0; x < nu; x++)
+		blc[depth[x] > maxbits ? maxbits : depth[x]]++;
+	long excess = -(1L << maxbits);
+	for (unsigned bits = 1; bits <= maxbits; bits++)
+		excess += (long)blc[bits] << (maxbits - bits);
+	while (excess > 0) {
 		unsigned bits = maxbits - 1;
 		while (blc[bits] == 0)
 			bits--;
 		blc[bits]--;
 		blc[bits + 1] += 2;
 		blc[maxbits]--;
-		overflow -= 2;
+		excess--;
 	}
 	memset(h->len, 0, sizeof(h->len));
 	unsigned idx = 0;
@@ -651,7 +651,7 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, 0, flush);
+				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush);
 	if (level <= 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
 				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush);

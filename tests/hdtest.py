@@ -156,7 +156,20 @@ def corpus_small():
         "random_100": bytes(rnd[:100]),
         "mixed": bytes(fq[:20000]) + bytes(rnd[:20000]) + bytes(20000) + bytes(tx[:5280]),
         "bytes_0_255_x4": bytes(range(256)) * 4,
+        # Fibonacci literal frequencies, shuffled: a Huffman tree ~20 levels deep, i.e. leaves more than one
+        # level below the 15-bit limit (the length limiter once counted such a leaf like one at 16)
+        "fib_lits": _fib_literals(),
     }
+
+
+def _fib_literals():
+    a, b, parts = 1, 1, []
+    for k in range(21):
+        parts.append(np.full(a, 33 + k, dtype=np.uint8))
+        a, b = b, a + b
+    v = np.concatenate(parts)
+    np.random.default_rng(11).shuffle(v)
+    return v.tobytes()
 
 
 def corpus_fuzz(seed, count):

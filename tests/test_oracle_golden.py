@@ -236,3 +236,17 @@ def test_zlib_gzip_frames_match_reference_wrappers():
     assert bytes(buf[:n]).hex() == g["rfc1952"]["bytes"]
     assert o.hdo_zlib_frame(buf.ctypes.data, len(p) + 5, p.ctypes.data, len(p), 0) == 0
     assert o.hdo_gzip_frame(buf.ctypes.data, len(p) + 17, p.ctypes.data, len(p), 0, 0, 0) == 0
+
+
+@pytest.mark.parametrize("level", [2, 3, 6, 9])
+def test_twin_dynamic_codes_stay_valid_on_deep_trees(level):
+    """Code lengths are limited to 15 (litlen/offset) and 7 (precode) bits.  Inputs whose Huffman tree has
+    leaves more than one level below the limit (Fibonacci-like frequencies; the code-length alphabet of
+    run-heavy blocks) once came out over-subscribed -- bytes zlib and libdeflate reject.  Every fuzz block
+    and the Fibonacci block must inflate with zlib."""
+    import zlib
+    blocks = hdtest.corpus_fuzz(1003, 160) + hdtest.corpus_fuzz(7, 80) + [hdtest.corpus_small()["fib_lits"]]
+    for i, d in enumerate(blocks):
+        r, z = hdtest.oracle_twin(d, level)
+        assert r == 0, i
+        assert zlib.decompress(z, -15) == d, (i, len(d))
