@@ -643,6 +643,15 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	return ret;
 }
 
+/* test hook: the code lengths build_code() gives a frequency vector (tests/test_oracle_golden.py checks
+ * Kraft equality and the length limit on adversarial distributions) */
+void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, uint8_t *lens_out)
+{
+	huff_t h;
+	build_code(freq, nsyms, maxbits, &h);
+	memcpy(lens_out, h.len, nsyms);
+}
+
 static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
 {
 	if (level <= 0)

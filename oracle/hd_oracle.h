@@ -58,6 +58,9 @@ int hdo_store_deflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
  * *destLen, or non-zero when the result does not fit. */
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level);
+/* test hook: code lengths of the twin's Huffman construction for a frequency vector */
+void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, uint8_t *lens_out);
+
 /* ... in full-flush form (HD_FRAME_RAW_FLUSH; applet/7dictzip.c:93-126) */
 int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			   size_t sourceLen, int level);

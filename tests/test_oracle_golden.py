@@ -250,3 +250,39 @@ def test_twin_dynamic_codes_stay_valid_on_deep_trees(level):
         r, z = hdtest.oracle_twin(d, level)
         assert r == 0, i
         assert zlib.decompress(z, -15) == d, (i, len(d))
+
+
+def test_twin_code_lengths_are_complete_and_limited():
+    """hdo_build_lengths (the twin's Huffman construction, which the kernel mirrors): for Fibonacci and for
+    random / heavy-tailed frequency vectors over the three alphabets, every length <= the limit and the
+    Kraft sum exactly 1 (a complete prefix code: what zlib's inflate_table and libdeflate demand)."""
+    o = hdtest.oracle()
+    o.hdo_build_lengths.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
+
+    def lens(freq, maxbits):
+        f = np.array(freq, dtype=np.uint32)
+        out = np.zeros(len(f), dtype=np.uint8)
+        o.hdo_build_lengths(f.ctypes.data, len(f), maxbits, out.ctypes.data)
+        return out
+
+    def kraft(ls, maxbits):
+        return sum(1 << (maxbits - int(x)) for x in ls if x)
+
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    alphabets = [(19, 7), (32, 15), (288, 15)]
+    for nsym, maxbits in alphabets:
+        for k in range(2, min(nsym, 34) + 1):
+            ls = lens(fib[:k] + [0] * (nsym - k), maxbits)
+            assert max(ls) <= maxbits and kraft(ls, maxbits) == 1 << maxbits, (nsym, k)
+    rng = np.random.default_rng(3)
+    for t in range(3000):
+        nsym, maxbits = alphabets[t % 3]
+        k = int(rng.integers(1, nsym + 1))
+        f = np.zeros(nsym, dtype=np.uint32)
+        idx = rng.choice(nsym, k, replace=False)
+        f[idx] = [rng.integers(1, 5, k), (rng.pareto(0.5, k) * 3 + 1).clip(1, 30000).astype(np.uint32),
+                  np.array([fib[i % 30] for i in range(k)], dtype=np.uint32), rng.integers(1, 30000, k)][t % 4]
+        ls = lens(f, maxbits)
+        assert max(ls) <= maxbits and kraft(ls, maxbits) == 1 << maxbits, t
