@@ -44,7 +44,7 @@ EXPORTS = [
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
     "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
     "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
-    "hipdeflate_unpipe_result", "hipdeflate_unpipe_close",
+    "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
     L.hipdeflate_unpipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p]
     L.hipdeflate_unpipe_close.restype = None
     L.hipdeflate_unpipe_close.argtypes = [_vp]
+    L.hipdeflate_test_build_lengths.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]
     _lib = L
     return L
 

@@ -7,6 +7,7 @@
 #include <string.h>
 #include "../../include/hipdeflate.h"
 #include "hd_device.hpp"
+#include "hd_deflate_dynamic.hpp"
 
 namespace {
 
@@ -30,7 +31,43 @@ __global__ __launch_bounds__(64) void k_selftest_slots(uint32_t *out)
 	}
 }
 
+// one wavefront per frequency vector through the encoder's Huffman construction
+__global__ __launch_bounds__(64) void k_selftest_build(const uint32_t *freq, uint32_t nsyms, uint32_t maxbits, uint8_t *lens)
+{
+	__shared__ uint32_t f[288], o[288];
+	__shared__ hd::HuffScratch hs;
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t s = lane; s < nsyms; s += 64)
+		f[s] = freq[(size_t)blockIdx.x * nsyms + s];
+	hd::build_code(f, nsyms, maxbits, o, hs, lane);
+	for (uint32_t s = lane; s < nsyms; s += 64)
+		lens[(size_t)blockIdx.x * nsyms + s] = (uint8_t)(o[s] >> 16);
+}
+
 } // namespace
+
+/* test entry: code lengths the DEVICE Huffman construction gives `nvec` frequency vectors of `nsyms` symbols
+ * each (tests/test_gpu_parity.py compares them with the oracle's on adversarial distributions) */
+extern "C" int hipdeflate_test_build_lengths(const uint32_t *freq, uint32_t nvec, uint32_t nsyms, uint32_t maxbits,
+					     uint8_t *lens_out)
+{
+	int r = hipdeflate_available();
+	if (r)
+		return r;
+	if (!freq || !lens_out || !nvec || nsyms < 2 || nsyms > 288 || maxbits < 1 || maxbits > 15)
+		return HD_E_ARG;
+	uint32_t *df;
+	uint8_t *dl;
+	const size_t n = (size_t)nvec * nsyms;
+	if (hipMalloc((void **)&df, n * 4) != hipSuccess || hipMalloc((void **)&dl, n) != hipSuccess)
+		return HD_E_NOMEM;
+	(void)hipMemcpy(df, freq, n * 4, hipMemcpyHostToDevice);
+	hipLaunchKernelGGL(k_selftest_build, dim3(nvec), dim3(64), 0, 0, df, nsyms, maxbits, dl);
+	const hipError_t e = hipMemcpy(lens_out, dl, n, hipMemcpyDeviceToHost);
+	(void)hipFree(df);
+	(void)hipFree(dl);
+	return e == hipSuccess ? 0 : HD_E_NODEVICE;
+}
 
 extern "C" int hipdeflate_selftest(void)
 {

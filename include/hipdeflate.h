@@ -205,6 +205,10 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
 
 /* device self-test of the wave primitives (scan, CRC folding); 0 = pass */
 int hipdeflate_selftest(void);
+/* test entry: the code lengths the device's Huffman construction gives nvec frequency vectors of nsyms
+ * (2..288) symbols each under a length limit of maxbits (1..15); lens_out[nvec * nsyms] */
+int hipdeflate_test_build_lengths(const uint32_t *freq, uint32_t nvec, uint32_t nsyms, uint32_t maxbits,
+				  uint8_t *lens_out);
 
 #ifdef __cplusplus
 }

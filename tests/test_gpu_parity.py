@@ -550,3 +550,35 @@ def test_streaming_unpipe_matches_batch_api(pkg):
     ref = [hdtest.oracle_inflate(bytes(bad)[o:o + ln], isz)[0] for o, ln, isz in pkg.bgzf_scan(bytes(bad))]
     assert st != 0 or not any(ref)                   # the oracle decides whether that flip is detectable
     assert pkg.unpipe_decompress(pkg.bgzf_compress_bytes(b"", level=1), 4, 2) == (0, b"")
+
+
+def test_device_huffman_construction_matches_oracle_on_adversarial_frequencies(pkg):
+    """The kernels' build_code against the twin's (hdo_build_lengths, itself checked for complete, length-
+    limited codes in test_oracle_golden.py) on Fibonacci and heavy-tailed frequency vectors of the three
+    alphabets: the deep trees real data rarely produces."""
+    import ctypes
+    o = hdtest.oracle()
+    o.hdo_build_lengths.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(5)
+    for nsym, maxbits in ((19, 7), (32, 15), (288, 15)):
+        vecs = []
+        for k in range(2, min(nsym, 34) + 1):
+            vecs.append(fib[:k] + [0] * (nsym - k))
+        for t in range(400):
+            k = int(rng.integers(1, nsym + 1))
+            f = np.zeros(nsym, dtype=np.uint32)
+            idx = rng.choice(nsym, k, replace=False)
+            f[idx] = [rng.integers(1, 5, k), (rng.pareto(0.5, k) * 3 + 1).clip(1, 30000).astype(np.uint32),
+                      np.array([fib[i % 30] for i in range(k)], dtype=np.uint32), rng.integers(1, 30000, k)][t % 4]
+            vecs.append(list(f))
+        freq = np.array(vecs, dtype=np.uint32)
+        got = np.zeros(freq.shape, dtype=np.uint8)
+        assert pkg.lib().hipdeflate_test_build_lengths(freq.ctypes.data, len(vecs), nsym, maxbits, got.ctypes.data) == 0
+        for i in range(len(vecs)):
+            want = np.zeros(nsym, dtype=np.uint8)
+            row = np.ascontiguousarray(freq[i])
+            o.hdo_build_lengths(row.ctypes.data, nsym, maxbits, want.ctypes.data)
+            assert np.array_equal(got[i], want), (nsym, i)
