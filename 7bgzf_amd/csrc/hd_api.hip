@@ -179,8 +179,7 @@ int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
 	if (level <= 1) {
 		hd::DeflateArgs b = a;
 		b.level = level;
-		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false, HD_MIN_MATCH, 0, HD_INTRA_DIST>),
-				   dim3(a.nblocks), dim3(64), 0, st, b);
+		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false>), dim3(a.nblocks), dim3(64), 0, st, b);
 	} else {
 		int r = hd::launch_deflate_dynamic(a, level, st);
 		if (r)

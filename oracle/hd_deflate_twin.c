@@ -247,7 +247,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, HD_INTRA_DIST };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0 };                /* level 1 is the speed level: no run candidates */
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
