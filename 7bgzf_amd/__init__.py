@@ -45,6 +45,7 @@ EXPORTS = [
     "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
     "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
+    "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev",
 ]
 
 
@@ -92,13 +93,16 @@ def lib():
     L.hip_deflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hip_deflate_flush.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hip_inflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t]
+    L.hip_inflate_flush.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t]
     L.bgzf_compress.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hipdeflate_batch_deflate.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _vp,
                                            ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp]
     L.hipdeflate_batch_inflate.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hipdeflate_batch_inflate_flush.argtypes = L.hipdeflate_batch_inflate.argtypes
     L.hipdeflate_batch_deflate_dev.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _vp,
                                                ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, _vp, _vp]
     L.hipdeflate_batch_inflate_dev.argtypes = [_vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hipdeflate_batch_inflate_flush_dev.argtypes = L.hipdeflate_batch_inflate_dev.argtypes
     L.hipdeflate_scan_sizes_dev.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint64, _vp, _vp, _vp]
     L.hipdeflate_compact_dev.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, ctypes.c_uint32, _vp, _vp]
     L.hipdeflate_pipe_open.restype = _vp
@@ -185,6 +189,16 @@ def hip_inflate(data, cap):
     return r, bytes(dst[: n.value]) if r == 0 else b""
 
 
+def hip_inflate_flush(data, cap):
+    """-> (ret, bytes) for a full-flushed chunk (no final block): the decoder side of
+    hip_deflate_flush, as zlib_inflate / igzip_inflate in applet/7dictzip.c:318-323."""
+    src = as_u8(data)
+    dst = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = ctypes.c_size_t(cap)
+    r = lib().hip_inflate_flush(_p(dst), ctypes.byref(n), _p(src), len(src))
+    return r, bytes(dst[: n.value]) if r == 0 else b""
+
+
 def pipe_compress(data, level=1, frame=FRAME_BGZF, block=0xff00, per_batch=64, depth=3):
     """Run `data` through the streaming encoder (hipdeflate_pipe_*): as many batches in flight as the
     pipe allows before results are fetched.  -> the concatenated members (no EOF member)."""
@@ -265,8 +279,9 @@ def batch_deflate(data, offs, lens, level=1, frame=FRAME_RAW, slot=None):
     return members, crc, st
 
 
-def batch_inflate(streams, caps, want_crc=True):
-    """Inflate a list of raw-DEFLATE streams.  -> (outputs list, crc32 array, status array)."""
+def batch_inflate(streams, caps, want_crc=True, flushed=False):
+    """Inflate a list of raw-DEFLATE streams.  -> (outputs list, crc32 array, status array).
+    flushed: the streams are full-flushed chunks (hipdeflate_batch_inflate_flush)."""
     nb = len(streams)
     ilen = np.array([len(s) for s in streams], dtype=np.uint32)
     ioff = np.zeros(nb, dtype=np.uint64)
@@ -281,8 +296,9 @@ def batch_inflate(streams, caps, want_crc=True):
     olen = np.zeros(nb, dtype=np.uint32)
     crc = np.zeros(nb, dtype=np.uint32)
     st = np.zeros(nb, dtype=np.int32)
-    _check(lib().hipdeflate_batch_inflate(_p(src), _p(ioff), _p(ilen), nb, _p(out), _p(ooff), _p(caps), _p(olen),
-                                          _p(crc) if want_crc else None, _p(st)), "hipdeflate_batch_inflate")
+    fn = lib().hipdeflate_batch_inflate_flush if flushed else lib().hipdeflate_batch_inflate
+    _check(fn(_p(src), _p(ioff), _p(ilen), nb, _p(out), _p(ooff), _p(caps), _p(olen),
+              _p(crc) if want_crc else None, _p(st)), "hipdeflate_batch_inflate")
     outs = [bytes(out[int(ooff[i]): int(ooff[i]) + int(olen[i])]) if st[i] == 0 else b"" for i in range(nb)]
     return outs, crc, st
 

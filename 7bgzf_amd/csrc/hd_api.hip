@@ -291,9 +291,9 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	return launch_deflate(a, level, (hipStream_t)stream);
 }
 
-int hipdeflate_batch_inflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
-				 const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status,
-				 void *stream)
+static int batch_inflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
+			     const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status, void *stream,
+			     uint32_t flags)
 {
 	int r = ensure();
 	if (r)
@@ -314,9 +314,25 @@ int hipdeflate_batch_inflate_dev(const void *in, const void *in_off, const void 
 	a.crc = (uint32_t *)crc32;
 	a.status = (int32_t *)status;
 	a.ct = g.d_ct;
+	a.flags = flags;
 	hipLaunchKernelGGL(hd::k_inflate, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, a);
 	HD_CHECK(hipGetLastError());
 	return 0;
+}
+
+int hipdeflate_batch_inflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
+				 const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status,
+				 void *stream)
+{
+	return batch_inflate_dev(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, crc32, status, stream, 0);
+}
+
+int hipdeflate_batch_inflate_flush_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
+				       const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status,
+				       void *stream)
+{
+	return batch_inflate_dev(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, crc32, status, stream,
+				 hd::INF_FLUSHED);
 }
 
 int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t base, void *dst_off, void *total,
@@ -468,9 +484,9 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 	return 0;
 }
 
-int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
-			     uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
-			     uint32_t *crc32, int32_t *status)
+static int batch_inflate_host(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
+			      uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+			      uint32_t *crc32, int32_t *status, uint32_t flags)
 {
 	int r = ensure();
 	if (r)
@@ -517,8 +533,8 @@ int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const ui
 	int32_t *d_st = (int32_t *)(d_crc + nblocks);
 	HD_CHECK(hipMemcpyAsync(g.d_in.p, hin, in_total, hipMemcpyHostToDevice, g.stream));
 	HD_CHECK(hipMemcpyAsync(dm, g.h_meta.p, (size_t)nblocks * 24, hipMemcpyHostToDevice, g.stream));
-	r = hipdeflate_batch_inflate_dev(g.d_in.p, d_ioff, d_ilen, nblocks, g.d_slots.p, d_ooff, d_ocap, d_olen,
-					 crc32 ? d_crc : nullptr, d_st, g.stream);
+	r = batch_inflate_dev(g.d_in.p, d_ioff, d_ilen, nblocks, g.d_slots.p, d_ooff, d_ocap, d_olen, crc32 ? d_crc : nullptr,
+			      d_st, g.stream, flags);
 	if (r)
 		return r;
 	uint32_t *h_olen = (uint32_t *)g.h_meta.p + 6 * (size_t)nblocks;     // past the 24 B/blk inputs
@@ -537,6 +553,20 @@ int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const ui
 			memcpy(out + out_off[i], (const uint8_t *)g.h_out.p + h_ooff[i], h_olen[i]);
 	}
 	return 0;
+}
+
+int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
+			     uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+			     uint32_t *crc32, int32_t *status)
+{
+	return batch_inflate_host(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, crc32, status, 0);
+}
+
+int hipdeflate_batch_inflate_flush(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,
+				   uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+				   uint32_t *crc32, int32_t *status)
+{
+	return batch_inflate_host(in, in_off, in_len, nblocks, out, out_off, out_cap, out_len, crc32, status, hd::INF_FLUSHED);
 }
 
 /* ---- streaming encoder ---------------------------------------------------------- */
@@ -941,7 +971,7 @@ int hip_deflate_flush(unsigned char *dest, size_t *destLen, const unsigned char 
 	return deflate_one(dest, destLen, source, sourceLen, level, HD_FRAME_RAW_FLUSH);
 }
 
-int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)
+static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, uint32_t flags)
 {
 	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xfffffff0u)
 		return HD_E_ARG;
@@ -949,13 +979,23 @@ int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *sourc
 	uint32_t ilen = (uint32_t)sourceLen, olen = 0;
 	uint32_t ocap = *destLen > 0xfffffff0u ? 0xfffffff0u : (uint32_t)*destLen;
 	int32_t st = 0;
-	int r = hipdeflate_batch_inflate(source, &ioff, &ilen, 1, dest, &ooff, &ocap, &olen, nullptr, &st);
+	int r = batch_inflate_host(source, &ioff, &ilen, 1, dest, &ooff, &ocap, &olen, nullptr, &st, flags);
 	if (r)
 		return r;
 	if (st)
 		return st;
 	*destLen = olen;
 	return 0;
+}
+
+int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)
+{
+	return inflate_one(dest, destLen, source, sourceLen, 0);
+}
+
+int hip_inflate_flush(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)
+{
+	return inflate_one(dest, destLen, source, sourceLen, hd::INF_FLUSHED);
 }
 
 } // extern "C"

@@ -39,7 +39,13 @@ struct InflateArgs {
 	uint32_t *crc;
 	int32_t *status;
 	const CrcTables *ct;
+	uint32_t flags;
 };
+
+// InflateArgs::flags: a stream may stop after a non-final block once every input byte is used -- the chunks of
+// 7dictzip / 7razf end in a full-flush marker, not in a final block, and the reference reads them with inflaters
+// that report "out of input" as success (zlib_inflate, lib/zlibutil.c:289-291; igzip_inflate, zlibutil_igzip.c:111)
+constexpr uint32_t INF_FLUSHED = 1;
 
 constexpr uint32_t INF_LT_BITS = 9;      // litlen direct table (8 VGPRs once loaded)
 constexpr uint32_t INF_DT_BITS = 8;      // offset direct table
@@ -732,6 +738,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				break;
 		}
 		if (bfinal)
+			break;
+		if ((a.flags & INF_FLUSHED) && consumed_bits() <= 8 * (int64_t)n && consumed_bits() + 7 >= 8 * (int64_t)n)
 			break;
 		if (consumed_bits() > 8 * (int64_t)n + 64) { st = HD_BAD_DATA; break; }
 	}

@@ -86,6 +86,14 @@ int hip_inflate(unsigned char *dest, size_t *destLen,
 int hip_deflate_flush(unsigned char *dest, size_t *destLen,
 		      const unsigned char *source, size_t sourceLen, int level);
 
+/* The decoder for such chunks -- the role zlib_inflate / igzip_inflate play in the
+ * readers of 7dictzip (applet/7dictzip.c:318-323) and 7razf: a chunk has no final
+ * block, so the stream may also stop after a non-final block once every source byte
+ * has been used (lib/zlibutil.c:289-291, lib/zlibutil_igzip.c:111: "out of input" is
+ * success there).  Input that runs out inside a block is still HD_BAD_DATA. */
+int hip_inflate_flush(unsigned char *dest, size_t *destLen,
+		      const unsigned char *source, size_t sourceLen);
+
 /* ---- batch API, host buffers ------------------------------------------- */
 
 /* Compress nblocks independent blocks.  Block i is in[in_off[i] .. +in_len[i]).
@@ -111,6 +119,13 @@ int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off,
 			     const uint32_t *out_cap,
 			     uint32_t *out_len, uint32_t *crc32, int32_t *status);
 
+/* hipdeflate_batch_inflate with hip_inflate_flush's stopping rule */
+int hipdeflate_batch_inflate_flush(const uint8_t *in, const uint64_t *in_off,
+				   const uint32_t *in_len, uint32_t nblocks,
+				   uint8_t *out, const uint64_t *out_off,
+				   const uint32_t *out_cap,
+				   uint32_t *out_len, uint32_t *crc32, int32_t *status);
+
 /* ---- batch API, device-resident buffers --------------------------------- */
 /* Same contracts, every pointer is a DEVICE address (hipMalloc'd, or a torch
  * CUDA tensor's data_ptr()); `stream` is a hipStream_t (NULL = default stream).
@@ -127,6 +142,12 @@ int hipdeflate_batch_inflate_dev(const void *in, const void *in_off,
 				 void *out, const void *out_off, const void *out_cap,
 				 void *out_len, void *crc32, void *status,
 				 void *stream);
+
+int hipdeflate_batch_inflate_flush_dev(const void *in, const void *in_off,
+				       const void *in_len, uint32_t nblocks,
+				       void *out, const void *out_off, const void *out_cap,
+				       void *out_len, void *crc32, void *status,
+				       void *stream);
 
 /* Gather the variable-length members produced by batch_deflate_dev into one
  * contiguous stream: member i (out_len[i] bytes at slots + i*stride) goes to

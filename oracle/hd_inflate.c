@@ -135,12 +135,24 @@ static const uint8_t  precode_order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11
 	13, 2, 14, 1, 15 };
 
 static int inflate_ex(uint8_t *dest, size_t *destLen, const uint8_t *source,
-		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit);
+		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit, int flushed);
 
 int hdo_inflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		size_t sourceLen, uint64_t *consumed_bits)
 {
-	return inflate_ex(dest, destLen, source, sourceLen, consumed_bits, NULL);
+	return inflate_ex(dest, destLen, source, sourceLen, consumed_bits, NULL, 0);
+}
+
+/* The inflate the reference's 7dictzip / 7razf readers get from zlib_inflate
+ * (lib/zlibutil.c:266-300: Z_BUF_ERROR, i.e. out of input, ends the loop and is
+ * success) and igzip_inflate (lib/zlibutil_igzip.c:93-119: ISAL_END_INPUT is
+ * success) on a full-flushed chunk, which has no final block: the stream may stop
+ * after a non-final block when every input byte has been used.  Stricter than the
+ * reference on purpose -- input that runs out INSIDE a block stays HD_BAD_DATA. */
+int hdo_inflate_flushed(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			size_t sourceLen, uint64_t *consumed_bits)
+{
+	return inflate_ex(dest, destLen, source, sourceLen, consumed_bits, NULL, 1);
 }
 
 /* Restatement of zlibutil_buffer_full_flush (applet/7dictzip.c:93-126,
@@ -155,7 +167,7 @@ int hdo_full_flush(uint8_t *stream, size_t *len, size_t cap, size_t max_out)
 	uint64_t end = 0, hdr = 0;
 	size_t outlen = max_out;
 	uint8_t *tmp = malloc(max_out ? max_out : 1);
-	int r = inflate_ex(tmp, &outlen, stream, *len, &end, &hdr);
+	int r = inflate_ex(tmp, &outlen, stream, *len, &end, &hdr, 0);
 	free(tmp);
 	if (r)
 		return r;
@@ -172,7 +184,7 @@ int hdo_full_flush(uint8_t *stream, size_t *len, size_t cap, size_t max_out)
 }
 
 static int inflate_ex(uint8_t *dest, size_t *destLen, const uint8_t *source,
-		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit)
+		      size_t sourceLen, uint64_t *consumed_bits, uint64_t *last_header_bit, int flushed)
 {
 	bits_t b = { source, (uint64_t)sourceLen * 8, 0 };
 	size_t cap = *destLen, out = 0;
@@ -283,6 +295,8 @@ static int inflate_ex(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			}
 		}
 		if (bfinal)
+			break;
+		if (flushed && b.pos <= b.nbits && b.pos + 7 >= b.nbits)
 			break;
 		if (overrun(&b))
 			return HD_BAD_DATA;

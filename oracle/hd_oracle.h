@@ -44,6 +44,11 @@ uint32_t hdo_adler32(uint32_t adler, const uint8_t *buf, size_t n);
 int hdo_inflate(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		size_t sourceLen, uint64_t *consumed_bits);
 
+/* Same, for a full-flushed chunk (no final block): success when the input is used
+ * up at a block boundary (zlib_inflate / igzip_inflate as 7dictzip.c:318-323 uses them). */
+int hdo_inflate_flushed(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			size_t sourceLen, uint64_t *consumed_bits);
+
 /* zlibutil_buffer_full_flush (applet/7dictzip.c:93-126) applied to a finished raw
  * stream in place: BFINAL of the last block cleared, empty stored block appended.
  * *len in = stream bytes, out = new length; cap = room in `stream`. */

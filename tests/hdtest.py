@@ -53,6 +53,7 @@ def oracle():
         lib.hdo_adler32.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
         lib.hdo_inflate.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64)]
+        lib.hdo_inflate_flushed.argtypes = lib.hdo_inflate.argtypes
         lib.hdo_deflate_twin.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_int]
         lib.hdo_deflate_twin_flush.argtypes = lib.hdo_deflate_twin.argtypes
@@ -116,6 +117,10 @@ def call_dec(func, data, cap, extra_arg=False):
 
 def oracle_inflate(data, cap):
     return call_dec(oracle().hdo_inflate, data, cap, extra_arg=True)
+
+
+def oracle_inflate_flushed(data, cap):
+    return call_dec(oracle().hdo_inflate_flushed, data, cap, extra_arg=True)
 
 
 def oracle_twin(data, level, cap=None):

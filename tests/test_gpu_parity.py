@@ -94,6 +94,57 @@ def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
         assert r != 0, k
 
 
+def test_inflate_flushed_chunks_match_oracle(pkg):
+    """hip_inflate_flush / hipdeflate_batch_inflate_flush: verdict, bytes and CRC identical to the oracle's
+    hdo_inflate_flushed on (a) the reference's own 7dictzip chunks (golden full_flush.json), (b) our
+    encoder's flush form at every level, (c) final-block streams, (d) chunks cut short and bit-flipped
+    chunks; and the strict entry point keeps refusing a chunk (applet/7dictzip.c:319)."""
+    import base64
+    import json
+    import os
+    corpus = hdtest.corpus_small()
+    streams, caps, want = [], [], []
+    for v in json.load(open(os.path.join(hdtest.GOLDEN, "full_flush.json"))):
+        chunk = base64.b64decode(v["flushed"])
+        data = corpus[v["input"]]
+        streams += [chunk, base64.b64decode(v["stream"]), chunk[:-1], chunk[: len(chunk) // 2], chunk + chunk]
+        caps += [len(data), len(data), len(data), len(data), 2 * len(data)]
+    for level in (0, 1, 2, 6):
+        for k in ("fastq_777", "text_5000", "random_100", "empty", "zeros_64k", "mixed"):
+            if k not in corpus:
+                continue
+            r, z = hdtest.oracle_twin_flush(corpus[k], level)
+            assert r == 0
+            streams += [z, z + z, z[:-2]]
+            caps += [len(corpus[k]), 2 * len(corpus[k]), len(corpus[k])]
+    rng = np.random.default_rng(5)
+    base = hdtest.oracle_twin_flush(corpus["text_5000"], 6)[1]
+    for _ in range(200):
+        m = bytearray(base)
+        bit = int(rng.integers(0, len(m) * 8))
+        m[bit >> 3] ^= 1 << (bit & 7)
+        streams.append(bytes(m))
+        caps.append(len(corpus["text_5000"]) + 64)
+    outs, crc, st = pkg.batch_inflate(streams, caps, flushed=True)
+    ok = 0
+    for i, z in enumerate(streams):
+        r, out = hdtest.oracle_inflate_flushed(z, caps[i])
+        assert (int(st[i]) == 0) == (r == 0), (i, int(st[i]), r)
+        if r == 0:
+            assert outs[i] == out and int(crc[i]) == hdtest.oracle_crc32(out), i
+            ok += 1
+    assert 100 < ok < len(streams)
+    # the same chunks through the strict reader: refused unless they end in a final block
+    outs2, _, st2 = pkg.batch_inflate(streams, caps)
+    for i, z in enumerate(streams):
+        r, out = hdtest.oracle_inflate(z, caps[i])
+        assert (int(st2[i]) == 0) == (r == 0), i
+    chunk = hdtest.oracle_twin_flush(corpus["fastq_777"], 1)[1]
+    r, out = pkg.hip_inflate_flush(chunk, len(corpus["fastq_777"]))
+    assert r == 0 and out == corpus["fastq_777"]
+    assert pkg.hip_inflate(chunk, len(corpus["fastq_777"]))[0] != 0
+
+
 @pytest.mark.parametrize("level", [0, 1, 2, 3, 6])
 def test_encode_zlib_and_gzip_frames(pkg, level):
     """HD_FRAME_ZLIB / HD_FRAME_GZIP: member == the oracle's wrapper (pinned against the reference's

@@ -53,6 +53,56 @@ def test_migz_framing_roundtrip():
         assert p.returncode == 0 and p.stdout == data
 
 
+DZ = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7dictzip")
+
+
+@pytest.mark.parametrize("level,extreme", [(1, False), (6, False), (2, True), (0, False)])
+def test_dictzip_writer_and_reader_against_the_reference(tmp_path, level, extreme):
+    """hd7dictzip (applet/7dictzip.c re-shaped into batches): the file is a plain gzip member (Python's
+    gzip checks CRC-32 and ISIZE, which come from folding the kernel's per-chunk CRCs), carries the 'RA'
+    chunk table, every chunk is the kernel's full-flush form (== twin), the REAL reference's 7dictzip
+    reads it, and we read the reference's file."""
+    import struct
+    assert os.path.exists(DZ)
+    bs = 0xff00 if extreme else 58315
+    data = bytes(hdtest.synth().fastq_like(9 * bs + 4321, seed=31)) + bytes(hdtest.synth().random_bytes(bs + 5))
+    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.dz")
+    open(fi, "wb").write(data)
+    p = subprocess.run([DZ, "-G%d" % level] + (["-X"] if extreme else []) + [fi, fo], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "compression level = %d (hip)" % level in p.stderr.decode() and "done." in p.stderr.decode()
+    d = open(fo, "rb").read()
+    assert gzip.decompress(d) == data
+    nchunks = (len(data) + bs - 1) // bs
+    assert d[:10] == bytes.fromhex("1f8b0804000000000003")
+    xlen, ra, sublen, ver, chlen, chcnt = struct.unpack("<H2sHHHH", d[10:22])
+    assert (xlen, ra, sublen, ver, chlen, chcnt) == (10 + 2 * nchunks, b"RA", 6 + 2 * nchunks, 1, bs, nchunks)
+    sizes = struct.unpack("<%dH" % nchunks, d[22:22 + 2 * nchunks])
+    pos = 22 + 2 * nchunks
+    for i, n in enumerate(sizes):
+        r, twin = hdtest.oracle_twin_flush(data[i * bs:(i + 1) * bs], level)
+        assert r == 0 and d[pos:pos + n] == twin, i
+        pos += n
+    assert d[pos:pos + 2] == b"\x03\x00" and len(d) == pos + 10
+    p = subprocess.run([DZ, "-d", fo], capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+    # damage: a flipped bit in a chunk or in the CRC is reported
+    bad = bytearray(d)
+    bad[-5] ^= 1
+    open(fo, "wb").write(bytes(bad))
+    p = subprocess.run([DZ, "-d", fo], capture_output=True, timeout=300)
+    assert p.returncode != 0 and "mismatch" in p.stderr.decode()
+    if os.path.exists(REF):
+        open(fo, "wb").write(d)
+        p = subprocess.run([REF, "7dictzip", "-cd", fo], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data
+        fr = str(tmp_path / "ref.dz")
+        p = subprocess.run([REF, "7dictzip", "-cl6"] + (["-X"] if extreme else []) + [fi, fr], capture_output=True, timeout=300)
+        assert p.returncode == 0
+        p = subprocess.run([DZ, "-d", fr], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+
+
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err

@@ -192,6 +192,32 @@ def test_full_flush_matches_reference_dictzip_chunks():
     assert 0 < extra < len(vects)      # both shapes of the suffix are covered
 
 
+def test_inflate_flushed_reads_reference_dictzip_chunks():
+    """hdo_inflate_flushed (the role of zlib_inflate / igzip_inflate at applet/7dictzip.c:318-323) on the
+    chunks the reference's own 7dictzip wrote: the same bytes the reference's final-block stream inflates
+    to; the strict inflate (libdeflate's contract) refuses a chunk, as the reference notes at :319; a chunk
+    cut inside a block stays an error (stricter than the reference, which takes whatever came out)."""
+    vects = json.load(open(os.path.join(hdtest.GOLDEN, "full_flush.json")))
+    corpus = hdtest.corpus_small()
+    for v in vects:
+        z, chunk = base64.b64decode(v["stream"]), base64.b64decode(v["flushed"])
+        data = corpus[v["input"]]
+        r, out = hdtest.oracle_inflate(z, len(data))
+        assert r == 0 and out == data
+        r, out = hdtest.oracle_inflate_flushed(chunk, len(data))
+        assert r == 0 and out == data, (v["input"], v["encoder"], v["level"])
+        assert hdtest.oracle_inflate(chunk, len(data))[0] != 0
+        assert hdtest.oracle_inflate_flushed(chunk[:-1], len(data))[0] != 0
+        if len(chunk) > 12:
+            assert hdtest.oracle_inflate_flushed(chunk[: len(chunk) // 2], len(data))[0] != 0
+        # a classic dictzip's last chunk ends in a final block: the flushed reader takes that too
+        r, out = hdtest.oracle_inflate_flushed(z, len(data))
+        assert r == 0 and out == data
+        # chunks of a run, concatenated up to a block boundary, are one valid flushed stream
+        r, out = hdtest.oracle_inflate_flushed(chunk + chunk, 2 * len(data))
+        assert r == 0 and out == data + data
+
+
 @pytest.mark.parametrize("level", [0, 1, 3, 6])
 def test_twin_flush_form_is_full_flush_of_twin(level):
     """The twin's flush form == hdo_full_flush(the twin's ordinary stream) whenever the ordinary

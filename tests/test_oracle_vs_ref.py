@@ -96,3 +96,33 @@ def test_store_and_framing_vs_reference(ref):
         ln = ctypes.c_size_t(n + 100)
         r2 = o.hdo_store_deflate(dst.ctypes.data, ctypes.byref(ln), a.ctypes.data, n)
         assert r1 == r2 == 0 and bytes(dst[: ln.value]) == z1
+
+
+def test_inflate_flushed_matches_reference_chunk_readers(ref):
+    """hdo_inflate_flushed against the two inflaters the reference's 7dictzip / 7razf readers use on
+    full-flushed chunks (zlib_inflate, lib/zlibutil.c:266-300; igzip_inflate, lib/zlibutil_igzip.c:93-119),
+    on chunks made from every reference encoder's stream by the oracle's own restatement of
+    zlibutil_buffer_full_flush (itself pinned to the reference's chunks in test_oracle_golden)."""
+    o = hdtest.oracle()
+    o.hdo_full_flush.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.c_size_t]
+    s = hdtest.synth()
+    inputs = [bytes(s.fastq_like(58315, seed=21)), bytes(s.text_like(20000, seed=22)), b"q" * 5000, bytes(s.random_bytes(3000))]
+    n_checked = 0
+    for data in inputs:
+        for name, level in ENC:
+            r, z = hdtest.call_enc(getattr(ref, name + "_deflate"), data, level, cap=2 * len(data) + 1000)
+            assert r == 0
+            buf = np.zeros(len(z) + 8, dtype=np.uint8)
+            buf[: len(z)] = np.frombuffer(z, dtype=np.uint8)
+            n = ctypes.c_size_t(len(z))
+            assert o.hdo_full_flush(buf.ctypes.data, ctypes.byref(n), len(buf), len(data) + 1) == 0
+            chunk = bytes(buf[: n.value])
+            for fn in (ref.zlib_inflate, ref.igzip_inflate):
+                r_ref, o_ref = hdtest.call_dec(fn, chunk, len(data))
+                assert r_ref == 0 and o_ref == data
+            r_our, o_our = hdtest.oracle_inflate_flushed(chunk, len(data))
+            assert r_our == 0 and o_our == data
+            assert hdtest.call_dec(ref.libdeflate_inflate, chunk, len(data))[0] != 0     # applet/7dictzip.c:319
+            assert hdtest.oracle_inflate(chunk, len(data))[0] != 0
+            n_checked += 1
+    assert n_checked == len(inputs) * len(ENC)
