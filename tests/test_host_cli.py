@@ -103,6 +103,62 @@ def test_dictzip_writer_and_reader_against_the_reference(tmp_path, level, extrem
         assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
 
 
+RZ = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7razf")
+
+
+@pytest.mark.parametrize("level,nbytes", [(1, 9 * 32768 + 4321), (6, 32768), (3, 100), (0, 3 * 32768)])
+def test_razf_writer_and_reader_against_the_reference(tmp_path, level, nbytes):
+    """hd7razf (applet/7razf.c in batches): one gzip member (zlib checks CRC-32 / ISIZE) + big-endian index;
+    every chunk but the last is the kernel's full-flush form, the last its ordinary stream (== twin); the
+    index is what the reference writes for the same chunk sizes; the REAL 7razf reads it, we read its."""
+    import struct
+    import zlib
+    assert os.path.exists(RZ)
+    data = (bytes(hdtest.synth().fastq_like(nbytes, seed=41)) + bytes(hdtest.synth().random_bytes(40000)))[:nbytes]
+    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.raz")
+    open(fi, "wb").write(data)
+    p = subprocess.run([RZ, "-G%d" % level, fi], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = p.stdout
+    open(fo, "wb").write(d)
+    assert d[:19] == bytes.fromhex("1f8b0804000000000003070052415a46018000")
+    z = zlib.decompressobj(31)
+    assert z.decompress(d) == data
+    nchunks = (len(data) + 32767) // 32768
+    total, index_at = struct.unpack(">QQ", d[-16:])
+    assert total == len(data) and len(z.unused_data) == len(d) - index_at
+    tb = struct.unpack(">I", d[index_at:index_at + 4])[0]
+    assert tb == nchunks - 1 and len(d) == index_at + 4 + 8 + 4 * tb + 16
+    bin0 = struct.unpack(">Q", d[index_at + 4:index_at + 12])[0]
+    cells = struct.unpack(">%dI" % tb, d[index_at + 12:index_at + 12 + 4 * tb])
+    pos = 19
+    for k in range(nchunks):
+        chunk = data[k * 32768:(k + 1) * 32768]
+        r, twin = (hdtest.oracle_twin_flush if k < nchunks - 1 else hdtest.oracle_twin)(chunk, level)
+        assert r == 0 and d[pos:pos + len(twin)] == twin, k
+        if k >= 1:
+            assert bin0 + cells[k - 1] == pos
+        pos += len(twin)
+    assert pos + 8 == index_at
+    p = subprocess.run([RZ, "-d", fo], capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+    bad = bytearray(d)
+    bad[index_at - 6] ^= 4
+    open(fo, "wb").write(bytes(bad))
+    p = subprocess.run([RZ, "-d", fo], capture_output=True, timeout=300)
+    assert p.returncode != 0 and "mismatch" in p.stderr.decode()
+    if os.path.exists(REF):
+        open(fo, "wb").write(d)
+        p = subprocess.run([REF, "7razf", "-cd", fo], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data
+        p = subprocess.run([REF, "7razf", "-cl6", fi], capture_output=True, timeout=300)
+        assert p.returncode == 0
+        fr = str(tmp_path / "ref.raz")
+        open(fr, "wb").write(p.stdout)
+        p = subprocess.run([RZ, "-d", fr], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+
+
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err
