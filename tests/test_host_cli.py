@@ -159,6 +159,55 @@ def test_razf_writer_and_reader_against_the_reference(tmp_path, level, nbytes):
         assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
 
 
+GZA = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7gzinga")
+
+
+@pytest.mark.parametrize("level,nbytes", [(1, 7 * 102400 + 999), (6, 102400), (2, 0), (0, 2 * 102400)])
+def test_gzinga_writer_and_reader_against_the_reference(tmp_path, level, nbytes):
+    """hd7gzinga (applet/7gzinga.c in batches): 100 KiB members with an empty comment + the index member;
+    a plain gzip reader reads the whole file, every member's payload == twin, the index text is the
+    reference's, the REAL 7gzinga reads it and we read its."""
+    assert os.path.exists(GZA)
+    data = (bytes(hdtest.synth().text_like(nbytes, seed=51)) + bytes(hdtest.synth().random_bytes(3000)))[:nbytes]
+    fo = str(tmp_path / "out.gz")
+    p = subprocess.run([GZA, "-G%d" % level], input=data, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = p.stdout
+    open(fo, "wb").write(d)
+    assert gzip.decompress(d) == data
+    pos, ends = 0, []
+    for k in range((len(data) + 102399) // 102400):
+        chunk = data[k * 102400:(k + 1) * 102400]
+        r, twin = hdtest.oracle_twin(chunk, level)
+        assert r == 0
+        member = bytes.fromhex("1f8b08100000000000ff00") + twin + hdtest.oracle_crc32(chunk).to_bytes(4, "little") + \
+            len(chunk).to_bytes(4, "little")
+        assert d[pos:pos + len(member)] == member, k
+        pos += len(member)
+        ends.append(pos)
+    index = bytes.fromhex("1f8b08100000000000ff") + "".join("%d:%d;" % (k, e) for k, e in enumerate(ends)).encode() + \
+        bytes.fromhex("0003000000000000000000")
+    assert d[pos:] == index
+    p = subprocess.run([GZA, "-d", fo], capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+    if nbytes:
+        bad = bytearray(d)
+        bad[ends[0] - 7] ^= 1                                        # a CRC-32 byte of the first member
+        open(fo, "wb").write(bytes(bad))
+        p = subprocess.run([GZA, "-d", fo], capture_output=True, timeout=300)
+        assert p.returncode != 0 and "mismatch" in p.stderr.decode()
+    if os.path.exists(REF) and nbytes:
+        open(fo, "wb").write(d)
+        p = subprocess.run([REF, "7gzinga", "-cd", fo], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data
+        p = subprocess.run([REF, "7gzinga", "-cl6"], input=data, capture_output=True, timeout=300)
+        assert p.returncode == 0
+        fr = str(tmp_path / "ref.gz")
+        open(fr, "wb").write(p.stdout)
+        p = subprocess.run([GZA, "-d", fr], capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+
+
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err
