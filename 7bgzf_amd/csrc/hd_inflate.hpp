@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	// (~10 SALU per token), literals are stored in parallel at positions from a
 	// DPP prefix sum, matches are copied in order.  A window is entered only
 	// when nothing rare can happen inside it: five whole dwords of stream ahead,
-	// room for the largest output, less than a piece waiting for the flush.
+	// some room in the output (the window's budget), less than a piece waiting for the flush.
 	// Returns 0 = fall back to the scalar loop for one token, 1 = end of block
 	// consumed, 2 = error (st set).  Reader state is the scalar one on both sides.
 	// output budget of one window: pending <= 1023 + 704 = 1727 <= INF_RING - 64 - 257, so a source is
@@ -336,7 +336,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			if (pos - flushed >= HD_PIECE)
 				flush_pieces();
 			const uint32_t d0 = B >> 5;
-			if (!(d0 + 7 <= dw_safe && pos + WIN_OUT_BUDGET + HD_MAX_MATCH <= cap))
+			// the budget shrinks to the room that is left, so windows run up to the last bytes of the
+			// output (a token that does not fit is cut below and meets the scalar loop's checks)
+			const uint32_t budget = cap - pos < WIN_OUT_BUDGET ? cap - pos : WIN_OUT_BUDGET;
+			if (!(d0 + 7 <= dw_safe && budget != 0))
 				break;
 			// the stream bits come from an LDS copy of the pieces around d0 (every lane
 			// reads its own dwords: no scalar gather)
@@ -417,8 +420,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// output positions; cut in front of the first token that would overrun the budget
 			const uint32_t incl0 = wave_incl_scan(((real0 >> lane) & 1) ? s0.outlen : 0u);
 			const uint32_t incl1 = wave_incl_scan(((real1 >> lane) & 1) ? s1.outlen : 0u) + readlane(incl0, 63);
-			const uint64_t over0 = __ballot(((real0 >> lane) & 1) && incl0 > WIN_OUT_BUDGET);
-			const uint64_t over1 = __ballot(((real1 >> lane) & 1) && incl1 > WIN_OUT_BUDGET);
+			const uint64_t over0 = __ballot(((real0 >> lane) & 1) && incl0 > budget);
+			const uint64_t over1 = __ballot(((real1 >> lane) & 1) && incl1 > budget);
 			if (over0 | over1) {
 				if (over0) {
 					b = (uint32_t)__ffsll((unsigned long long)over0) - 1;

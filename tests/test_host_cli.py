@@ -208,6 +208,53 @@ def test_gzinga_writer_and_reader_against_the_reference(tmp_path, level, nbytes)
         assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
 
 
+CS = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7ciso")
+
+
+@pytest.mark.parametrize("level,threshold", [(1, 100), (6, 100), (2, 50)])
+def test_ciso_writer_and_reader_against_the_reference(tmp_path, level, threshold):
+    """hd7ciso (applet/7ciso.c in batches): 2048-byte sectors, the tiny-block end of the path (several
+    thousand blocks per call).  Header and offset table as the reference lays them out, every compressed
+    sector == twin, sectors over the threshold stored plain with bit 31 set; the REAL 7ciso reads our
+    file and we read its."""
+    import struct
+    assert os.path.exists(CS)
+    s = hdtest.synth()
+    data = bytes(s.text_like(1 << 20, seed=61)) + bytes(300000) + bytes(s.random_bytes(200000)) + \
+        bytes(s.fastq_like(1 << 20, seed=62)) + b"tail of the image, not a whole sector"
+    fi, fo = str(tmp_path / "in.iso"), str(tmp_path / "out.cso")
+    open(fi, "wb").write(data)
+    p = subprocess.run([CS, "-G%d" % level, "-t%d" % threshold, fi, fo], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = open(fo, "rb").read()
+    nblk = (len(data) + 2047) // 2048
+    assert d[:24] == b"CISO" + struct.pack("<IQIBBH", 24, len(data), 2048, 1, 0, 0)
+    idx = struct.unpack("<%dI" % (nblk + 1), d[24:24 + 4 * (nblk + 1)])
+    assert idx[0] & 0x7fffffff == 24 + 4 * (nblk + 1) and idx[-1] == len(d)
+    plain = 0
+    for k in range(nblk):
+        sector = data[k * 2048:(k + 1) * 2048]
+        a, b = idx[k] & 0x7fffffff, idx[k + 1] & 0x7fffffff
+        r, twin = hdtest.oracle_twin(sector, level)
+        assert r == 0
+        if len(twin) > 2048 * threshold // 100:
+            assert idx[k] >> 31 and d[a:b] == sector, k
+            plain += 1
+        else:
+            assert not idx[k] >> 31 and d[a:b] == twin, k
+    assert 0 < plain < nblk
+    p = subprocess.run([CS, "-d"], input=d, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+    if os.path.exists(REF):
+        p = subprocess.run([REF, "7ciso", "-cd"], input=d, capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data
+        fr = str(tmp_path / "ref.cso")
+        p = subprocess.run([REF, "7ciso", "-l6", "-t%d" % threshold, fi, fr], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        p = subprocess.run([CS, "-d"], input=open(fr, "rb").read(), capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+
+
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err
