@@ -45,7 +45,7 @@ EXPORTS = [
     "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
     "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
-    "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev",
+    "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.hipdeflate_version.restype = ctypes.c_char_p
     L.hipdeflate_scratch_bytes.restype = ctypes.c_uint64
+    L.hipdeflate_bound.restype = ctypes.c_uint64
+    L.hipdeflate_bound.argtypes = [ctypes.c_uint64, ctypes.c_int]
     L.hipdeflate_init.argtypes = [ctypes.c_int]
     sz_p = ctypes.POINTER(ctypes.c_size_t)
     L.hip_deflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
@@ -268,7 +270,7 @@ def batch_deflate(data, offs, lens, level=1, frame=FRAME_RAW, slot=None):
     nb = len(offs)
     if slot is None:
         mx = int(lens.max()) if nb else 0
-        slot = (mx + 5 * (mx // 65535 + 1) + 64 + 15) & ~15
+        slot = int(lib().hipdeflate_bound(mx, level))
     out = np.zeros(max(nb * slot, 1), dtype=np.uint8)
     olen = np.zeros(nb, dtype=np.uint32)
     crc = np.zeros(nb, dtype=np.uint32)

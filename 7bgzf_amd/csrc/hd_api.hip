@@ -16,6 +16,7 @@
 #include "hd_deflate_dynamic.hpp"
 #include "hd_inflate.hpp"
 #include "hd_compact.hpp"
+#include "hd_segment.hpp"
 
 namespace {
 
@@ -172,19 +173,28 @@ inline int bind_device()
 	return 0;
 }
 
-int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
+// the ordinary coding of a batch at `level`: one wave per block
+static int code_batch(const hd::DeflateArgs &a, int level, hipStream_t st)
 {
-	if (a.nblocks == 0)
-		return 0;
 	if (level <= 1) {
 		hd::DeflateArgs b = a;
 		b.level = level;
 		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false>), dim3(a.nblocks), dim3(64), 0, st, b);
-	} else {
-		int r = hd::launch_deflate_dynamic(a, level, st);
-		if (r)
-			return r;
+		return 0;
 	}
+	return hd::launch_deflate_dynamic(a, level, st);
+}
+
+int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
+{
+	if (a.nblocks == 0)
+		return 0;
+	// slots that could hold a block longer than HD_SEG_LIMIT: such blocks are coded in segments
+	int r = (level >= 1 && a.split_max > HD_SEG_LIMIT)
+			? hd::launch_deflate_segmented(a, level, st, [&](const hd::DeflateArgs &x) { return code_batch(x, level, st); })
+			: code_batch(a, level, st);
+	if (r)
+		return r;
 	if (a.frame == HD_FRAME_ZLIB)
 		hipLaunchKernelGGL(hd::k_adler32_patch, dim3(a.nblocks), dim3(64), 0, st, a.in, a.in_off, a.in_len, a.nblocks,
 				   a.out, a.out_stride, a.out_len, a.status);
@@ -228,9 +238,23 @@ void hipdeflate_shutdown(void)
 	g.ready = false;
 }
 
+static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level)
+{
+	if (level >= 1 && cap > HD_SEG_LIMIT)
+		return hd::segmented_scratch_bytes(nblocks, cap, level);
+	return level < 2 ? 0 : hd::dynamic_scratch_bytes(nblocks, cap, level);
+}
+
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level)
 {
-	return hd::dynamic_scratch_bytes(nblocks, max_block, level);
+	return scratch_need(nblocks, max_block, level);
+}
+
+uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
+{
+	const uint64_t payload = (level >= 1 && block_bytes > HD_SEG_LIMIT) ? HD_SEG_WORST(block_bytes, 0)
+									    : block_bytes + 5 * (block_bytes / 65535 + 1) + 5;
+	return (payload + 32 + 15) & ~(uint64_t)15;       // + the longest container (20 + 8 bytes)
 }
 
 /* ---- device-pointer API ---------------------------------------------------- */
@@ -264,10 +288,11 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	a.skip_small = 0;
 	a.split_max = hd::split_max_block(out_stride, out_cap);
 	a.split_ovf = nullptr;
-	if (level >= 2) {
-		// token slabs for the dynamic levels: library-owned, grow-only
+	a.seg_limit = 0;
+	const uint64_t need = scratch_need(nblocks, a.split_max, level);
+	if (need) {
+		// token slabs of the dynamic levels, segment slots of large blocks: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);
-		const uint64_t need = hd::dynamic_scratch_bytes(nblocks, a.split_max, level);
 		if (g.d_tok.cap < need) {
 			// a re-allocation must not pull the rug from under launches in flight
 			HD_CHECK(hipDeviceSynchronize());
@@ -413,7 +438,7 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 	}
 	const uint64_t cap_user = out_stride < out_cap ? out_stride : out_cap;
 	// device slot: what the user allows, but never more than any encoding needs
-	const size_t need = max_len + 5 * (max_len / 65535 + 1) + 32;
+	const size_t need = (size_t)hipdeflate_bound(max_len, level);
 	const size_t slot = up16(cap_user < need ? cap_user : need);
 	const size_t meta_bytes = (size_t)nblocks * (8 + 4 + 4 + 4 + 4 + 8);
 	if (g.h_in.reserve(in_total + 16) || g.h_meta.reserve(meta_bytes) || g.d_in.reserve(in_total + 16) ||
@@ -605,7 +630,7 @@ hipdeflate_pipe *hipdeflate_pipe_open(int level, int frame, uint32_t block_bytes
 	p->block = block_bytes;
 	p->per_batch = blocks_per_batch;
 	// a member never needs more than the stored form + the largest frame
-	p->slot_stride = up16((size_t)block_bytes + 5 * ((size_t)block_bytes / 65535 + 1) + 32);
+	p->slot_stride = (size_t)hipdeflate_bound(block_bytes, level);
 	if (frame == HD_FRAME_BGZF && p->slot_stride > 65536)
 		p->slot_stride = 65536;
 	p->slots.resize(depth);

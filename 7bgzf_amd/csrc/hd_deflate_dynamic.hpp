@@ -339,6 +339,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const uint32_t n = a.in_len[b];
 		if (EMIT ? a.split_ovf[b] != 0 : (a.skip_small && a.split_ovf[b] == 0))
 			continue;                            // the other path's block
+		if (!EMIT && a.seg_limit && n > a.seg_limit)
+			continue;                            // coded in segments (hd_segment.hpp)
 		const bool aligned = (((uintptr_t)src) & 15) == 0;
 		uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 

@@ -51,6 +51,7 @@ struct DeflateArgs {
 	uint32_t skip_small;            // fused dynamic kernel: leave blocks <= split_max to the split path
 	uint32_t split_max;             // split path: largest block it takes (sizes the scratch layout)
 	uint32_t *split_ovf;            // split path: per block, 1 = left to the fused kernel (too many tokens)
+	uint32_t seg_limit;             // level-1 and fused dynamic kernel: != 0 = leave longer blocks alone (hd_segment.hpp codes them)
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -250,6 +251,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			a.split_ovf[b] = 1;
 		return;                              // the fused kernel takes the large blocks
 	}
+	if (!TOK && a.seg_limit && n > a.seg_limit)
+		return;                              // coded in segments (hd_segment.hpp)
 	const bool aligned = (((uintptr_t)src) & 15) == 0;
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
 	const CrcTables *ct = a.ct;

@@ -1,0 +1,214 @@
+// hd_segment.hpp -- levels >= 1, blocks longer than HD_SEG_LIMIT (a 1 MiB MiGz member, a large
+// zlibutil buffer): the block is coded as independent HD_SEG_BYTES segments, every one in
+// full-flush form, an empty final block behind the last (include/hipdeflate_params.h; the CPU
+// twin's twin_segmented()).  One member is then work for 17 wavefronts instead of 40 ms of a single
+// one, and wavefronts that start together no longer read 1 MiB apart (one HBM channel for all).  Three small launches wrap the ordinary dynamic
+// path: a segment table, the coding of the segments into scratch slots, and a stitch (sizes, header,
+// trailer, CRC-32 of the whole from the CRCs of the parts) followed by the gather of the payloads.
+#pragma once
+#include "hd_compact.hpp"
+#include "hd_deflate_dynamic.hpp"
+
+namespace hd {
+
+constexpr uint32_t SEG_STRIDE = (HD_STORED_SIZE(HD_SEG_BYTES) + 5u + 32u + 15u) & ~15u;   // a slot holds any segment's worst case
+constexpr uint32_t SEG_ROUND_MAX = 65536;                                       // segments coded per round (4.3 GB of slots)
+
+struct SegArgs {
+	DeflateArgs a;               // the members: the caller's arrays
+	uint32_t first, count;       // blocks of this round
+	uint32_t S;                  // segment slots per block
+	uint64_t *seg_off;           // [count * S] each
+	uint32_t *seg_len;
+	uint32_t *seg_olen;
+	uint32_t *seg_crc;
+	int32_t *seg_st;
+	uint64_t *seg_dst;
+};
+
+// segment slots per block: enough for the longest block whose worst case fits the slot
+inline uint32_t seg_slots_per_block(uint32_t cap)
+{
+	const uint32_t full = HD_STORED_SIZE(HD_SEG_BYTES) + 5u;
+	// (a raw frame has no header: the count may be one high for the others, never low)
+	return cap / full + (cap % full >= 13u ? 1u : 0u);
+}
+
+inline uint32_t seg_round_blocks(uint32_t nblocks, uint32_t S)
+{
+	uint32_t r = SEG_ROUND_MAX / S;
+	if (r == 0)
+		r = 1;
+	return r < nblocks ? r : nblocks;
+}
+
+// bytes per round: tables + slots (the coding's own scratch comes behind)
+inline uint64_t seg_round_bytes(uint32_t round_blocks, uint32_t S)
+{
+	const uint64_t nseg = (uint64_t)round_blocks * S;
+	return nseg * (8 + 4 + 4 + 4 + 4 + 8) + 64 + nseg * SEG_STRIDE;
+}
+
+// level 1 needs the tables and slots only; the dynamic levels add the small blocks' and the segments' token scratch
+inline uint64_t segmented_scratch_bytes(uint32_t nblocks, uint32_t cap, int level)
+{
+	const uint32_t S = seg_slots_per_block(cap), rb = seg_round_blocks(nblocks, S);
+	if (level < 2)
+		return seg_round_bytes(rb, S) + 64;
+	return dynamic_scratch_bytes(nblocks, cap, level) + seg_round_bytes(rb, S) + dynamic_scratch_bytes(rb * S, SEG_STRIDE, level) + 64;
+}
+
+__global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
+{
+	const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+	if (t >= g.count * g.S)
+		return;
+	const uint32_t i = g.first + t / g.S, k = t % g.S;
+	const uint32_t len = g.a.in_len[i];
+	const uint64_t o = (uint64_t)k * HD_SEG_BYTES;
+	// blocks up to the limit are not segmented (the fused kernel takes them): all their slots stay empty
+	const uint32_t sl = (len > HD_SEG_LIMIT && o < len) ? (len - o < HD_SEG_BYTES ? (uint32_t)(len - o) : HD_SEG_BYTES) : 0u;
+	g.seg_off[t] = g.a.in_off[i] + (sl ? o : 0);
+	g.seg_len[t] = sl;
+}
+
+// x^n mod P (reflected): the operator that appends n/8 bytes to a CRC
+__device__ inline uint32_t gf_xpow(uint64_t n)
+{
+	uint32_t p = 1u << 31, sq = 1u << 30;
+	for (; n; n >>= 1) {
+		if (n & 1)
+			p = gf_mul(sq, p);
+		sq = gf_mul(sq, sq);
+	}
+	return p;
+}
+
+// one thread per member: where each segment's payload goes, the container bytes around them
+__global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
+{
+	const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+	if (t >= g.count)
+		return;
+	const DeflateArgs &a = g.a;
+	const uint32_t i = g.first + t, len = a.in_len[i];
+	const uint64_t base = (uint64_t)t * g.S;
+	if (len <= HD_SEG_LIMIT) {
+		for (uint32_t k = 0; k < g.S; k++) {
+			g.seg_olen[base + k] = 0;               // nothing of this block's to gather
+			g.seg_dst[base + k] = 0;
+		}
+		return;
+	}
+	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = frame_trl_bytes(a.frame);
+	const bool flush = a.frame == HD_FRAME_RAW_FLUSH;
+	uint64_t cap = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+	if (a.frame == HD_FRAME_BGZF && cap > 65536)
+		cap = 65536;
+	const uint32_t nseg = HD_SEG_COUNT(len);
+	bool ok = nseg <= g.S && (uint64_t)hdr + HD_SEG_WORST((uint64_t)len, flush) + trl <= cap;
+	for (uint32_t k = 0; ok && k < nseg; k++)
+		ok = g.seg_st[base + k] == 0;
+	if (!ok) {
+		for (uint32_t k = 0; k < g.S; k++) {
+			g.seg_olen[base + k] = 0;
+			g.seg_dst[base + k] = 0;
+		}
+		a.out_len[i] = 0;
+		if (a.status) a.status[i] = 1;
+		if (a.crc) a.crc[i] = 0;
+		return;
+	}
+	uint8_t *dst = a.out + (uint64_t)i * a.out_stride;
+	uint32_t pos = hdr, crc = 0;
+	const uint32_t xfull = gf_xpow(8ull * HD_SEG_BYTES);
+	for (uint32_t k = 0; k < g.S; k++) {
+		if (k >= nseg) {
+			g.seg_olen[base + k] = 0;
+			g.seg_dst[base + k] = 0;
+			continue;
+		}
+		g.seg_dst[base + k] = (uint64_t)i * a.out_stride + pos;
+		pos += g.seg_olen[base + k];
+		const uint32_t sl = g.seg_len[base + k];
+		crc = k == 0 ? g.seg_crc[base] : gf_mul(sl == HD_SEG_BYTES ? xfull : gf_xpow(8ull * sl), crc) ^ g.seg_crc[base + k];
+	}
+	if (!flush) {
+		dst[pos] = 0x03;                                // the empty final block
+		dst[pos + 1] = 0x00;
+		pos += 2;
+	}
+	const uint32_t paylen = pos - hdr, total = pos + trl;
+	const uint32_t sizefield = a.frame == HD_FRAME_BGZF ? total - 1 : paylen;
+	for (uint32_t o = 0; o < hdr; o++)
+		dst[o] = (uint8_t)frame_hdr_byte(a.frame, o, sizefield);
+	for (uint32_t k = 0; k < trl / 2; k++) {
+		const uint32_t f = frame_trl_field(a.frame, k, crc, len);
+		dst[pos + 2 * k] = (uint8_t)f;
+		dst[pos + 2 * k + 1] = (uint8_t)(f >> 8);
+	}
+	a.out_len[i] = total;
+	if (a.status) a.status[i] = 0;
+	if (a.crc) a.crc[i] = crc;
+}
+
+// a.scratch: segmented_scratch_bytes(a.nblocks, capacity, level).  `code(args)` launches the level's
+// ordinary coding of a batch (the level-1 kernel, or launch_deflate_dynamic): once for the caller's blocks
+// with seg_limit set -- it takes the blocks up to the limit, the one way such a block is coded whatever
+// its neighbours are -- and once per round for the segments.
+template <class F>
+inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t st, F code)
+{
+	const uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+	const uint32_t cap = cap64 > 0x7fffffffu ? 0x7fffffffu : (uint32_t)cap64;
+	const uint32_t S = seg_slots_per_block(cap), rb = seg_round_blocks(a.nblocks, S);
+	DeflateArgs f = a;
+	f.seg_limit = HD_SEG_LIMIT;
+	int r = code(f);
+	if (r)
+		return r;
+
+	uint8_t *p = a.scratch + (level >= 2 ? dynamic_scratch_bytes(a.nblocks, cap, level) : 0);
+	p = (uint8_t *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+	SegArgs g;
+	g.a = a;
+	g.S = S;
+	const uint64_t nseg_round = (uint64_t)rb * S;
+	g.seg_off = (uint64_t *)p;
+	g.seg_dst = g.seg_off + nseg_round;
+	g.seg_len = (uint32_t *)(g.seg_dst + nseg_round);
+	g.seg_olen = g.seg_len + nseg_round;
+	g.seg_crc = g.seg_olen + nseg_round;
+	g.seg_st = (int32_t *)(g.seg_crc + nseg_round);
+	uint8_t *slots = (uint8_t *)(((uintptr_t)(g.seg_st + nseg_round) + 15) & ~(uintptr_t)15);
+	uint8_t *inner = slots + nseg_round * SEG_STRIDE;
+	inner = (uint8_t *)(((uintptr_t)inner + 15) & ~(uintptr_t)15);
+	for (uint32_t first = 0; first < a.nblocks; first += rb) {
+		g.first = first;
+		g.count = a.nblocks - first < rb ? a.nblocks - first : rb;
+		const uint32_t ns = g.count * S;
+		hipLaunchKernelGGL(k_seg_table, dim3((ns + 255) / 256), dim3(256), 0, st, g);
+		DeflateArgs s = a;
+		s.in_off = g.seg_off;
+		s.in_len = g.seg_len;
+		s.nblocks = ns;
+		s.frame = HD_FRAME_RAW_FLUSH;
+		s.out = slots;
+		s.out_stride = SEG_STRIDE;
+		s.out_cap = SEG_STRIDE;
+		s.out_len = g.seg_olen;
+		s.crc = g.seg_crc;
+		s.status = g.seg_st;
+		s.scratch = inner;
+		s.split_max = SEG_STRIDE;
+		s.seg_limit = 0;
+		if ((r = code(s)))
+			return r;
+		hipLaunchKernelGGL(k_seg_stitch, dim3((g.count + 63) / 64), dim3(64), 0, st, g);
+		hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)SEG_STRIDE,
+				   (const uint32_t *)g.seg_olen, (const uint64_t *)g.seg_dst, ns, a.out);
+	}
+	return 0;
+}
+
+} // namespace hd

@@ -178,7 +178,7 @@ def main():
 
     frame = pkg.FRAME_MIGZ if args.block_kib else pkg.FRAME_BGZF
     hdr = 20 if args.block_kib else 18
-    slot = 65536 if not args.block_kib else ((BLOCK + BLOCK // 8 + 4096 + 15) & ~15)
+    slot = 65536 if not args.block_kib else int(pkg.lib().hipdeflate_bound(BLOCK, 9))
     enc = dev.DeviceDeflate(nb, slot=slot)
     if args.mode == "encode":
         level = args.level

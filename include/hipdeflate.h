@@ -94,6 +94,13 @@ int hip_deflate_flush(unsigned char *dest, size_t *destLen,
 int hip_inflate_flush(unsigned char *dest, size_t *destLen,
 		      const unsigned char *source, size_t sourceLen);
 
+/* Bytes of output room that always suffice for one block of block_bytes at `level`, in any frame,
+ * a multiple of 16: the slot size (out_stride / out_cap) to give the batch calls, the role of the
+ * 1.5 x block the reference allocates (zlibutil_buffer_allocate, applet/7bgzf.c:168).  Levels >= 1
+ * code a block longer than HD_SEG_LIMIT in flushed 64 KiB segments (hipdeflate_params.h) and refuse
+ * it when the room is below this bound, whatever the data would have needed. */
+uint64_t hipdeflate_bound(uint64_t block_bytes, int level);
+
 /* ---- batch API, host buffers ------------------------------------------- */
 
 /* Compress nblocks independent blocks.  Block i is in[in_off[i] .. +in_len[i]).

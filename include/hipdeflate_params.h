@@ -69,6 +69,13 @@
 /* a DEFLATE block of the dynamic path is closed at the first step boundary at
  * which it holds at least this many tokens (scratch slab = this + 64 tokens) */
 #define HD_DYN_BLOCK_TOKENS (1u << 15)
+/* Levels >= 1: a block longer than HD_SEG_LIMIT (a MiGz member, a big zlibutil buffer) is coded as
+ * independent HD_SEG_BYTES segments -- each with its own window and codes, each ending in a full flush,
+ * an empty final block (03 00) behind the last -- so that one member is work for many wavefronts.
+ * The windows are 4..16 KiB, so a fresh window every 0xff00 bytes costs < 1 % of ratio.  Such a block needs
+ * room for the worst case of every segment (stored + flush), HD_SEG_WORST(n). */
+#define HD_SEG_BYTES       0xff00u     /* not a power of two: waves that start together must not meet on one HBM channel */
+#define HD_SEG_LIMIT       (320u << 10)
 #define HD_TOKEN_MATCH     0x80000000u /* token: literal byte | MATCH | (len-3)<<16 | (dist-1) */
 #define HD_LITLEN_MAXBITS  15
 #define HD_OFFSET_MAXBITS  15
@@ -80,6 +87,12 @@
 
 /* stored-block framing cost: 5 bytes per <=65535-byte block, at least one */
 #define HD_STORED_SIZE(n)  ((n) + 5u * ((n) == 0 ? 1u : (((n) + 65534u) / 65535u)))
+/* worst-case payload of a segmented block of n bytes: every segment stored (two stored blocks per full
+ * segment) + its flush suffix; `flush` = the member itself is in flush form (no 03 00 behind) */
+#define HD_SEG_COUNT(n)    (((n) + HD_SEG_BYTES - 1u) / HD_SEG_BYTES)
+#define HD_SEG_WORST(n, flush) \
+	(((n) / HD_SEG_BYTES) * (HD_STORED_SIZE(HD_SEG_BYTES) + 5u) + \
+	 ((n) % HD_SEG_BYTES ? HD_STORED_SIZE((n) % HD_SEG_BYTES) + 5u : 0u) + ((flush) ? 0u : 2u))
 
 /* result codes of the inflate path = enum libdeflate_result
  * (lib/libdeflate/libdeflate.h:193-208), which libdeflate_inflate

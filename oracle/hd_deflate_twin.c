@@ -652,8 +652,36 @@ void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, u
 	memcpy(lens_out, h.len, nsyms);
 }
 
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush);
+
+/* levels >= 1, blocks longer than HD_SEG_LIMIT (include/hipdeflate_params.h): independent segments in
+ * flush form one behind the other, then the empty final block unless the member itself is a flush form.
+ * The room has to cover the worst case of every segment, whatever the data turns out to need. */
+static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
+{
+	if (*destLen < HD_SEG_WORST((uint64_t)sourceLen, flush))
+		return 1;
+	size_t o = 0;
+	for (size_t s = 0; s < sourceLen; s += HD_SEG_BYTES) {
+		size_t n = sourceLen - s < HD_SEG_BYTES ? sourceLen - s : HD_SEG_BYTES;
+		size_t room = *destLen - o;
+		int r = twin(dest + o, &room, source + s, n, level, 1);
+		if (r)
+			return r;
+		o += room;
+	}
+	if (!flush) {
+		dest[o++] = 0x03;
+		dest[o++] = 0x00;
+	}
+	*destLen = o;
+	return 0;
+}
+
 static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
 {
+	if (level >= 1 && sourceLen > HD_SEG_LIMIT)
+		return twin_segmented(dest, destLen, source, sourceLen, level, flush);
 	if (level <= 0)
 		return write_stored(dest, destLen, source, sourceLen, flush);   /* level 0 = the stored branch */
 	if (level == 1)

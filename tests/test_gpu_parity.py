@@ -290,6 +290,54 @@ def test_encode_migz_1mib_blocks_match_twin(pkg, level):
         assert st2[i] == 0 and outs[i] == data[offs[i]:offs[i] + lens[i]] and int(crc2[i]) == int(crc[i])
 
 
+@pytest.mark.parametrize("level", [1, 2, 6])
+def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, level):
+    """Blocks longer than HD_SEG_LIMIT are coded as flushed 0xff00-byte segments and stitched on the device
+    (hd_segment.hpp): payload == twin in every frame, CRC-32 folded from the segments' CRCs, Adler-32 and
+    the size fields right; shorter blocks in the same big-slot batch are coded whole; a slot below
+    hipdeflate_bound refuses the long block whatever it would have needed, as the twin does."""
+    import gzip
+    s = hdtest.synth()
+    big = bytes(s.text_like(500000, seed=5)) + bytes(s.random_bytes(66000)) + bytes(s.fastq_like(200000, seed=6))
+    blocks = [big, big[: (320 << 10) + 1], big[: 320 << 10], big[:70000], b"", big[1000:401000]]
+    blob, offs, lens = b"", [], []
+    for b in blocks:
+        offs.append(len(blob))
+        lens.append(len(b))
+        blob += b + bytes(-len(b) % 16)
+    slot = int(pkg.lib().hipdeflate_bound(len(big), level))
+    for frame, hdr, trl in ((pkg.FRAME_RAW, 0, 0), (pkg.FRAME_MIGZ, 20, 8), (pkg.FRAME_GZIP, 10, 8), (pkg.FRAME_ZLIB, 2, 4),
+                            (pkg.FRAME_RAW_FLUSH, 0, 0)):
+        members, crc, st = pkg.batch_deflate(blob, offs, lens, level, frame, slot=slot)
+        for i, b in enumerate(blocks):
+            assert st[i] == 0, (frame, i)
+            m = members[i]
+            twin = (hdtest.oracle_twin_flush if frame == pkg.FRAME_RAW_FLUSH else hdtest.oracle_twin)(b, level, cap=slot - hdr - trl)
+            assert twin[0] == 0 and m[hdr:len(m) - trl] == twin[1], (frame, i, level)
+            assert int(crc[i]) == zlib.crc32(b)
+            if frame == pkg.FRAME_GZIP:
+                assert gzip.decompress(m) == b
+            elif frame == pkg.FRAME_ZLIB:
+                assert zlib.decompress(m) == b
+            elif frame == pkg.FRAME_MIGZ:
+                assert int.from_bytes(m[16:20], "little") == len(m) - 28 and gzip.decompress(m) == b
+            elif frame == pkg.FRAME_RAW:
+                assert zlib.decompress(m, -15) == b
+    # the capacity rule: one 16-byte step below the bound of the long block
+    tight = slot - 48
+    members, crc, st = pkg.batch_deflate(blob, offs, lens, level, pkg.FRAME_RAW, slot=tight)
+    for i, b in enumerate(blocks):
+        r, twin = hdtest.oracle_twin(b, level, cap=tight)
+        assert (st[i] == 0) == (r == 0), i
+        if r == 0:
+            assert members[i] == twin
+    assert st[0] != 0 and st[3] == 0
+    r, z = pkg.hip_deflate(big, level)
+    assert r == 0 and z == hdtest.oracle_twin(big, level)[1]
+    outs, dcrc, dst = pkg.batch_inflate([z], [len(big)])
+    assert dst[0] == 0 and outs[0] == big
+
+
 def test_encode_unaligned_offsets_and_ragged_lengths(pkg):
     s = hdtest.synth()
     data = bytes(s.fastq_like(300000, seed=3))

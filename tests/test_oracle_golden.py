@@ -245,6 +245,33 @@ def test_twin_flush_form_is_full_flush_of_twin(level):
         assert r4 != 0, name
 
 
+@pytest.mark.parametrize("level", [1, 2, 6])
+def test_twin_codes_long_blocks_in_flushed_segments(level):
+    """Levels >= 1, blocks longer than HD_SEG_LIMIT (320 KiB): independent 0xff00-byte segments, each the
+    twin's own flush form, 03 00 behind the last (include/hipdeflate_params.h).  One byte less and the block
+    is coded whole.  The room must cover every segment's worst case; zlib reads the result."""
+    import zlib
+    s = hdtest.synth()
+    limit, seg = 320 << 10, 0xff00
+    data = bytes(s.text_like(400000, seed=91)) + bytes(s.random_bytes(70000)) + bytes(s.fastq_like(300000, seed=92))
+    r, z = hdtest.oracle_twin(data, level)
+    assert r == 0 and zlib.decompress(z, -15) == data
+    parts = b"".join(hdtest.oracle_twin_flush(data[o:o + seg], level)[1] for o in range(0, len(data), seg))
+    assert z == parts + b"\x03\x00"
+    r, zf = hdtest.oracle_twin_flush(data, level)
+    assert r == 0 and zf == parts
+    nseg, last = divmod(len(data), seg)
+    worst = nseg * (seg + 10) + (last + 10 if last else 0) + 2
+    assert hdtest.oracle_twin(data, level, cap=worst)[0] == 0
+    assert hdtest.oracle_twin(data, level, cap=worst - 1)[0] != 0          # although the stream is far shorter
+    assert hdtest.oracle_twin_flush(data, level, cap=worst - 3)[0] != 0
+    whole = data[:limit]
+    r, z = hdtest.oracle_twin(whole, level)
+    assert r == 0 and zlib.decompress(z, -15) == whole and not z.endswith(b"\x00\x00\xff\xff\x03\x00")
+    r, z = hdtest.oracle_twin(data[:limit + 1], level)
+    assert r == 0 and zlib.decompress(z, -15) == data[:limit + 1] and z.endswith(b"\x00\x00\xff\xff\x03\x00")
+
+
 def test_zlib_gzip_frames_match_reference_wrappers():
     """hdo_zlib_frame / hdo_gzip_frame against zlibutil_buffer_code's own output recorded from the
     reference (boundary.json, lib/zlibutil.c:374-405; mtime zeroed in the golden)."""
