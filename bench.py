@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--data", default="fastq", choices=["fastq", "text", "random"],
                     help="fastq = configs[1..3]; text = config 5 (enwik-like); random = config 1 stand-in")
+    ap.add_argument("--slot", type=int, default=0, help="experiment: output slot bytes per block (multiple of 16; 0 = default)")
     ap.add_argument("--block-kib", type=int, default=0, help="0 = BGZF 0xff00-byte blocks; else MiGz blocks of N KiB")
     ap.add_argument("--stream", default="own", choices=["own", "libdeflate6", "zlib6", "libdeflate1"],
                     help="decode mode: who compressed the stream (reference encoders need oracle/_ref/libref.so)")
@@ -178,7 +179,7 @@ def main():
 
     frame = pkg.FRAME_MIGZ if args.block_kib else pkg.FRAME_BGZF
     hdr = 20 if args.block_kib else 18
-    slot = 65536 if not args.block_kib else int(pkg.lib().hipdeflate_bound(BLOCK, 9))
+    slot = args.slot or (65536 if not args.block_kib else int(pkg.lib().hipdeflate_bound(BLOCK, 9)))
     enc = dev.DeviceDeflate(nb, slot=slot)
     if args.mode == "encode":
         level = args.level

@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l2 -- python3 be
 grep '^{' $OUT/bench_kt_l2.log > $OUT/bench_line_l2.json || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l3 -- python3 bench.py --steps 2 --warmup 1 --level 3 --no-cpu > $OUT/bench_kt_l3.log 2>&1
 grep '^{' $OUT/bench_kt_l3.log > $OUT/bench_line_l3.json || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_migz6 -- python3 bench.py --steps 2 --warmup 1 --level 6 --data text --block-kib 1024 --no-cpu > $OUT/bench_kt_migz6.log 2>&1
+grep '^{' $OUT/bench_kt_migz6.log > $OUT/bench_line_migz6.json || true
 python3 - $OUT <<'PY'
 import csv,glob,sys,json,collections
 out=sys.argv[1]
