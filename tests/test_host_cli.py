@@ -40,9 +40,12 @@ def test_filter_matches_library_and_reference_format(level):
         assert rc == 0 and back == data, err
 
 
-def test_migz_framing_roundtrip():
+@pytest.mark.parametrize("level", [1, 6])
+def test_migz_framing_roundtrip(level):
+    """1 MiB members (coded as flushed 0xff00-byte segments, hd_segment.hpp): plain gzip readers, our reader
+    and the reference's 7migz all take them back."""
     data = bytes(hdtest.synth().text_like(3 * 1024 * 1024 + 17, seed=10))
-    rc, blob, err = run(["-M", "-b1024", "-G1"], data)
+    rc, blob, err = run(["-M", "-b1024", "-G%d" % level], data)
     assert rc == 0, err
     assert blob[:16] == bytes.fromhex("1f8b08040000000000ff08004d5a0400")
     assert gzip.decompress(blob) == data
