@@ -299,7 +299,8 @@ def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, l
     import gzip
     s = hdtest.synth()
     big = bytes(s.text_like(500000, seed=5)) + bytes(s.random_bytes(66000)) + bytes(s.fastq_like(200000, seed=6))
-    blocks = [big, big[: (320 << 10) + 1], big[: 320 << 10], big[:70000], b"", big[1000:401000]]
+    blocks = [big, big[: (320 << 10) + 1], big[: 320 << 10], big[:70000], b"", big[1000:401000],
+              big[: 6 * 0xff00], big[: 6 * 0xff00 + 1], big[7: 7 + 6 * 0xff00 - 1]]      # whole segments, one byte over / under
     blob, offs, lens = b"", [], []
     for b in blocks:
         offs.append(len(blob))
