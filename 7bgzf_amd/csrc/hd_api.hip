@@ -1013,6 +1013,15 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	return 0;
 }
 
+#ifdef HD_INFLATE_STATS
+int hipdeflate_test_inflate_stats(uint64_t *out8)
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_inf_stats), 64));
+	return 0;
+}
+#endif
+
 int hip_inflate(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen)
 {
 	return inflate_one(dest, destLen, source, sourceLen, 0);

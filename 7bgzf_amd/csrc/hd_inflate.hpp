@@ -47,6 +47,14 @@ struct InflateArgs {
 // that report "out of input" as success (zlib_inflate, lib/zlibutil.c:289-291; igzip_inflate, zlibutil_igzip.c:111)
 constexpr uint32_t INF_FLUSHED = 1;
 
+#ifdef HD_INFLATE_STATS
+// experiment build only (tools/exp_inflate_stats.sh): where the tokens go
+__device__ unsigned long long g_inf_stats[8];
+#define INF_STAT(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define INF_STAT(k, v) do { } while (0)
+#endif
+
 constexpr uint32_t INF_LT_BITS = 9;      // litlen direct table (8 VGPRs once loaded)
 constexpr uint32_t INF_DT_BITS = 8;      // offset direct table
 constexpr uint32_t INF_RING    = 2048;   // LDS output ring: small on purpose, occupancy beats window
@@ -433,8 +441,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					b = 64 + f;
 				}
 			}
-			if (real0 == 0)
+			INF_STAT(0, 1);
+			if (real0 == 0) {
+				INF_STAT(6, 1);
 				break;                                     // the token at B is not for a window: scalar loop
+			}
+			INF_STAT(1, __popcll(real0) + __popcll(real1));
 			const uint32_t cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
 						   : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
 			const bool mine0 = (real0 >> lane) & 1, mine1 = (real1 >> lane) & 1;
@@ -461,6 +473,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 							  s0.offset >= rel0 + s0.length && s0.length <= 64);
 			const uint64_t simple1 = __ballot(match1 && wend - srcl1 <= INF_RING - 64 &&
 							  s1.offset >= rel1 + s1.length && s1.length <= 64);
+			// (copying them two at a time, both reads ahead of both writes, measured 2 % slower: the kernel
+			// is bound by scalar issue, not by the LDS round trips)
 			for (uint64_t sm = simple0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				sm &= sm - 1;
@@ -671,9 +685,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					flush_pieces();
 				refill();
 				if (overrun()) { st = HD_BAD_DATA; break; }
+				INF_STAT(2, 1);
 				const uint32_t li = (uint32_t)bb & ((1u << INF_LT_BITS) - 1);
 				uint32_t e = readlane(LT[li >> 6], li & 63);
 				if (((e >> 8) & 3) == K_SLOW) {
+					INF_STAT(3, 1);
 					const uint32_t sl = uniform(slow_decode(bb, L.lit_count, L.lit_sorted));
 					e = litlen_entry(sl & 0xffff, sl >> 16);
 				}
@@ -688,8 +704,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					pos++;
 					continue;
 				}
-				if (kind == K_EOB)
+				if (kind == K_EOB) {
+					INF_STAT(5, 1);
 					break;
+				}
 				const uint32_t eb = (e >> 4) & 15;
 				const uint32_t length = (e >> 16) + ((uint32_t)bb & ((1u << eb) - 1));
 				bb >>= eb;
@@ -699,6 +717,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t di = (uint32_t)bb & ((1u << INF_DT_BITS) - 1);
 				uint32_t d = readlane(DT[di >> 6], di & 63);
 				if (((d >> 8) & 3) == K_SLOW) {
+					INF_STAT(4, 1);
 					const uint32_t sl = uniform(slow_decode(bb, L.off_count, L.off_sorted));
 					d = offset_entry(sl & 0xffff, sl >> 16);
 				}

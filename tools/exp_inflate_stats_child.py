@@ -1,0 +1,15 @@
+"""child of tools/exp_inflate_stats.sh: runs bench.py's decode leg in-process on 1 GiB and prints the counters"""
+import ctypes, importlib, sys, runpy
+sys.path.insert(0, '.')
+stream = sys.argv[1]
+sys.argv = ["bench.py", "--no-cpu", "--mode", "decode", "--stream", stream, "--gib", "1", "--steps", "1", "--warmup", "0"] + \
+    (["--level", "1"] if stream == "own" else [])
+try:
+    runpy.run_path("bench.py", run_name="__main__")
+except SystemExit:
+    pass
+pkg = importlib.import_module("7bgzf_amd")
+out = (ctypes.c_uint64 * 8)()
+pkg.lib().hipdeflate_test_inflate_stats(out)
+names = ["windows", "window_tokens", "scalar_tokens", "slow_litlen", "slow_dist", "eob", "window_empty", "-"]
+print({n: int(v) for n, v in zip(names, out)})
