@@ -93,24 +93,35 @@ __device__ __forceinline__ uint32_t offset_entry(uint32_t sym, uint32_t len)
 	return (base << 16) | (eb << 4) | len;
 }
 
+// 6400 bytes = five 1280-byte allocation units = 25 waves per CU (7200 were six units, 21 waves; this
+// kernel answers to occupancy: 16 waves measured 85 GB/s where 21 gave 102).  What is live only while a
+// block header is read shares its bytes with what is live only in the symbol loop:
+//   - the precode's table is the first 128 entries of `lit` (the litlen table is built after the code
+//     lengths are complete);
+//   - the table builder's per-length scratch lies in cl[320..448), the landing zone of an RLE overrun
+//     (decompress_template.h:171), dead once the lengths are in;
+//   - cl / pre_lens share the union with the window decoder's dump slots and stream copy; the dump
+//     slots follow the ring directly, ring[INF_RING + lane] addresses them.
 struct InfLds {
 	uint32_t lit[1u << INF_LT_BITS];
 	uint32_t off[1u << INF_DT_BITS];
 	uint16_t lit_sorted[288];
 	uint16_t off_sorted[32];
 	uint16_t lit_count[16], off_count[16];
-	uint8_t pre_lens[32];
-	uint32_t t_cnt[16], t_first[16], t_offs[16], t_base[16];   // table-build scratch, one entry per code length
-	// header-time scratch and the window decoder's stream copy are never live together
+	__attribute__((aligned(16))) uint8_t ring[INF_RING];
 	union {
 		struct {
-			uint32_t pre[128];
-			uint8_t cl[288 + 32 + 138 + 6];   // + worst-case RLE overrun (decompress_template.h:171)
+			uint8_t cl[288 + 32 + 138 + 6];   // + worst-case RLE overrun
+			uint8_t pre_lens[32];
 		};
-		uint32_t comp[256];               // 4 pieces of the compressed stream for the window decoder
+		struct {
+			uint8_t dump[64];                 // a dump slot per lane, right behind the ring
+			uint32_t comp[128];               // 2 pieces of the compressed stream for the window decoder
+		};
 	};
-	__attribute__((aligned(16))) uint8_t ring[INF_RING + 64];   // + a dump slot per lane
 };
+static_assert(sizeof(InfLds) == 6400, "InfLds must stay within five LDS allocation units");
+constexpr uint32_t INF_T_SCRATCH = 320;      // byte offset in cl of { u32 cnt[16]; u16 first[16]; u16 offs[16]; }
 
 // Build one decode table from code lengths (all 64 lanes).  Returns false for
 // what build_decode_table() rejects (deflate_decompress.c:799-853).
@@ -120,9 +131,11 @@ struct InfLds {
 struct InfLds;
 template <int KIND>
 __device__ __noinline__ uint32_t build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
-					  uint16_t *sorted, uint16_t *count_out, uint32_t *t_cnt, uint32_t *t_first,
-					  uint32_t *t_offs, uint32_t *t_base, uint32_t lane)
+					  uint16_t *sorted, uint16_t *count_out, uint8_t *scratch, uint32_t lane)
 {
+	// per-length counters; once the counts are read they serve as the running rank bases
+	uint32_t *t_cnt = (uint32_t *)scratch, *t_base = t_cnt;
+	uint16_t *t_first = (uint16_t *)(scratch + 64), *t_offs = t_first + 16;
 	if (lane < 16)
 		t_cnt[lane] = 0;
 	for (uint32_t base = 0; base < nsyms; base += 64) {
@@ -140,10 +153,11 @@ __device__ __noinline__ uint32_t build_table(const uint8_t *lens, uint32_t nsyms
 				o += t_cnt[l];
 		}
 		mine = t_cnt[lane];
-		t_first[lane] = code;
-		t_offs[lane] = o;
-		t_base[lane] = 0;
+		t_first[lane] = (uint16_t)code;       // < 2^15 for every code that passes the checks below
+		t_offs[lane] = (uint16_t)o;
 	}
+	if (lane < 16)
+		t_base[lane] = 0;                     // (all lanes are past the loop that read the counts)
 	if (count_out && lane < 16)
 		count_out[lane] = (uint16_t)mine;
 	const uint32_t used = readlane(wave_incl_scan((lane >= 1 && lane < 16) ? mine << (15 - lane) : 0u), 63);
@@ -354,8 +368,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t p0 = d0 >> 6;
 			if (p0 != lds_p0) {
 				if (p0 != lds_p0 + 1)
-					L.comp[((p0 & 3) << 6) + lane] = load_piece(p0);
-				L.comp[(((p0 + 1) & 3) << 6) + lane] = load_piece(p0 + 1);
+					L.comp[((p0 & 1) << 6) + lane] = load_piece(p0);
+				L.comp[(((p0 + 1) & 1) << 6) + lane] = load_piece(p0 + 1);
 				lds_p0 = p0;
 			}
 			// A window is 128 bits: every lane decodes the token that would start at bit
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			auto spec = [&](uint32_t bl) -> Spec {                // bl = bit offset from dword d0
 				Spec r;
 				const uint32_t di = d0 + (bl >> 5);
-				const uint32_t lo = L.comp[di & 255], mid = L.comp[(di + 1) & 255], hi = L.comp[(di + 2) & 255];
+				const uint32_t lo = L.comp[di & 127], mid = L.comp[(di + 1) & 127], hi = L.comp[(di + 2) & 127];
 				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
 				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
 				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
@@ -617,14 +631,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					bb >>= 3;
 					bc -= 3;
 				}
-				if (!uniform(build_table<2>(L.pre_lens, 19, L.pre, 7, L.lit_sorted, nullptr, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane))) { st = HD_BAD_DATA; break; }
+				if (!uniform(build_table<2>(L.pre_lens, 19, L.lit, 7, L.lit_sorted, nullptr, L.cl + INF_T_SCRATCH, lane))) { st = HD_BAD_DATA; break; }
 				uint8_t *cl = L.cl;
 				uint32_t i = 0, prev = 0;
 				bool bad = false;
 				while (i < nlit + noff) {
 					refill();
 					if (consumed_bits() > 8 * (int64_t)n + 64) { bad = true; break; }
-					const uint32_t e = uniform(L.pre[(uint32_t)bb & 127]);
+					const uint32_t e = uniform(L.lit[(uint32_t)bb & 127]);
 					const uint32_t cl_len = e & 15, s = e >> 16;
 					bb >>= cl_len;
 					bc -= cl_len;
@@ -656,8 +670,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				}
 				if (bad || i != nlit + noff) { st = HD_BAD_DATA; break; }
 				static_loaded = false;
-				if (!uniform(build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane)) ||
-				    !uniform(build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane))) {
+				if (!uniform(build_table<1>(cl + nlit, noff, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.cl + INF_T_SCRATCH, lane)) ||
+				    !uniform(build_table<0>(cl, nlit, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.cl + INF_T_SCRATCH, lane))) {
 					st = HD_BAD_DATA;
 					break;
 				}
@@ -666,8 +680,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				uint8_t *cl = L.cl;
 				for (uint32_t s = lane; s < 320; s += 64)
 					cl[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
-				build_table<1>(cl + 288, 32, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane);
-				build_table<0>(cl, 288, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.t_cnt, L.t_first, L.t_offs, L.t_base, lane);
+				build_table<1>(cl + 288, 32, L.off, INF_DT_BITS, L.off_sorted, L.off_count, L.cl + INF_T_SCRATCH, lane);
+				build_table<0>(cl, 288, L.lit, INF_LT_BITS, L.lit_sorted, L.lit_count, L.cl + INF_T_SCRATCH, lane);
 				static_loaded = true;
 			}
 
