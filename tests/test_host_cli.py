@@ -258,6 +258,51 @@ def test_ciso_writer_and_reader_against_the_reference(tmp_path, level, threshold
         assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
 
 
+DX = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7daxcr")
+
+
+@pytest.mark.parametrize("level", [1, 6, 0])
+def test_daxcr_writer_and_reader_against_the_reference(tmp_path, level):
+    """hd7daxcr (applet/7daxcr.c in batches): 8192-byte frames as RFC 1950 members made on the device
+    (HD_FRAME_ZLIB: header, twin payload, Adler-32), 32-bit offset and 16-bit size tables as the
+    reference lays them out; zlib reads every frame, the REAL 7daxcr reads our file and we read its."""
+    import struct
+    import zlib
+    assert os.path.exists(DX)
+    s = hdtest.synth()
+    data = bytes(s.text_like(600000, seed=71)) + bytes(100000) + bytes(s.random_bytes(50000)) + \
+        bytes(s.fastq_like(400000, seed=72)) + b"a ragged last frame"
+    fi, fo = str(tmp_path / "in.iso"), str(tmp_path / "out.dax")
+    open(fi, "wb").write(data)
+    p = subprocess.run([DX, "-G%d" % level, fi, fo], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = open(fo, "rb").read()
+    nblk = (len(data) + 8191) // 8192
+    assert d[:32] == b"DAX\0" + struct.pack("<III", len(data), 1, 0) + bytes(16)
+    idx = struct.unpack("<%dI" % nblk, d[32:32 + 4 * nblk])
+    sizes = struct.unpack("<%dH" % nblk, d[32 + 4 * nblk:32 + 6 * nblk])
+    pos = 32 + 6 * nblk
+    for k in range(nblk):
+        frame = data[k * 8192:(k + 1) * 8192]
+        assert idx[k] == pos
+        m = d[pos:pos + sizes[k]]
+        r, twin = hdtest.oracle_twin(frame, level)
+        assert r == 0 and m[:2] == b"\x78\xda" and m[2:-4] == twin, k
+        assert m[-4:] == zlib.adler32(frame).to_bytes(4, "big") and zlib.decompress(m) == frame
+        pos += sizes[k]
+    assert pos == len(d)
+    p = subprocess.run([DX, "-d"], input=d, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+    if os.path.exists(REF):
+        p = subprocess.run([REF, "7daxcr", "-cd"], input=d, capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data
+        fr = str(tmp_path / "ref.dax")
+        p = subprocess.run([REF, "7daxcr", "-l6", fi, fr], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        p = subprocess.run([DX, "-d"], input=open(fr, "rb").read(), capture_output=True, timeout=300)
+        assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
+
+
 def test_rejects_garbage():
     rc, out, err = run(["-d"], b"this is not a bgzf file at all, not even close")
     assert rc != 0 and "not BGZF or corrupted" in err
