@@ -30,9 +30,9 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
 	// one persistent wave per LDS slot of the level (levels 2-4: 14.5 KiB -> 10 resident per CU
-	// -- 11 do not fit, measured --; 5-6: 18.5 KiB -> 8; 7-9: 34.5 KiB -> 4); a grid larger
-	// than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 7 ? 4u : level >= 5 ? 8u : 10u;
+	// -- 11 do not fit, measured --; 5-6: 18.5 KiB -> 8; 7-8: 27 KiB -> 5; 9: 34.5 KiB -> 4); a grid
+	// larger than what is resident would run its tail serially
+	const uint32_t per_cu = level >= 9 ? 4u : level >= 7 ? 5u : level >= 5 ? 8u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -41,13 +41,13 @@ inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 // input byte of the largest block the launch admits, + histograms).  Sub-batches are as large as this
 // budget allows (measured on 16 GiB of 0xff00-byte blocks at level 2, 4 B per byte: 4.1 GiB -> 148,
 // 8.2 GiB -> 154, 33 GiB -> 158 GB/s), at most 65536 blocks.
-constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)8448 << 20;
+constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)12672 << 20;
 constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 16u : level <= 4 ? 11u : level <= 6 ? 9u : 4u);
+	return 256u * (level == 2 ? 16u : level <= 4 ? 11u : level <= 6 ? 9u : level <= 8 ? 6u : 4u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)
@@ -893,12 +893,16 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 {
 	if (level == 2)
 		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
-	else if (level <= 4)
+	else if (level == 3)
 		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
+	else if (level == 4)
+		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	else if (level <= 6)
 		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
-	else
+	else if (level <= 8)
 		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
+	else
+		launch_level<HD_L9_WIN_BITS, HD_L9_HASH_BITS, HD_L9_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	return 0;
 }
 

@@ -40,21 +40,29 @@
 #define HD_L2_WIN_BITS     12
 #define HD_L2_HASH_BITS    11
 #define HD_L2_MIN_LEN      4
-/* levels 3..4: the same with an 8 KiB ring; tokens buffered in a per-wave scratch slab in HBM
+/* level 3: the same with an 8 KiB ring; tokens buffered in a per-wave scratch slab in HBM
  * between the parse and the emit pass */
 #define HD_L3_WIN_BITS     13
 #define HD_L3_HASH_BITS    11
 #define HD_L3_MIN_LEN      4
-/* levels 5..6: one-lane-lookahead lazy parse, dynamic Huffman, in the level-2 window
- * with twice the table: 19 KiB of LDS, 8 waves per CU */
+/* level 4: level 3's geometry (11 parse waves per CU) with the lazy rule of the higher levels:
+ * one-lane lookahead, minimum length 5 */
+#define HD_L4_WIN_BITS     13
+#define HD_L4_HASH_BITS    11
+#define HD_L4_MIN_LEN      5
+/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring with twice the table: 9 parse waves per CU */
 #define HD_L5_WIN_BITS     13
 #define HD_L5_HASH_BITS    12
 #define HD_L5_MIN_LEN      5
-/* levels 7..9: the same parse with a 16 KiB ring and a 2^13 table (text: 3.5 % smaller
- * output than levels 5..6; 34.5 KiB of LDS, 4 waves per CU, about half the speed) */
+/* levels 7..8: the same parse with a 16 KiB ring (6 parse waves per CU) */
 #define HD_L7_WIN_BITS     14
-#define HD_L7_HASH_BITS    13
+#define HD_L7_HASH_BITS    12
 #define HD_L7_MIN_LEN      5
+/* level 9: 16 KiB ring and a 2^13 table (text: 3 % smaller output than levels 5..6; 34.5 KiB of
+ * LDS, 4 waves per CU, about half the speed) */
+#define HD_L9_WIN_BITS     14
+#define HD_L9_HASH_BITS    13
+#define HD_L9_MIN_LEN      5
 
 #define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
 

@@ -689,14 +689,20 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
 				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush);
-	if (level <= 4)
+	if (level == 3)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
 				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush);
+	if (level == 4)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
+				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush);
 	if (level <= 6)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
 				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush);
-	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-			       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush);
+	if (level <= 8)
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
+				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush);
+	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L9_WIN_BITS, HD_L9_HASH_BITS,
+			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
