@@ -276,6 +276,8 @@ int main(int argc, char **argv)
 					decode = 1;
 				else if (*p == 'c')
 					;
+				else if (*p == '@')
+					break;                          /* -@<threads>: accepted and ignored */
 				else if (*p == 'X')
 					extreme = 1;
 				else if (*p == 'G' || *p == 'l') {

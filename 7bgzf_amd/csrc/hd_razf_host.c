@@ -270,6 +270,8 @@ int main(int argc, char **argv)
 					decode = 1;
 				else if (*p == 'c')
 					;
+				else if (*p == '@')
+					break;                          /* -@<threads>: accepted and ignored */
 				else if (*p == 'G' || *p == 'l') {
 					level = p[1] ? atoi(p + 1) : 1;
 					break;
