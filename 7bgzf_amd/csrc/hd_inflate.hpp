@@ -466,10 +466,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const bool mine0 = (real0 >> lane) & 1, mine1 = (real1 >> lane) & 1;
 			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid where mine
 			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
-			if (mine0 && s0.is_lit)
-				L.ring[opos0 & (INF_RING - 1)] = (uint8_t)(s0.e >> 16);
-			if (mine1 && s1.is_lit)
-				L.ring[opos1 & (INF_RING - 1)] = (uint8_t)(s1.e >> 16);
+			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
+			L.ring[(mine0 && s0.is_lit) ? (opos0 & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)(s0.e >> 16);
+			L.ring[(mine1 && s1.is_lit) ? (opos1 & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)(s1.e >> 16);
 			const uint32_t wend = pos + cum;
 			// per-lane verdicts for the matches, so that the scalar loops below only dispatch
 			const bool match0 = mine0 && s0.is_len, match1 = mine1 && s1.is_len;
