@@ -539,6 +539,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			}
 			pos = wend;
 			B += b;
+			// the walk stopped in front of a token no window takes (long codeword, end of block): a new
+			// window there would come back empty (6 % of all windows did) -- the scalar loop is next
+			if ((wm & 64) && !(over0 | over1))
+				break;
 		}
 		// hand the position back to the scalar reader
 		dw = B >> 5;
