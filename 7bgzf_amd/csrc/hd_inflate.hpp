@@ -220,22 +220,26 @@ __device__ __noinline__ uint32_t build_table(const uint8_t *lens, uint32_t nsyms
 	return 1;
 }
 
-// bit-serial canonical decode for codewords longer than the direct table;
-// returns symbol | length << 16.  (Function results come back in VGPRs: callers
-// pass them through readfirstlane so that the decode state stays scalar.)
-__device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted)
+// Canonical decode for codewords longer than the direct table; returns symbol | length << 16.
+// All fifteen lengths are tried at once: lane l holds count[l], two prefix sums give its length's first
+// codeword (first[l] = sum_{k<l} count[k] << (l - k), i.e. the Kraft sum in 2^-15 units shifted back) and
+// its offset into the sorted symbols, one ballot finds the length that matches.  (The bit-serial loop it
+// replaces paid an LDS round trip per length: ~1 M such tokens per GiB of a libdeflate-6 stream.)
+__device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count, const uint16_t *sorted, uint32_t lane)
 {
-	uint32_t code = 0, first = 0, index = 0;
-	for (uint32_t l = 1; l <= 15; l++) {
-		code |= (uint32_t)(bb >> (l - 1)) & 1;
-		const uint32_t cnt = uniform(count[l]);
-		if (code - first < cnt)
-			return uniform(sorted[index + (code - first)]) | (l << 16);
-		index += cnt;
-		first = (first + cnt) << 1;
-		code <<= 1;
-	}
-	return 15u << 16;
+	const bool in = lane >= 1 && lane < 16;
+	const uint32_t l = lane & 15;
+	const uint32_t cnt = in ? count[l] : 0u;
+	const uint32_t scaled = cnt << (15 - l);
+	const uint32_t first = (wave_incl_scan(scaled) - scaled) >> (15 - l);
+	const uint32_t offs = wave_incl_scan(cnt) - cnt;
+	const uint32_t code = __brev((uint32_t)bb) >> (32 - (l ? l : 1));     // the first l stream bits, MSB first
+	const uint32_t d = code - first;
+	const uint64_t hit = __ballot(in && d < cnt);
+	if (!hit)
+		return 15u << 16;
+	const uint32_t len = (uint32_t)__ffsll((unsigned long long)hit) - 1;
+	return (uint32_t)sorted[readlane(offs + d, len)] | (len << 16);
 }
 
 __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				uint32_t e = readlane(LT[li >> 6], li & 63);
 				if (((e >> 8) & 3) == K_SLOW) {
 					INF_STAT(3, 1);
-					const uint32_t sl = uniform(slow_decode(bb, L.lit_count, L.lit_sorted));
+					const uint32_t sl = uniform(slow_decode(bb, L.lit_count, L.lit_sorted, lane));
 					e = litlen_entry(sl & 0xffff, sl >> 16);
 				}
 				const uint32_t clen = e & 15;
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				uint32_t d = readlane(DT[di >> 6], di & 63);
 				if (((d >> 8) & 3) == K_SLOW) {
 					INF_STAT(4, 1);
-					const uint32_t sl = uniform(slow_decode(bb, L.off_count, L.off_sorted));
+					const uint32_t sl = uniform(slow_decode(bb, L.off_count, L.off_sorted, lane));
 					d = offset_entry(sl & 0xffff, sl >> 16);
 				}
 				const uint32_t dlen = d & 15, deb = (d >> 4) & 15;
