@@ -1013,6 +1013,15 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	return 0;
 }
 
+#ifdef HD_EMIT_STATS
+int hipdeflate_test_emit_stats(uint64_t *out8)
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_emit_stats), 64));
+	return 0;
+}
+#endif
+
 #ifdef HD_INFLATE_STATS
 int hipdeflate_test_inflate_stats(uint64_t *out8)
 {

@@ -94,6 +94,16 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int 
 	       (uint64_t)split_sub_batch(nblocks, split_max, level) * split_layout(split_max).bytes + 16;
 }
 
+#ifdef HD_EMIT_STATS
+// experiment build only: cycles of the emit-only kernel by phase (tools/exp_emit_stats.sh)
+__device__ unsigned long long g_emit_stats[8];
+#define EMIT_T0() const unsigned long long t_ph = EMIT ? clock64() : 0ull
+#define EMIT_T(k) do { if (EMIT && lane == 0) atomicAdd(&g_emit_stats[k], clock64() - t_ph); } while (0)
+#else
+#define EMIT_T0() do { } while (0)
+#define EMIT_T(k) do { } while (0)
+#endif
+
 struct HuffScratch {
 	uint32_t freq[288];      // working copy (dummy symbols added)
 	uint32_t nf[576];        // node weights: leaves ascending, then internal nodes
@@ -473,8 +483,13 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		auto flush_block = [&](bool final) -> bool {
 			if (lane == 0)
 				L.lf[256] += 1;                     // end of block
-			build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane);
-			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, Bd.hs, lane);
+			{
+				EMIT_T0();
+				build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane);
+				build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, Bd.hs, lane);
+				EMIT_T(0);
+			}
+			EMIT_T0();
 			if (lane < 19)
 				L.pfreq[lane] = 0;
 			if (lane == 0) {
@@ -527,6 +542,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				L.misc[1] = hlit;
 				L.misc[2] = hdist;
 			}
+			EMIT_T(1);
 			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane);
 			const uint32_t ni = uniform(L.misc[0]), hlit = uniform(L.misc[1]), hdist = uniform(L.misc[2]);
 			uint32_t hclen = 19;
@@ -600,10 +616,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			// straight-line: both forms are computed and one is selected; a token's two fields
 			// (litlen code + extra bits, offset code + extra bits: <= 20 + 28 bits) go out as
 			// one 64-bit OR over up to three dwords
-			for (uint32_t base = 0; base < ntok_slab; base += 64) {
-				const uint32_t k = base + lane;
-				const bool valid = k < ntok_slab;
-				const uint32_t tk = valid ? tok[k] : 0u;
+			auto put_tokens = [&](uint32_t tk, uint32_t base) {
+				const bool valid = base + lane < ntok_slab;
 				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
 				uint32_t ls, leb, lev, ds, deb, dev;
 				len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
@@ -626,7 +640,37 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				atomicOr(&stage[(i + 2) & (STG - 1)], hi);
 				bitpos += readlane(incl, 63);
 				flush_ready();
+			};
+			EMIT_T(2);
+			if (EMIT) {
+				// The emit-only kernel reads its tokens from HBM: one dependent load per 64 tokens left the
+				// wave waiting for memory most of the time (~0.5 us per iteration).  Tokens come in groups of
+				// eight loads issued back to back, and the next group is requested before the current one is
+				// coded.  (Reloading a register right after its use does not work: with the staging ring's
+				// stores in the loop the compiler waits for vmcnt(0) before every use, i.e. for the load just
+				// issued as well.)
+				constexpr uint32_t PF = 8;
+				uint32_t cur[PF], nxt[PF];
+#pragma unroll
+				for (uint32_t j = 0; j < PF; j++)
+					nxt[j] = 64 * j + lane < ntok_slab ? tok[64 * j + lane] : 0u;
+				for (uint32_t base = 0; base < ntok_slab; base += 64 * PF) {
+#pragma unroll
+					for (uint32_t j = 0; j < PF; j++) {
+						cur[j] = nxt[j];
+						const uint32_t kn = base + 64 * (PF + j) + lane;
+						nxt[j] = kn < ntok_slab ? tok[kn] : 0u;
+					}
+#pragma unroll
+					for (uint32_t j = 0; j < PF; j++)
+						if (base + 64 * j < ntok_slab)
+							put_tokens(cur[j], base + 64 * j);
+				}
+			} else {
+				for (uint32_t base = 0; base < ntok_slab; base += 64)
+					put_tokens(base + lane < ntok_slab ? tok[base + lane] : 0u, base);
 			}
+			EMIT_T(3);
 			{
 				const uint32_t eob = Bd.lcode[256];
 				emit1(lane == 0 ? (eob & 0xffff) : 0u, lane == 0 ? (eob >> 16) : 0u);
