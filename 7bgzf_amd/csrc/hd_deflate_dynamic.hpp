@@ -492,59 +492,87 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			EMIT_T0();
 			if (lane < 19)
 				L.pfreq[lane] = 0;
-			if (lane == 0) {
-				uint32_t hlit = 286, hdist = 30;
-				while (hlit > 257 && (Bd.lcode[hlit - 1] >> 16) == 0)
-					hlit--;
-				while (hdist > 1 && (Bd.dcode[hdist - 1] >> 16) == 0)
-					hdist--;
-				for (uint32_t i = 0; i < hlit; i++)
-					Bd.lens()[i] = (uint8_t)(Bd.lcode[i] >> 16);
-				for (uint32_t i = 0; i < hdist; i++)
-					Bd.lens()[hlit + i] = (uint8_t)(Bd.dcode[i] >> 16);
-				const uint32_t total = hlit + hdist;
-				uint32_t ni = 0, i = 0;
-				while (i < total) {
-					const uint32_t v = Bd.lens()[i];
-					uint32_t run = 1;
-					while (i + run < total && Bd.lens()[i + run] == v)
-						run++;
-					i += run;
-					if (v == 0) {
-						while (run >= 11) {
-							const uint32_t r = run < 138 ? run : 138;
-							Bd.items()[ni++] = (uint16_t)(18 | ((r - 11) << 8));
-							L.pfreq[18]++;
-							run -= r;
-						}
-						if (run >= 3) {
-							Bd.items()[ni++] = (uint16_t)(17 | ((run - 3) << 8));
-							L.pfreq[17]++;
-							run = 0;
-						}
-					} else {
-						Bd.items()[ni++] = (uint16_t)v;
-						L.pfreq[v]++;
-						run--;
-						while (run >= 3) {
-							const uint32_t r = run < 6 ? run : 6;
-							Bd.items()[ni++] = (uint16_t)(16 | ((r - 3) << 8));
-							L.pfreq[16]++;
-							run -= r;
-						}
-					}
-					while (run--) {
-						Bd.items()[ni++] = (uint16_t)v;
-						L.pfreq[v]++;
-					}
+			// ---- code lengths and their RLE (deflate_compute_precode_items, deflate_compress.c:1483-1557),
+			// by all lanes: on lane 0 this loop was a fifth of the emit kernel's time (~300 dependent LDS
+			// round trips).  hlit / hdist from two ballots; run starts by ballot + popcount per 64 lengths;
+			// one lane per run computes how many 18 / 17 / 16 / literal items the greedy rule makes of it, a
+			// prefix sum places them, the lane writes them.
+			uint32_t hlit, hdist;
+			{
+				const uint64_t ml = __ballot(lane < 29 && (Bd.lcode[257 + lane] >> 16) != 0);
+				const uint64_t md = __ballot(lane < 29 && (Bd.dcode[1 + lane] >> 16) != 0);
+				hlit = ml ? 257 + 64 - (uint32_t)__clzll((long long)ml) : 257;
+				hdist = md ? 1 + 64 - (uint32_t)__clzll((long long)md) : 1;
+			}
+			const uint32_t total = hlit + hdist;
+			uint8_t *lens = Bd.lens();
+			uint16_t *items = Bd.items();
+			uint16_t *run_start = Bd.hs.parent;            // free until the precode is built
+			for (uint32_t i = lane; i < total; i += 64)
+				lens[i] = (uint8_t)((i < hlit ? Bd.lcode[i] : Bd.dcode[i - hlit]) >> 16);
+			uint32_t nruns = 0;
+			for (uint32_t base = 0; base < total; base += 64) {
+				const uint32_t i = base + lane;
+				const bool st = i < total && (i == 0 || lens[i] != lens[i - 1]);
+				const uint64_t m = __ballot(st);
+				if (st)
+					run_start[nruns + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+				nruns += (uint32_t)__popcll(m);
+			}
+			if (lane == 0)
+				run_start[nruns] = (uint16_t)total;
+			uint32_t ni = 0;
+			for (uint32_t rb = 0; rb < nruns; rb += 64) {
+				const uint32_t r = rb + lane;
+				const bool valid = r < nruns;
+				const uint32_t s0 = valid ? run_start[r] : 0, len = valid ? run_start[r + 1] - s0 : 0;
+				const uint32_t v = valid ? lens[s0] : 0;
+				// the greedy rule in closed form: `big` full-size repeat items, one more for a rest that is
+				// long enough, single symbols for what is left (and in front, for a non-zero length)
+				uint32_t rep, big, rest, lead;
+				if (v == 0) {
+					rep = 18; lead = 0;
+					big = len / 138; rest = len - 138 * big;
+				} else {
+					rep = 16; lead = valid ? 1u : 0u;
+					big = (len - lead) / 6; rest = (len - lead) - 6 * big;
 				}
+				const uint32_t full = v == 0 ? 138u : 6u, base_len = v == 0 ? 11u : 3u;
+				uint32_t extra_rep = 0, extra_sym = rep, extra_base = base_len;   // the one item for the rest
+				if (rest >= base_len) {
+					extra_rep = 1;
+				} else if (v == 0 && rest >= 3) {
+					extra_rep = 1; extra_sym = 17; extra_base = 3;
+				}
+				const uint32_t tail = extra_rep ? 0u : rest;
+				const uint32_t c = valid ? lead + big + extra_rep + tail : 0u;
+				const uint32_t incl = wave_incl_scan(c);
+				uint32_t o = ni + incl - c;
+				if (valid) {
+					if (lead)
+						items[o++] = (uint16_t)v;
+					for (uint32_t j = 0; j < big; j++)
+						items[o++] = (uint16_t)(rep | ((full - base_len) << 8));
+					if (extra_rep)
+						items[o++] = (uint16_t)(extra_sym | ((rest - extra_base) << 8));
+					for (uint32_t j = 0; j < tail; j++)
+						items[o++] = (uint16_t)v;
+					if (lead + tail)
+						atomicAdd(&L.pfreq[v], lead + tail);
+					if (big)
+						atomicAdd(&L.pfreq[rep], big);
+					if (extra_rep)
+						atomicAdd(&L.pfreq[extra_sym], 1u);
+				}
+				ni += readlane(incl, 63);
+			}
+			if (lane == 0) {
 				L.misc[0] = ni;
 				L.misc[1] = hlit;
 				L.misc[2] = hdist;
 			}
 			EMIT_T(1);
 			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane);
-			const uint32_t ni = uniform(L.misc[0]), hlit = uniform(L.misc[1]), hdist = uniform(L.misc[2]);
 			uint32_t hclen = 19;
 			while (hclen > 4 && (uniform(L.pcode[k_perm19[hclen - 1]]) >> 16) == 0)
 				hclen--;
