@@ -168,3 +168,28 @@ def test_kernel_resource_budgets():
         assert units <= want, (k, v)                 # 16 / 11 / 9 / 6 / 4 waves per CU: parse_slots()
     (v,) = inf.values()
     assert v["VGPRs"] <= 72 and v["LDS Size"] <= 6400, v         # five LDS units, 7 waves per SIMD: 25 waves per CU
+
+
+def test_container_hosts_crc_fold_matches_zlib(tmp_path):
+    """hd7dictzip / hd7razf write a member's CRC-32 folded from the kernel's per-chunk CRCs
+    (7bgzf_amd/csrc/hd_host_util.h: crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/P).  The fold itself needs
+    no GPU: compiled here and compared with zlib.crc32 over random splits, equal and ragged chunk sizes."""
+    import subprocess
+    import zlib
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "crc_fold_check.c")
+    inc = os.path.join(hdtest.ROOT, "7bgzf_amd", "csrc")
+    exe = str(tmp_path / "crc_fold_check")
+    subprocess.run(["gcc", "-O2", "-I", inc, "-o", exe, src], check=True)
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        data = rng.integers(0, 256, int(rng.integers(1, 400000)), dtype=np.uint8).tobytes()
+        if trial % 3 == 0:
+            cuts = list(range(0, len(data), 58315)) + [len(data)]                 # dictzip's chunking
+        elif trial % 3 == 1:
+            cuts = list(range(0, len(data), 32768)) + [len(data)]                 # razf's
+        else:
+            cuts = sorted(set([0, len(data)] + [int(x) for x in rng.integers(0, len(data) + 1, 9)]))
+        parts = [data[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        text = "".join("%08x %d\n" % (zlib.crc32(p), len(p)) for p in parts)
+        out = subprocess.run([exe], input=text.encode(), capture_output=True, check=True).stdout.decode().strip()
+        assert int(out, 16) == zlib.crc32(data), (trial, len(parts))
