@@ -176,6 +176,7 @@ def test_container_hosts_crc_fold_matches_zlib(tmp_path):
     no GPU: compiled here and compared with zlib.crc32 over random splits, equal and ragged chunk sizes."""
     import subprocess
     import zlib
+    import numpy as np
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "crc_fold_check.c")
     inc = os.path.join(hdtest.ROOT, "7bgzf_amd", "csrc")
     exe = str(tmp_path / "crc_fold_check")
