@@ -47,7 +47,7 @@ constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 16u : level <= 4 ? 11u : level <= 6 ? 9u : level <= 8 ? 6u : 4u);
+	return 256u * (level == 2 ? 18u : level <= 4 ? 11u : level <= 6 ? 9u : level <= 8 ? 6u : 4u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
-	constexpr uint32_t HS = 1u << HASH_BITS;
+	constexpr uint32_t HS = HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
 	// staging ring (dwords) and flush granule: the token loop adds up to 64 x 48 bits = 96 dwords to
 	// fewer than FLUSH_DW pending ones before it flushes one granule, so 128 + 96 <= 256 is what it takes
 	// (a 128-dword ring would do for typical data and overflow on 48-bit tokens)
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 			f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 			const bool can = p + HD_MIN_MATCH <= n;
-			const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : HS;
+			const uint32_t h = can ? HD_TABLE_INDEX((f.v * HD_HASH_MUL) >> (32 - HASH_BITS), WIN_BITS, HASH_BITS) : HS;
 			const uint16_t mine = (uint16_t)(p + 1);
 			const uint32_t e = table[h];
 			table[h] = mine;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
-	constexpr uint32_t HS = 1u << HASH_BITS;
+	constexpr uint32_t HS = HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
 	constexpr uint32_t STG = 256;            // staging ring, dwords
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 	constexpr uint32_t TOKQ = 128;           // token queue: < 64 waiting + <= 64 of one step
@@ -238,8 +238,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t WAVES16 = 163840 / (((LDS_REST + 632 + 1279) / 1280) * 1280);
 	constexpr bool PACK16 = TOK && WAVES16 > WAVES32;
 	__shared__ __attribute__((aligned(16))) uint32_t stage[TOK ? (PACK16 ? 158 : 316) : STG];
-	// tokens waiting for the emit pass; [TOKQ, TOKQ + 64) = dump slots of lanes without one
-	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 64];
+	// tokens waiting for the emit pass; [TOKQ, TOKQ + 32) = dump slots of lanes without one (two lanes share
+	// a slot: what lands there is never read)
+	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 32];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 
 	const uint32_t lane = threadIdx.x;
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const bool can = INNER || p + HD_MIN_MATCH <= n;
 		// (a lane past the end of the block publishes nothing; it reads slot 0, harmlessly)
-		const uint32_t h = can ? (f.v * HD_HASH_MUL) >> (32 - HASH_BITS) : 0u;
+		const uint32_t h = can ? HD_TABLE_INDEX((f.v * HD_HASH_MUL) >> (32 - HASH_BITS), WIN_BITS, HASH_BITS) : 0u;
 		const uint16_t mine = (uint16_t)(p + 1);
 		const uint32_t e = table[h];
 		if (can)
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 				if (is_tok)
 					tokbuf[(qtail + rank) & (TOKQ - 1)] = tw;
 			} else {
-				tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + lane] = tw;
+				tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + (lane & 31)] = tw;
 			}
 			qtail += (uint32_t)__popcll(tm);
 		}

@@ -115,7 +115,7 @@ static void put_static_match(bw_t *w, unsigned len, unsigned off)
 
 /* ---- one parse step ---------------------------------------------------- */
 typedef struct {
-	uint16_t *table;      /* 1 << hash_bits entries: (position + 1) mod 2^16, 0 = empty */
+	uint16_t *table;      /* HD_TABLE_ENTRIES entries: (position + 1) mod 2^16, 0 = empty */
 	unsigned hash_bits;
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
@@ -134,6 +134,14 @@ typedef struct {
 static uint32_t load32(const uint8_t *p)
 {
 	return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+/* table slot of the four bytes v: the hash, scaled to the 1536 entries the 4 KiB-ring levels keep
+ * (HD_TABLE_INDEX, include/hipdeflate_params.h) */
+static uint32_t mf_index(const mf_t *mf, uint32_t v)
+{
+	const uint32_t h = (v * HD_HASH_MUL) >> (32 - mf->hash_bits);
+	return HD_TABLE_INDEX(h, mf->win == 4096 ? 12u : 0u, mf->hash_bits);
 }
 
 static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
@@ -156,7 +164,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 		if (p + HD_MIN_MATCH > n)
 			continue;
 		uint32_t v = load32(in + p);
-		uint32_t e = mf->table[(v * HD_HASH_MUL) >> (32 - mf->hash_bits)];
+		uint32_t e = mf->table[mf_index(mf, v)];
 		/* the latest p' < p with p' + 1 == e (mod 2^16); for inputs <= 64 KiB
 		 * that is simply e */
 		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
@@ -177,7 +185,7 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 			continue;
 		/* the kernel's lanes race for the slot and re-write until the largest
 		 * position of the step holds it: within a step the last lane wins */
-		mf->table[(load32(in + p) * HD_HASH_MUL) >> (32 - mf->hash_bits)] = (uint16_t)(p + 1);
+		mf->table[mf_index(mf, load32(in + p))] = (uint16_t)(p + 1);
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 3. verify */
 		size_t p = S + l;
