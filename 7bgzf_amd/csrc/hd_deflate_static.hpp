@@ -22,9 +22,9 @@
 //   stores.
 //
 // HBM traffic per block: input read once (16 B/lane pieces), output written
-// once.  LDS per wave: ring 2^WIN_BITS + table 2*2^HASH_BITS + 1 KiB staging +
-// 768 B token queue = 9.8 KiB at level 1: 8 of the 1280-byte units LDS is granted
-// in, 16 waves per CU.
+// once.  LDS per wave: ring 2^WIN_BITS + table (2 B x HD_TABLE_ENTRIES) + 1 KiB staging +
+// 640 B token queue = 8848 B at level 1: 7 of the 1280-byte units LDS is granted
+// in, 18 waves per CU.
 #pragma once
 #include <type_traits>
 #include "hd_device.hpp"
