@@ -47,7 +47,7 @@ constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 18u : level <= 4 ? 11u : level <= 6 ? 9u : level <= 8 ? 6u : 4u);
+	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 6 ? 9u : level <= 8 ? 6u : 4u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)

@@ -65,10 +65,11 @@
 #define HD_L9_MIN_LEN      5
 
 #define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
-/* Entries of the hash table.  The 4 KiB-ring levels (1 and 2) keep three quarters of 2^11 -- the hash's 11
- * bits scaled by 3/4 --: LDS is granted in 1280-byte units and 1536 entries are what brings the level-1
- * kernel from 8 units to 7, 18 waves per CU instead of 16 (measured: 220 -> 228 GB/s for 1.2 % more output). */
-#define HD_TABLE_34(win_bits, hash_bits)      ((win_bits) == 12 && (hash_bits) == 11)
+/* Entries of the hash table.  The levels with 11 hash bits (1..4) keep three quarters of 2^11 -- the hash's
+ * 11 bits scaled by 3/4 --: LDS is granted in 1280-byte units and 1536 entries are what brings the level-1
+ * kernel from 8 units to 7, 18 waves per CU instead of 16 (measured: 220 -> 228 GB/s for 1.2 % more output),
+ * and the parse of levels 3..4 from 11 waves to 12 (level 3: 141 -> 147 GB/s for 0.8 % more output). */
+#define HD_TABLE_34(win_bits, hash_bits)      ((win_bits) <= 13 && (hash_bits) == 11)
 #define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? 1536u : (1u << (hash_bits)))
 #define HD_TABLE_INDEX(h, win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? ((h) * 3u) >> 2 : (h))
 

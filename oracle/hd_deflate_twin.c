@@ -141,7 +141,7 @@ static uint32_t load32(const uint8_t *p)
 static uint32_t mf_index(const mf_t *mf, uint32_t v)
 {
 	const uint32_t h = (v * HD_HASH_MUL) >> (32 - mf->hash_bits);
-	return HD_TABLE_INDEX(h, mf->win == 4096 ? 12u : 0u, mf->hash_bits);
+	return HD_TABLE_INDEX(h, (unsigned)__builtin_ctz(mf->win), mf->hash_bits);
 }
 
 static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,

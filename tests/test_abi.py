@@ -163,9 +163,9 @@ def test_kernel_resource_budgets():
         assert v["VGPRs"] <= 128, (k, v)
         units = -(-v["LDS Size"] // 1280)
         tok = "ELb1E" in k                           # parse kernels; level 1 itself is ELb0E
-        want = 7 if "Li12ELi11E" in k else 11 if "Li13ELi11E" in k else (14 if tok else 16) if "Li13ELi12E" in k else \
+        want = 7 if "Li12ELi11E" in k else 10 if "Li13ELi11E" in k else (14 if tok else 16) if "Li13ELi12E" in k else \
             21 if "Li14ELi12E" in k else 32
-        assert units <= want, (k, v)                 # 18 / 11 / 9 / 6 / 4 waves per CU: parse_slots()
+        assert units <= want, (k, v)                 # 18 / 12 / 9 / 6 / 4 waves per CU: parse_slots()
     (v,) = inf.values()
     assert v["VGPRs"] <= 72 and v["LDS Size"] <= 6400, v         # five LDS units, 7 waves per SIMD: 25 waves per CU
 
