@@ -50,7 +50,7 @@
 #define HD_L4_WIN_BITS     13
 #define HD_L4_HASH_BITS    11
 #define HD_L4_MIN_LEN      5
-/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring with twice the table: 9 parse waves per CU */
+/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring, 12 hash bits over 2560 entries: 10 parse waves per CU */
 #define HD_L5_WIN_BITS     13
 #define HD_L5_HASH_BITS    12
 #define HD_L5_MIN_LEN      5
@@ -68,10 +68,14 @@
 /* Entries of the hash table.  The levels with 11 hash bits (1..4) keep three quarters of 2^11 -- the hash's
  * 11 bits scaled by 3/4 --: LDS is granted in 1280-byte units and 1536 entries are what brings the level-1
  * kernel from 8 units to 7, 18 waves per CU instead of 16 (measured: 220 -> 228 GB/s for 1.2 % more output),
- * and the parse of levels 3..4 from 11 waves to 12 (level 3: 141 -> 147 GB/s for 0.8 % more output). */
+ * and the parse of levels 3..4 from 11 waves to 12 (level 3: 141 -> 147 GB/s for 0.8 % more output).
+ * Levels 5..6 (8 KiB ring, 12 hash bits) keep five eighths of 2^12 = 2560 entries: 12 units instead of 14,
+ * 10 parse waves instead of 9 (level 6: 106 -> 116 GB/s on the FASTQ-like set at the same ratio, 89 -> 99 on
+ * text for 1.6 % more output; MiGz 1 MiB text 86 -> 96). */
 #define HD_TABLE_34(win_bits, hash_bits)      ((win_bits) <= 13 && (hash_bits) == 11)
-#define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? 1536u : (1u << (hash_bits)))
-#define HD_TABLE_INDEX(h, win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? ((h) * 3u) >> 2 : (h))
+#define HD_TABLE_58(win_bits, hash_bits)      ((win_bits) == 13 && (hash_bits) == 12)
+#define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? 1536u : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
+#define HD_TABLE_INDEX(h, win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? ((h) * 3u) >> 2 : HD_TABLE_58(win_bits, hash_bits) ? ((h) * 5u) >> 3 : (h))
 
 /* Besides the hash table, which only knows earlier steps, a lane takes the lane just before it as its
  * candidate when that one holds the same four bytes (a run of five equal bytes): the latest occurrence,
