@@ -30,9 +30,9 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
 	// one persistent wave per LDS slot of the level (levels 2-4: 14.5 KiB -> 10 resident per CU
-	// -- 11 do not fit, measured --; 5-6: 16 KiB -> 9; 7-8: 27 KiB -> 5; 9: 34.5 KiB -> 4); a grid
+	// -- 11 do not fit, measured --; 5-6: 16 KiB -> 9; 7-8: 27 KiB -> 5; 9: 31 KiB -> 5); a grid
 	// larger than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 9 ? 4u : level >= 7 ? 5u : level >= 5 ? 9u : 10u;
+	const uint32_t per_cu = level >= 7 ? 5u : level >= 5 ? 9u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -47,7 +47,7 @@ constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 6 ? 10u : level <= 8 ? 6u : 4u);
+	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 6 ? 10u : level <= 8 ? 6u : 5u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)

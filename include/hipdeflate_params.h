@@ -58,8 +58,8 @@
 #define HD_L7_WIN_BITS     14
 #define HD_L7_HASH_BITS    12
 #define HD_L7_MIN_LEN      5
-/* level 9: 16 KiB ring and a 2^13 table (text: 3 % smaller output than levels 5..6; 34.5 KiB of
- * LDS, 4 waves per CU, about half the speed) */
+/* level 9: 16 KiB ring, 13 hash bits over 6144 entries (text: 4 % smaller output than levels 5..6;
+ * 30 KiB of LDS, 5 waves per CU, about half the speed) */
 #define HD_L9_WIN_BITS     14
 #define HD_L9_HASH_BITS    13
 #define HD_L9_MIN_LEN      5
@@ -71,10 +71,11 @@
  * and the parse of levels 3..4 from 11 waves to 12 (level 3: 141 -> 147 GB/s for 0.8 % more output).
  * Levels 5..6 (8 KiB ring, 12 hash bits) keep five eighths of 2^12 = 2560 entries: 12 units instead of 14,
  * 10 parse waves instead of 9 (level 6: 106 -> 116 GB/s on the FASTQ-like set at the same ratio, 89 -> 99 on
- * text for 1.6 % more output; MiGz 1 MiB text 86 -> 96). */
-#define HD_TABLE_34(win_bits, hash_bits)      ((win_bits) <= 13 && (hash_bits) == 11)
+ * text for 1.6 % more output; MiGz 1 MiB text 86 -> 96).  Level 9 (16 KiB ring, 13 hash bits) keeps three
+ * quarters of 2^13: 24 units instead of 27, 5 parse waves instead of 4 (text: 46 -> 54 GB/s for 0.7 % more output). */
+#define HD_TABLE_34(win_bits, hash_bits)      (((win_bits) <= 13 && (hash_bits) == 11) || ((win_bits) == 14 && (hash_bits) == 13))
 #define HD_TABLE_58(win_bits, hash_bits)      ((win_bits) == 13 && (hash_bits) == 12)
-#define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? 1536u : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
+#define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? (3u << ((hash_bits) - 2)) : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
 #define HD_TABLE_INDEX(h, win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? ((h) * 3u) >> 2 : HD_TABLE_58(win_bits, hash_bits) ? ((h) * 5u) >> 3 : (h))
 
 /* Besides the hash table, which only knows earlier steps, a lane takes the lane just before it as its

@@ -155,8 +155,8 @@ def test_kernel_resource_budgets():
         assert v["VGPRs"] <= 168, (k, v)
         # LDS is granted in 1280-byte units (measured: 10 waves of 15584 B do not fit a CU, of 15328 B do)
         units = -(-v["LDS Size"] // 1280)
-        want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else 14 if "Li13ELi12E" in k else 25 if "Li14ELi12E" in k else 32
-        assert units <= want, (k, v)                 # 10 / 9 / 5 / 4 waves per CU: dynamic_grid()
+        want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else 14 if "Li13ELi12E" in k else 25
+        assert units <= want, (k, v)                 # 10 / 9 / 5 / 5 waves per CU: dynamic_grid()
     (v,) = emit.values()
     assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
     for k, v in sta.items():                                     # level 1 and the parse kernels of levels 2-9
@@ -164,8 +164,8 @@ def test_kernel_resource_budgets():
         units = -(-v["LDS Size"] // 1280)
         tok = "ELb1E" in k                           # parse kernels; level 1 itself is ELb0E
         want = 7 if "Li12ELi11E" in k else 10 if "Li13ELi11E" in k else 12 if "Li13ELi12E" in k else \
-            21 if "Li14ELi12E" in k else 32
-        assert units <= want, (k, v)                 # 18 / 12 / 10 / 6 / 4 waves per CU: parse_slots()
+            21 if "Li14ELi12E" in k else 25
+        assert units <= want, (k, v)                 # 18 / 12 / 10 / 6 / 5 waves per CU: parse_slots()
     (v,) = inf.values()
     assert v["VGPRs"] <= 72 and v["LDS Size"] <= 6400, v         # five LDS units, 7 waves per SIMD: 25 waves per CU
 
