@@ -46,6 +46,7 @@ EXPORTS = [
     "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
     "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
+    "hipdeflate_compact_span_dev",
 ]
 
 
@@ -107,6 +108,7 @@ def lib():
     L.hipdeflate_batch_inflate_flush_dev.argtypes = L.hipdeflate_batch_inflate_dev.argtypes
     L.hipdeflate_scan_sizes_dev.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint64, _vp, _vp, _vp]
     L.hipdeflate_compact_dev.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, ctypes.c_uint32, _vp, _vp]
+    L.hipdeflate_compact_span_dev.argtypes = [_vp, ctypes.c_uint64, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint64, _vp]
     L.hipdeflate_pipe_open.restype = _vp
     L.hipdeflate_pipe_open.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
     L.hipdeflate_pipe_input.restype = _vp

@@ -412,6 +412,13 @@ int hipdeflate_compact_dev(const void *slots, uint64_t stride, const void *out_l
 	return 0;
 }
 
+int hipdeflate_compact_span_dev(const void *slots, uint64_t stride, const void *out_len, const void *dst_off,
+				uint32_t nblocks, void *span, uint64_t span_base, void *stream)
+{
+	// k_compact only ever forms dst + dst_off[i] with dst_off[i] >= span_base: the address of "stream byte 0"
+	return hipdeflate_compact_dev(slots, stride, out_len, dst_off, nblocks, (uint8_t *)span - span_base, stream);
+}
+
 /* ---- host-pointer API ------------------------------------------------------ */
 
 int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const uint32_t *in_len, uint32_t nblocks,

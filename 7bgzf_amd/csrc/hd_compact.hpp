@@ -67,20 +67,31 @@ __global__ __launch_bounds__(256) void k_scan_tiles(uint64_t *tile_sum, uint32_t
 	}
 }
 
-// pass 3: exclusive scan inside each tile
+// pass 3: exclusive scan inside each tile.  The intra-tile sums are 64 bits wide like the other two passes:
+// a tile of 2048 members of >= 2 MiB each (MiGz -b, the uint32 in_len API) passes 4 GiB.
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t x)
+{
+	// x < 2^35 per lane (eight u32): split at bit 26, so that both 32-bit DPP scans stay carry-free
+	// (64 x 2^26 = 2^32 is never reached, 64 x 2^9 is tiny)
+	const uint32_t a = wave_incl_scan((uint32_t)x & 0x3ffffffu);
+	const uint64_t b = wave_incl_scan((uint32_t)(x >> 26));
+	return (uint64_t)a + (b << 26);
+}
+
 __global__ __launch_bounds__(256) void k_scan_finish(const uint32_t *len, uint32_t n, const uint64_t *tile_off, uint64_t *dst_off)
 {
-	__shared__ uint32_t wtot[4];
+	__shared__ uint64_t wtot[4];
 	const uint32_t t = threadIdx.x, tile = blockIdx.x, lane = t & 63, w = t >> 6;
 	// thread t owns 8 consecutive elements
 	const uint32_t i0 = tile * SCAN_TILE + t * 8;
-	uint32_t v[8], s = 0;
+	uint32_t v[8];
+	uint64_t s = 0;
 #pragma unroll
 	for (int k = 0; k < 8; k++) {
 		v[k] = i0 + k < n ? len[i0 + k] : 0;
 		s += v[k];
 	}
-	const uint32_t incl = wave_incl_scan(s);
+	const uint64_t incl = wave_incl_scan64(s);
 	if (lane == 63)
 		wtot[w] = incl;
 	__syncthreads();

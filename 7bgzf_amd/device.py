@@ -41,10 +41,12 @@ class DeviceDeflate:
                                                   _ptr(self.total), _stream())
         _pkg._check(rc, "hipdeflate_scan_sizes_dev")
 
-    def compact(self, dst):
-        rc = _pkg.lib().hipdeflate_compact_dev(_ptr(self.slots), self.slot, _ptr(self.out_len), _ptr(self.dst_off),
-                                               self.nblocks, _ptr(dst), _stream())
-        _pkg._check(rc, "hipdeflate_compact_dev")
+    def compact(self, dst, span_base=0):
+        """members -> dst; with span_base != 0 dst is this rank's span of a sharded stream and
+        dst_off[] (scan(base=span_base)) are offsets in the whole stream"""
+        rc = _pkg.lib().hipdeflate_compact_span_dev(_ptr(self.slots), self.slot, _ptr(self.out_len),
+                                                    _ptr(self.dst_off), self.nblocks, _ptr(dst), span_base, _stream())
+        _pkg._check(rc, "hipdeflate_compact_span_dev")
 
 
 def device_inflate(comp, in_off, in_len, out, out_off, out_cap, out_len, crc, status):

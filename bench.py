@@ -5,22 +5,31 @@ Default workload (BASELINE.json configs[1], the config the metric is quoted on):
   BGZF encode, 0xff00-byte blocks, greedy LZ77 + static Huffman (level 1),
   16 GiB synthetic FASTQ-like bytes resident in HBM, 1 x MI355X.
 One "step" = one pass of the hot path over that batch: the encode kernel over
-all 263,173 blocks, the size prefix scan (plus, with N > 1, the one RCCL
-all_gather of per-rank totals -- SURVEY.md 8(e)) and the gather of the members
-into one contiguous BGZF stream.  value = input bytes of ALL ranks / time.
+all 263,173 blocks, the size prefix scan and the gather of the members into one
+contiguous BGZF stream.  value = input bytes of ALL ranks / time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode encode|decode]
-                  [--level L] [--gib G] [--no-cpu]
+                  [--level L] [--gib G] [--no-cpu] [--no-extra]
 
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU
-(weak scaling: every rank holds its own G GiB shard = a contiguous block range).
+(weak scaling: every rank holds its own G GiB shard = a contiguous block range of
+a G*N GiB stream).  The step then contains the ONE exchange of the path (SURVEY.md
+8(e)): all_gather of the per-rank compressed totals (7bgzf_amd/shard.py, RCCL) ->
+this rank's base -> member offsets in the whole stream (scan with that base) ->
+gather into the rank's span (what the rank would pwrite() at `base`).
+HD_BENCH_FORCE_DIST=1 runs that path at world size 1.
 
 The JSON line also carries
   roofline      the dominant kernel against the HBM roofline, timed with events on
                 the launch stream inside the timed region (DESIGN.md "Measurement")
   cpu_baseline  the REAL reference per-block path (libdeflate 1.23 through
                 libdeflate_deflate, lib/zlibutil.c:179, from oracle/_ref/libref.so)
-                on this box's host cores, on a bounded sample of the same workload.
+                on this box's host cores, on a bounded sample of the same workload;
+                plus the reused-compressor figure, one core alone, and our CPU twin.
+  configs       (N = 1, default invocation only) the other GPU configs of BASELINE.json
+                measured in the same run: level 2 on the same data, decode of the
+                reference's libdeflate-6 stream (config 3), MiGz 1 MiB level 6 on
+                enwik-like text (config 5).
 """
 import argparse
 import ctypes
@@ -37,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-BLOCK = 0xff00                 # applet/7bgzf.c:146-147 (overridden by --block-kib for MiGz)
+BGZF_BLOCK = 0xff00            # applet/7bgzf.c:146-147
 
 
 def parse():
@@ -50,6 +59,7 @@ def parse():
     ap.add_argument("--gib", type=float, default=16.0, help="input GiB per GPU")
     ap.add_argument("--tile-mib", type=int, default=64, help="host-generated tile replicated on the device")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="only the headline config (profiling runs)")
     ap.add_argument("--data", default="fastq", choices=["fastq", "text", "random"],
                     help="fastq = configs[1..3]; text = config 5 (enwik-like); random = config 1 stand-in")
     ap.add_argument("--slot", type=int, default=0, help="experiment: output slot bytes per block (multiple of 16; 0 = default)")
@@ -62,236 +72,348 @@ def parse():
 # ---- CPU baseline: the reference's own per-block function on host cores ------------
 
 
-def cpu_baseline(tile, level, mode, sample_budget_s=16.0):
-    so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
-    ncores = len(os.sched_getaffinity(0))
-    blocks = [tile[i:i + BLOCK] for i in range(0, len(tile) - BLOCK + 1, BLOCK)]
-    if os.path.exists(so):
-        ref = ctypes.CDLL(so)
-        kind = "reference"
-        enc, dec = ref.libdeflate_deflate, ref.libdeflate_inflate
-        what = "libdeflate 1.23 via libdeflate_%s (lib/zlibutil.c), one call per 0xff00 block" % (
-            "deflate" if mode == "encode" else "inflate")
-    else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import hdtest
-        o = hdtest.oracle()
-        kind = "port"
-        enc = o.hdo_deflate_twin
-        dec = lambda d, dl, s, sl: o.hdo_inflate(d, dl, s, sl, None)
-        what = "oracle CPU twin (oracle/_ref not built)"
-    vp = ctypes.c_void_p
+def _pool(work, threads, n_iter):
+    """run work(idx, n_iter) -> bytes done on `threads` python threads (ctypes drops the GIL); GB/s, wall s"""
+    res = [0] * threads
 
-    def enc_block(blk, out):
-        n = ctypes.c_size_t(len(out))
-        r = enc(out.ctypes.data_as(vp), ctypes.byref(n), blk.ctypes.data_as(vp), ctypes.c_size_t(len(blk)), level)
-        assert r == 0
-        return n.value
-
-    comp = None
-    if mode == "decode":
-        comp = []
-        out = np.zeros(BLOCK * 2, dtype=np.uint8)
-        for blk in blocks[:256]:
-            n = enc_block(blk, out)
-            comp.append(out[:n].copy())
-
-    def work(idx, n_iter, res):
-        out = np.zeros(BLOCK * 2, dtype=np.uint8)
-        done = 0
-        t0 = time.perf_counter()
-        for k in range(n_iter):
-            if mode == "encode":
-                blk = blocks[(idx * 7919 + k) % len(blocks)]
-                enc_block(blk, out)
-            else:
-                z = comp[(idx * 31 + k) % len(comp)]
-                n = ctypes.c_size_t(BLOCK)
-                r = dec(out.ctypes.data_as(vp), ctypes.byref(n), z.ctypes.data_as(vp), ctypes.c_size_t(len(z)))
-                assert r == 0 and n.value == BLOCK
-            done += BLOCK
-        res[idx] = (done, time.perf_counter() - t0)
-
-    # calibrate on one core, then size the all-core run to the CPU-work budget
-    res = [None]
-    work(0, 64, res)
-    per_block = res[0][1] / 64
-    one_core = BLOCK / per_block / 1e9
-    threads = min(ncores, 16)          # a one-GPU box owns 16 host cores
-    n_iter = max(16, int(sample_budget_s / per_block / threads))
-    res = [None] * threads
-    th = [threading.Thread(target=work, args=(i, n_iter, res)) for i in range(threads)]
+    def run(i):
+        res[i] = work(i, n_iter)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(threads)]
     t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
-    total = sum(r[0] for r in res)
-    return {"value": round(total / wall / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": kind,
-            "sample": "%s; %d blocks (%.2f GB) of the same FASTQ-like workload over %d threads, %.1f s CPU work; "
-                      "1 core alone: %.4f GB/s" % (what, threads * n_iter, total / 1e9, threads, wall * threads,
-                                                   one_core)}
+    return sum(res) / wall / 1e9, wall
 
 
-def main():
-    global BLOCK
-    args = parse()
-    if args.block_kib:
-        BLOCK = args.block_kib * 1024
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    force_dist = world == 1 and os.environ.get("HD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
-    if world > 1 or force_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    pkg = importlib.import_module("7bgzf_amd")
-    dev = importlib.import_module("7bgzf_amd.device")
-    synth = importlib.import_module("7bgzf_amd.synth")
-    pkg.lib().hipdeflate_init(local)
-    if not pkg.available():
-        raise SystemExit("no usable MI355X; there is no CPU fallback to measure")
-
-    # ---- synthetic input: a seeded FASTQ-like tile replicated to G GiB in HBM ---------
-    tile_bytes = args.tile_mib << 20
-    if args.mode == "decode" and args.stream != "own":
-        tile_bytes = tile_bytes // BLOCK * BLOCK      # whole blocks per tile: the compressed tile repeats too
-    if args.data == "fastq":
-        tile_np = synth.fastq_like(tile_bytes, seed=1234 + rank, first_record=1 + rank * 10_000_000)
-    elif args.data == "text":
-        tile_np = synth.text_like(tile_bytes, seed=4321 + rank)
+def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
+    so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    ncores = len(os.sched_getaffinity(0))
+    threads = min(ncores, 16)          # a one-GPU box owns 16 host cores
+    blocks = [tile[i:i + block] for i in range(0, len(tile) - block + 1, block)][:1024]
+    vp = ctypes.c_void_p
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hdtest
+    o = hdtest.oracle()
+    have_ref = os.path.exists(so)
+    if have_ref:
+        ref = ctypes.CDLL(so)
+        kind = "reference"
+        enc, dec = ref.libdeflate_deflate, ref.libdeflate_inflate
+        ref.libdeflate_alloc_compressor.restype = vp
+        ref.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
+        ref.libdeflate_free_compressor.argtypes = [vp]
+        ref.libdeflate_deflate_compress.restype = ctypes.c_size_t
+        ref.libdeflate_deflate_compress.argtypes = [vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t]
+        what = "libdeflate 1.23 via libdeflate_%s (lib/zlibutil.c), one call per %d-byte block" % (
+            "deflate" if mode == "encode" else "inflate", block)
     else:
-        tile_np = synth.random_bytes(tile_bytes, seed=99 + rank)
-    assert len(tile_np) == tile_bytes
-    total = int(args.gib * (1 << 30))
-    reps = max(1, total // tile_bytes)
-    total = reps * tile_bytes
-    tile = torch.from_numpy(tile_np).cuda()
-    data = tile.repeat(reps)
-    del tile
-    assert data.numel() == total
-    off, ln = dev.block_table(total, BLOCK)
-    nb = off.numel()
+        kind = "port"
+        enc = o.hdo_deflate_twin
+        dec = lambda d, dl, s, sl: o.hdo_inflate(d, dl, s, sl, None)
+        what = "oracle CPU twin (oracle/_ref not built)"
 
-    frame = pkg.FRAME_MIGZ if args.block_kib else pkg.FRAME_BGZF
-    hdr = 20 if args.block_kib else 18
-    slot = args.slot or (65536 if not args.block_kib else int(pkg.lib().hipdeflate_bound(BLOCK, 9)))
-    enc = dev.DeviceDeflate(nb, slot=slot)
-    if args.mode == "encode":
-        level = args.level
-        packed = torch.empty(int(total * (0.75 if (level >= 1 and args.data != "random") else 1.01)) + (1 << 20),
-                             dtype=torch.uint8, device="cuda")
-    else:
-        level = args.level
-        if args.stream == "own":
-            # the stream to inflate is produced once, untimed, by our own encoder at --level
-            # (valid RFC 1951 multi-member BGZF); it then stays resident in HBM
-            enc.run(data, off, ln, level=level, frame=frame)
-            enc.scan()
-            torch.cuda.synchronize()
-            comp_total = int(enc.total.item())
-            packed = torch.empty(comp_total + 16, dtype=torch.uint8, device="cuda")
-            enc.compact(packed)
-            in_off = enc.dst_off + hdr
-            in_len = (enc.out_len - hdr).to(torch.int32)
-            want_crc = enc.crc
+    def enc_block(fn, blk, out):
+        n = ctypes.c_size_t(len(out))
+        r = fn(out.ctypes.data_as(vp), ctypes.byref(n), blk.ctypes.data_as(vp), ctypes.c_size_t(len(blk)), level)
+        assert r == 0
+        return n.value
+
+    comp = None
+    if mode == "decode":
+        comp = []
+        out = np.zeros(block * 2, dtype=np.uint8)
+        for blk in blocks[:256]:
+            n = enc_block(enc, blk, out)
+            comp.append(out[:n].copy())
+
+    def adapter_work(fn):
+        def work(idx, n_iter):
+            out = np.zeros(block * 2, dtype=np.uint8)
+            done = 0
+            for k in range(n_iter):
+                if mode == "encode":
+                    enc_block(fn, blocks[(idx * 7919 + k) % len(blocks)], out)
+                else:
+                    z = comp[(idx * 31 + k) % len(comp)]
+                    n = ctypes.c_size_t(block)
+                    r = dec(out.ctypes.data_as(vp), ctypes.byref(n), z.ctypes.data_as(vp), ctypes.c_size_t(len(z)))
+                    assert r == 0 and n.value == block
+                done += block
+            return done
+        return work
+
+    def reused_work(idx, n_iter):
+        # one libdeflate compressor per thread, reused (SURVEY.md 8(d)(i)): what the reference would
+        # cost without the alloc/free per call of lib/zlibutil.c:186-188
+        c = ref.libdeflate_alloc_compressor(level)
+        out = np.zeros(block * 2, dtype=np.uint8)
+        done = 0
+        for k in range(n_iter):
+            blk = blocks[(idx * 7919 + k) % len(blocks)]
+            assert ref.libdeflate_deflate_compress(c, blk.ctypes.data_as(vp), len(blk), out.ctypes.data_as(vp), len(out))
+            done += block
+        ref.libdeflate_free_compressor(c)
+        return done
+
+    def measure(work, share):
+        """calibrate on one core, then one-core and all-core figures inside `share` of the budget"""
+        t0 = time.perf_counter()
+        work(0, 16)
+        per_block = (time.perf_counter() - t0) / 16
+        budget = sample_budget_s * share
+        n1 = max(16, int(budget * 0.25 / per_block))
+        one, _ = _pool(work, 1, n1)
+        n_all = max(16, int(budget * 0.75 / per_block / threads))
+        allc, wall = _pool(work, threads, n_all)
+        return one, allc, wall, n_all
+
+    out = {}
+    one, allc, wall, n_all = measure(adapter_work(enc), 0.45 if mode == "encode" else 1.0)
+    out.update({"value": round(allc, 4), "unit": "GB/s", "cores": threads, "kind": kind,
+                "one_core": round(one, 4),
+                "sample": "%s; %d blocks (%.2f GB) of the same workload over %d threads, %.1f s CPU work"
+                          % (what, threads * n_all, threads * n_all * block / 1e9, threads, wall * threads)})
+    if mode == "encode":
+        if have_ref:
+            one, allc, _, _ = measure(reused_work, 0.3)
+            out["reused_compressor"] = {"one_core": round(one, 4), "all_cores": round(allc, 4),
+                                        "what": "libdeflate_deflate_compress level %d, one compressor per thread" % level}
+        one, allc, _, _ = measure(adapter_work(o.hdo_deflate_twin), 0.25)
+        out["twin"] = {"one_core": round(one, 4), "all_cores": round(allc, 4),
+                       "what": "oracle/hd_deflate_twin.c level %d: the serial restatement of the HIP encoder "
+                               "(same bytes as the kernel)" % level}
+    return out
+
+
+# ---- the GPU side -------------------------------------------------------------------
+
+
+class Bench:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        force = self.world == 1 and os.environ.get("HD_BENCH_FORCE_DIST") == "1"
+        self.use_dist = self.world > 1 or force
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", local))
+        self.pkg = importlib.import_module("7bgzf_amd")
+        self.dev = importlib.import_module("7bgzf_amd.device")
+        self.synth = importlib.import_module("7bgzf_amd.synth")
+        self.shard = importlib.import_module("7bgzf_amd.shard")
+        self.pkg.lib().hipdeflate_init(local)
+        if not self.pkg.available():
+            raise SystemExit("no usable MI355X; there is no CPU fallback to measure")
+
+    # a seeded tile replicated to G GiB in HBM
+    def make_data(self, kind, block, whole_blocks):
+        torch, args = self.torch, self.args
+        tile_bytes = args.tile_mib << 20
+        if whole_blocks:
+            tile_bytes = tile_bytes // block * block      # whole blocks per tile: a compressed tile repeats too
+        r = self.rank
+        if kind == "fastq":
+            tile_np = self.synth.fastq_like(tile_bytes, seed=1234 + r, first_record=1 + r * 10_000_000)
+        elif kind == "text":
+            tile_np = self.synth.text_like(tile_bytes, seed=4321 + r)
         else:
-            # BASELINE config 3: the REFERENCE's encoder (libdeflate 1.23 / zlib 1.3.1 built from
-            # the reference tree) compresses one tile of whole blocks on the host, untimed; the
-            # compressed tile is replicated like the data
-            import zlib as _z
-            from concurrent.futures import ThreadPoolExecutor
-            ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref.so"))
-            fn, lvl = {"libdeflate6": (ref.libdeflate_deflate, 6), "libdeflate1": (ref.libdeflate_deflate, 1),
-                       "zlib6": (ref.zlib_deflate, 6)}[args.stream]
-            tb = tile_np.tobytes()
-            nbt = tile_bytes // BLOCK
+            tile_np = self.synth.random_bytes(tile_bytes, seed=99 + r)
+        assert len(tile_np) == tile_bytes
+        total = int(args.gib * (1 << 30))
+        reps = max(1, total // tile_bytes)
+        data = torch.from_numpy(tile_np).cuda().repeat(reps)
+        return tile_np, data, reps
 
-            def comp(i):
-                src = tb[i * BLOCK:(i + 1) * BLOCK]
-                dst = ctypes.create_string_buffer(BLOCK * 2)
-                n = ctypes.c_size_t(BLOCK * 2)
-                assert fn(dst, ctypes.byref(n), src, ctypes.c_size_t(BLOCK), lvl) == 0
-                return dst.raw[:n.value], _z.crc32(src)
-            with ThreadPoolExecutor(16) as ex:
-                res = list(ex.map(comp, range(nbt)))
-            lens_t = np.array([len(r[0]) for r in res], dtype=np.int64)
-            offs_t = np.concatenate([[0], np.cumsum(lens_t)[:-1]])
-            ctile = np.frombuffer(b"".join(r[0] for r in res), dtype=np.uint8)
-            packed = torch.from_numpy(ctile.copy()).cuda().repeat(reps)
-            comp_total = packed.numel()
-            in_off = (torch.from_numpy(offs_t).cuda()[None, :] +
-                      (torch.arange(reps, device="cuda", dtype=torch.int64) * len(ctile))[:, None]).reshape(-1)
-            in_len = torch.from_numpy(lens_t.astype(np.int32)).cuda().repeat(reps)
-            want_crc = torch.from_numpy(np.array([r[1] for r in res], dtype=np.uint32).view(np.int32)).cuda().repeat(reps)
-            level = lvl
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            step(None)
+        self.fence()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(evs)
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kms = [a.elapsed_time(b) for a, b in evs]
+        return elapsed, sum(kms) / len(kms) / 1e3
+
+    def encode(self, data, block, level, migz, steps, warmup, slot_arg=0, incompressible=False):
+        """-> dict(elapsed, k_avg_s, total, comp_total, nb, ...) for `steps` passes of the encode path"""
+        torch, pkg, dev = self.torch, self.pkg, self.dev
+        total = data.numel()
+        off, ln = dev.block_table(total, block)
+        nb = off.numel()
+        frame = pkg.FRAME_MIGZ if migz else pkg.FRAME_BGZF
+        slot = slot_arg or (65536 if not migz else int(pkg.lib().hipdeflate_bound(block, 9)))
+        enc = dev.DeviceDeflate(nb, slot=slot)
+        packed = torch.empty(int(total * (1.01 if (level < 1 or incompressible) else 0.75)) + (1 << 20),
+                             dtype=torch.uint8, device="cuda")
+        state = {}
+
+        def step(evs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            enc.run(data, off, ln, level=level, frame=frame)
+            e1.record()
+            enc.scan()                                       # local offsets + this rank's total
+            base = 0
+            if self.use_dist:
+                # the ONE exchange of the path: per-rank compressed totals -> base offsets
+                totals = self.shard.exchange_totals(int(enc.total.item()), device="cuda")
+                bases, grand = self.shard.bases_from_totals(totals)
+                base = bases[self.rank]
+                enc.scan(base=base)                          # member offsets in the whole stream
+                state.update(totals=totals, bases=bases, grand=grand)
+            enc.compact(packed, span_base=base)              # members -> this rank's span
+            state["base"] = base
+            if evs is not None:
+                evs.append((e0, e1))
+
+        elapsed, k_avg_s = self.timed(step, steps, warmup)
+        # ---- sanity: nothing failed, sizes plausible (parity itself is tests/ -m gpu) -----
+        assert int(enc.status.abs().sum()) == 0
+        comp_total = int(enc.total.item())
+        assert int(enc.dst_off[0].item()) == state["base"]
+        assert int(enc.dst_off[-1].item()) + int(enc.out_len[-1].item()) == state["base"] + comp_total
+        if self.use_dist:
+            assert state["totals"][self.rank] == comp_total
+            assert state["grand"] == state["bases"][-1] + state["totals"][-1] == sum(state["totals"])
+        # the span starts with a member header and the last member ends where the span ends
+        head = bytes(packed[:4].cpu().numpy())
+        assert head == b"\x1f\x8b\x08\x04", head
+        res = dict(elapsed=elapsed, k_avg_s=k_avg_s, total=total, comp_total=comp_total, nb=nb, frame=frame,
+                   off=off, ln=ln, enc=enc, packed=packed, hdr=20 if migz else 18, dist=dict(state))
+        return res
+
+    def decode(self, data, packed, in_off, in_len, want_crc, block, steps, warmup):
+        torch, dev = self.torch, self.dev
+        total = data.numel()
+        off, ln = dev.block_table(total, block)
+        nb = off.numel()
         out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
         crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
         st = torch.zeros(nb, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        del enc.slots
         out = torch.empty_like(data)
 
-    totals = torch.zeros(world, dtype=torch.int64, device="cuda")
-    kern_ms = []
-
-    def step(timed):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if args.mode == "encode":
-            e0.record()
-            enc.run(data, off, ln, level=level, frame=frame)
-            e1.record()
-            enc.scan()
-            if world > 1 or force_dist:
-                # the ONE exchange of the path: per-rank compressed totals -> base offsets
-                dist.all_gather_into_tensor(totals, enc.total)
-            enc.compact(packed)
-        else:
+        def step(evs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             dev.device_inflate(packed, in_off, in_len, out, off, ln, out_len, crc, st)
             e1.record()
-        if timed:
-            kern_ms.append((e0, e1))
+            if evs is not None:
+                evs.append((e0, e1))
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1 or force_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- sanity: nothing failed, sizes plausible (parity itself is tests/ -m gpu) -----
-    if args.mode == "encode":
-        assert int(enc.status.abs().sum()) == 0
-        comp_total = int(enc.total.item())
-    else:
+        elapsed, k_avg_s = self.timed(step, steps, warmup)
         assert int(st.abs().sum()) == 0 and torch.equal(out_len, ln)
-        assert torch.equal(out[: 4 * BLOCK], data[: 4 * BLOCK]) and torch.equal(out[-BLOCK:], data[-BLOCK:])
+        assert torch.equal(out[: 4 * block], data[: 4 * block]) and torch.equal(out[-block:], data[-block:])
         assert torch.equal(crc, want_crc)
-    ratio = comp_total / total
+        return dict(elapsed=elapsed, k_avg_s=k_avg_s, total=total, comp_total=int(packed.numel()), nb=nb)
 
-    kms = [a.elapsed_time(b) for a, b in kern_ms]
-    k_avg_s = sum(kms) / len(kms) / 1e3
-    # algorithmic bytes of the dominant kernel per launch:
-    #   encode N_in + N_out + 8 B/block (len, crc); decode N_cmp + N_out
-    algo_bytes = total + comp_total + 8 * nb
-    achieved = algo_bytes / k_avg_s / 1e9
+    def reference_stream(self, tile_np, reps, block, which):
+        """BASELINE config 3: the REFERENCE's encoder (libdeflate 1.23 / zlib 1.3.1 built from the reference
+        tree) compresses one tile of whole blocks on the host, untimed; the compressed tile is replicated
+        like the data"""
+        import zlib as _z
+        from concurrent.futures import ThreadPoolExecutor
+        torch = self.torch
+        ref = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref.so"))
+        fn, lvl = {"libdeflate6": (ref.libdeflate_deflate, 6), "libdeflate1": (ref.libdeflate_deflate, 1),
+                   "zlib6": (ref.zlib_deflate, 6)}[which]
+        tb = tile_np.tobytes()
+        nbt = len(tb) // block
+
+        def comp(i):
+            src = tb[i * block:(i + 1) * block]
+            dst = ctypes.create_string_buffer(block * 2)
+            n = ctypes.c_size_t(block * 2)
+            assert fn(dst, ctypes.byref(n), src, ctypes.c_size_t(block), lvl) == 0
+            return dst.raw[:n.value], _z.crc32(src)
+        with ThreadPoolExecutor(16) as ex:
+            res = list(ex.map(comp, range(nbt)))
+        lens_t = np.array([len(r[0]) for r in res], dtype=np.int64)
+        offs_t = np.concatenate([[0], np.cumsum(lens_t)[:-1]])
+        ctile = np.frombuffer(b"".join(r[0] for r in res), dtype=np.uint8)
+        packed = torch.from_numpy(ctile.copy()).cuda().repeat(reps)
+        in_off = (torch.from_numpy(offs_t).cuda()[None, :] +
+                  (torch.arange(reps, device="cuda", dtype=torch.int64) * len(ctile))[:, None]).reshape(-1)
+        in_len = torch.from_numpy(lens_t.astype(np.int32)).cuda().repeat(reps)
+        want_crc = torch.from_numpy(np.array([r[1] for r in res], dtype=np.uint32).view(np.int32)).cuda().repeat(reps)
+        return packed, in_off, in_len, want_crc, lvl
+
+    def free(self):
+        import gc
+        gc.collect()
+        self.torch.cuda.empty_cache()
+
+
+def level_name(level):
+    return ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else \
+        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy" if level >= 5 else "greedy")) if level >= 2 \
+        else "level 0: stored"
+
+
+def summary(res, steps, world=1, mode="encode"):
+    """the per-config figures: GB/s of uncompressed bytes, kernel time, roofline fraction"""
+    # SURVEY.md 8(d): encode N_in + N_out + 8 B/block (len, crc); decode N_cmp + N_out
+    algo = res["total"] + res["comp_total"] + (8 * res["nb"] if mode == "encode" else 0)
+    ach = algo / res["k_avg_s"] / 1e9
+    return {"value": round(res["total"] * world * steps / res["elapsed"] / 1e9, 3), "unit": "GB/s", "steps": steps,
+            "ms_per_step": round(res["elapsed"] / steps * 1e3, 3), "kernel_ms_avg": round(res["k_avg_s"] * 1e3, 3),
+            "ratio": round(res["comp_total"] / res["total"], 4), "blocks": res["nb"],
+            "algorithmic_bytes_per_launch": algo, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+
+def main():
+    args = parse()
+    block = args.block_kib * 1024 if args.block_kib else BGZF_BLOCK
+    B = Bench(args)
+    torch = B.torch
+    world, rank = B.world, B.rank
+    decode_ref = args.mode == "decode" and args.stream != "own"
+    tile_np, data, reps = B.make_data(args.data, block, whole_blocks=decode_ref)
+    total = data.numel()
+    level = args.level
+    if args.mode == "encode":
+        res = B.encode(data, block, level, bool(args.block_kib), args.steps, args.warmup, slot_arg=args.slot,
+                       incompressible=args.data == "random")
+    else:
+        if args.stream == "own":
+            # the stream to inflate is produced once, untimed, by our own encoder at --level
+            # (valid RFC 1951 multi-member BGZF); it then stays resident in HBM
+            e = B.encode(data, block, level, bool(args.block_kib), 1, 0)
+            enc = e["enc"]
+            packed = e["packed"][: e["comp_total"] + 16]
+            in_off = enc.dst_off - e["dist"]["base"] + e["hdr"]
+            in_len = (enc.out_len - e["hdr"]).to(torch.int32)
+            want_crc = enc.crc
+            del enc.slots
+        else:
+            packed, in_off, in_len, want_crc, level = B.reference_stream(tile_np, reps, block, args.stream)
+        B.free()
+        res = B.decode(data, packed, in_off, in_len, want_crc, block, args.steps, args.warmup)
+    s = summary(res, args.steps, world, args.mode)
+
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_%s_l%d.json" % (args.mode, level))
     if os.path.exists(tp):
@@ -301,43 +423,106 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    gbs = total * world * args.steps / elapsed / 1e9
 
+    line = None
     if rank == 0:
+        shard_txt = "HBM-resident" if world == 1 else \
+            "HBM-resident; each rank = its own %.2f GiB shard (a contiguous block range) of a %.0f GiB stream" % (
+                total / 2 ** 30, total * world / 2 ** 30)
         line = {
             "metric": ("GB/s input compressed, %s blocks" if args.mode == "encode"
                        else "GB/s output produced, %s blocks (inflate)") % (
                            "BGZF 64KiB" if not args.block_kib else "MiGz %d KiB" % args.block_kib),
-            "value": round(gbs, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": s["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s %s, %s blocks, %s, %.2f GiB %s per GPU (seeded generator, "
-                                   "%d MiB tile x %d), %d blocks/GPU, HBM-resident" % (
+                                   "%d MiB tile x %d), %d blocks/GPU, %s" % (
                                        "MiGz" if args.block_kib else "BGZF", args.mode,
                                        ("%d KiB" % args.block_kib) if args.block_kib else "0xff00-byte",
                                        ("stream from the reference's %s (built from the reference tree)" % args.stream)
-                                       if (args.mode == "decode" and args.stream != "own") else
-                                       ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else
-                                       ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy" if level >= 5 else "greedy")) if level >= 2
-                                       else "level 0: stored",
-                                       total / 2 ** 30, {"fastq": "FASTQ-like", "text": "enwik-like text", "random": "random bytes"}[args.data],
-                                       args.tile_mib, reps, nb),
-                       "blocks_per_gpu": nb, "ratio": round(ratio, 4), "parallelism": "block-range shard x%d" % world,
-                       "step": "encode kernel + size scan (+ all_gather of totals) + compact" if args.mode == "encode"
-                       else "inflate kernel", "stream": args.stream if args.mode == "decode" else None},
+                                       if decode_ref else level_name(level),
+                                       total / 2 ** 30, {"fastq": "FASTQ-like", "text": "enwik-like text",
+                                                         "random": "random bytes"}[args.data],
+                                       args.tile_mib, reps, res["nb"], shard_txt),
+                       "blocks_per_gpu": res["nb"], "ratio": s["ratio"], "parallelism": "block-range shard x%d" % world,
+                       "step": ("encode kernel + size scan + %sgather into the contiguous stream" % (
+                           "all_gather of per-rank totals (RCCL) + scan with this rank's base + " if B.use_dist else ""))
+                       if args.mode == "encode" else "inflate kernel",
+                       "stream": args.stream if args.mode == "decode" else None},
             "roofline": {"bound": "hbm", "kernel": "k_deflate_static" if args.mode == "encode" and level <= 1
-                         else ("k_deflate_dynamic" if args.mode == "encode" else "k_inflate"),
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": round(k_avg_s * 1e3, 3)},
+                         else ("k_deflate_static<TOK> (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" else "k_inflate"),
+                         "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": s["frac"], "traffic": traffic,
+                         "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],
+                         "kernel_ms_avg": s["kernel_ms_avg"]},
         }
+        if B.use_dist and args.mode == "encode":
+            d = res["dist"]
+            line["config"]["stream_offsets"] = {"totals": d["totals"], "bases": d["bases"], "stream_bytes": d["grand"]}
+
+    # ---- the other GPU configs of BASELINE.json, same run (default invocation, one GPU) ----------
+    default_run = (args.mode == "encode" and level == 1 and args.data == "fastq" and not args.block_kib
+                   and world == 1 and not args.no_extra and not args.slot)
+    if default_run:
+        xs, xw = min(args.steps, 5), 1
+        configs = {}
+        res.pop("enc", None), res.pop("packed", None)
+        res = None
+        B.free()
+
+        def note(name, fn):
+            try:
+                configs[name] = fn()
+            except Exception as ex:                     # an extra config must not take the headline down
+                configs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            B.free()
+
+        def encode_l2():
+            r = B.encode(data, block, 2, False, xs, xw)
+            out = summary(r, xs)
+            out["workload"] = "BGZF encode, 0xff00-byte blocks, %s, same %.2f GiB FASTQ-like data" % (
+                level_name(2), total / 2 ** 30)
+            return out
+        note("encode_l2", encode_l2)
+
+        def decode_ld6():
+            so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+            if not os.path.exists(so):
+                return {"error": "oracle/_ref/libref.so not built"}
+            tb = (args.tile_mib << 20) // block * block
+            nt = total // tb
+            tnp = tile_np[:tb]
+            d2 = torch.from_numpy(tnp).cuda().repeat(nt)
+            packed, in_off, in_len, want_crc, _ = B.reference_stream(tnp, nt, block, "libdeflate6")
+            r = B.decode(d2, packed, in_off, in_len, want_crc, block, xs, xw)
+            out = summary(r, xs, mode="decode")
+            out["workload"] = ("BGZF decode (inflate), 0xff00-byte blocks, %.2f GiB out, stream from the reference's "
+                               "libdeflate 1.23 level 6; output and per-block CRC-32 checked" % (d2.numel() / 2 ** 30))
+            return out
+        note("decode_libdeflate6", decode_ld6)
+        del data
+        B.free()
+
+        def migz_l6():
+            mb = 1 << 20
+            _, tdata, _ = B.make_data("text", mb, whole_blocks=False)
+            r = B.encode(tdata, mb, 6, True, xs, xw)
+            out = summary(r, xs)
+            out["workload"] = "MiGz encode, 1 MiB blocks, %s, %.2f GiB enwik-like text" % (
+                level_name(6), tdata.numel() / 2 ** 30)
+            return out
+        note("migz_l6_text", migz_l6)
+        line["configs"] = configs
+
+    if rank == 0:
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tile_np, max(level, 1), args.mode)
+            line["cpu_baseline"] = cpu_baseline(tile_np, max(level, 1), args.mode, block)
         elif not args.no_cpu:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
+    if B.use_dist:
+        B.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

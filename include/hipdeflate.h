@@ -167,6 +167,15 @@ int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks,
 int hipdeflate_compact_dev(const void *slots, uint64_t stride,
 			   const void *out_len, const void *dst_off,
 			   uint32_t nblocks, void *dst, void *stream);
+/* The same gather for ONE RANK'S SPAN of a stream sharded across GPUs: dst_off[] holds
+ * offsets in the whole concatenated stream (scan_sizes_dev with base = sum of the lower ranks' totals, the
+ * one all_gather of the path), `span` is this rank's buffer and span_base the stream offset of its first
+ * byte: member i goes to span + (dst_off[i] - span_base).  The rank then pwrite()s the span at span_base --
+ * the in-order writer of applet/7bgzf.c:263-272 without moving payload between GPUs. */
+int hipdeflate_compact_span_dev(const void *slots, uint64_t stride,
+				const void *out_len, const void *dst_off,
+				uint32_t nblocks, void *span, uint64_t span_base,
+				void *stream);
 
 /* ---- streaming encoder: the host pipeline either side of the kernels ------------
  * Role of the read / compress / write loop of applet/7bgzf.c:159-293 (7migz.c:130-244)
