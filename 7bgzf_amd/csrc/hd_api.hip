@@ -532,6 +532,8 @@ static int batch_inflate_host(const uint8_t *in, const uint64_t *in_off, const u
 		return r;
 	size_t in_total = 0, out_total = 0;
 	for (uint32_t i = 0; i < nblocks; i++) {
+		if (in_len[i] >= HD_INFLATE_MAX_IN)
+			return HD_E_ARG;
 		in_total += up16(in_len[i]);
 		out_total += up16(out_cap[i]);
 	}
@@ -872,6 +874,8 @@ int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const
 	uint32_t *h_ilen = (uint32_t *)(h_ooff + n), *h_ocap = h_ilen + n;
 	size_t in_end = 0, osum = 0;
 	for (uint32_t i = 0; i < n; i++) {
+		if (in_len[i] >= HD_INFLATE_MAX_IN)
+			return HD_E_ARG;
 		h_ioff[i] = in_off[i];
 		h_ilen[i] = in_len[i];
 		h_ooff[i] = osum;
@@ -1005,7 +1009,7 @@ int hip_deflate_flush(unsigned char *dest, size_t *destLen, const unsigned char 
 
 static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, uint32_t flags)
 {
-	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xfffffff0u)
+	if (!dest || !destLen || (!source && sourceLen) || sourceLen >= HD_INFLATE_MAX_IN)
 		return HD_E_ARG;
 	uint64_t ioff = 0, ooff = 0;
 	uint32_t ilen = (uint32_t)sourceLen, olen = 0;

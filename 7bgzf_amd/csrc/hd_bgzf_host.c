@@ -151,25 +151,42 @@ static int do_compress(int level)
 	return 0;
 }
 
-/* header walk of _read_gz_header (applet/7bgzf.c:81-131), BC and MZ subfields only */
+/* header walk of _read_gz_header (applet/7bgzf.c:81-131): FLG / XLEN / FNAME / FCOMMENT / FHCRC, then the
+ * member length from the extra field -- BC (BGZF, u16 + 1), MZ (MiGz, payload u32 + header + 8), IG v1
+ * (mgzip, u64 whole member), IG v2 (u32 whole member), jerodsanto's mgzip (u24 whole member, 0x7d tag).
+ * 1 = ok: *hdr = header bytes, *total = whole member; always hdr + 8 <= total (room for CRC32 + ISIZE),
+ * so the payload length and the ISIZE read stay inside the member.  0 = not such a member / cut off. */
 static int member_len(const unsigned char *p, size_t avail, size_t *hdr, size_t *total)
 {
-	if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0) || !(p[3] & 4))
+	if (avail < 12 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0) || !(p[3] & 4))
 		return 0;
-	uint32_t xlen = rd16(p + 10);
-	if (avail < 12 + xlen)
+	const uint32_t xlen = rd16(p + 10);
+	const unsigned char *x = p + 12;
+	if (avail < 12 + (size_t)xlen)
 		return 0;
 	size_t n = 12 + xlen;
 	if (p[3] & 0x08) { while (n < avail && p[n++]) ; }
 	if (p[3] & 0x10) { while (n < avail && p[n++]) ; }
 	if (p[3] & 0x02) n += 2;
-	if (xlen == 6 && !memcmp(p + 12, "BC\x02\x00", 4))
-		*total = rd16(p + 16) + 1;
-	else if (xlen == 8 && !memcmp(p + 12, "MZ\x04\x00", 4))
-		*total = (size_t)rd32(p + 16) + n + 8;
+	if (n > avail)
+		return 0;
+	uint64_t t;
+	if (xlen == 6 && !memcmp(x, "BC\x02\x00", 4))
+		t = (uint64_t)rd16(x + 4) + 1;
+	else if (xlen == 8 && !memcmp(x, "MZ\x04\x00", 4))
+		t = (uint64_t)rd32(x + 4) + n + 8;
+	else if (xlen == 20 && !memcmp(x, "IG\x10\x00", 4))
+		t = (uint64_t)rd32(x + 4) | (uint64_t)rd32(x + 8) << 32;
+	else if (xlen == 8 && !memcmp(x, "IG\x04\x00", 4))
+		t = rd32(x + 4);
+	else if (xlen == 4 && x[3] == 0x7d)
+		t = rd32(x) & 0xffffffu;
 	else
 		return 0;
+	if (t < n + 8 || t > 0xfffffff0u)
+		return 0;
 	*hdr = n;
+	*total = (size_t)t;
 	return 1;
 }
 
@@ -226,9 +243,11 @@ static void *unreader_main(void *arg)
 		size_t p = 0, osum = 0;
 		while (nb < HD_BATCH && p < have) {
 			size_t hdr, total;
-			if (have - p < 20 && !eof)
-				break;
 			if (!member_len(buf + p, have - p, &hdr, &total)) {
+				/* a header the end of the batch cut (FNAME / IG v1 headers pass 20 bytes): carry it
+				 * over and look again with more bytes; p > 0 guarantees progress */
+				if (!eof && p > 0 && have - p < 4096)
+					break;
 				reader_fail(3);
 				return NULL;
 			}

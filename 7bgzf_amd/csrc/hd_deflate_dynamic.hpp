@@ -232,8 +232,10 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			excess += (int32_t)(h.blc[bits] << (maxbits - bits));
 		while (excess > 0) {
 			uint32_t bits = maxbits - 1;
-			while (h.blc[bits] == 0)
+			while (bits >= 1 && h.blc[bits] == 0)
 				bits--;
+			if (bits == 0)
+				break;                          // only with more symbols than 2^maxbits: no such code exists
 			h.blc[bits]--;
 			h.blc[bits + 1] += 2;
 			h.blc[maxbits]--;

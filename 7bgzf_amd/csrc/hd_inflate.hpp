@@ -251,6 +251,16 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		return;
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
+	if (n >= HD_INFLATE_MAX_IN) {
+		// stream positions are 32-bit BIT counts (over_t, B below): a stream this long is refused whole
+		// rather than decoded from wrapped positions (the host entry points answer HD_E_ARG before launching)
+		if (lane == 0) {
+			a.out_len[b] = 0;
+			if (a.crc) a.crc[b] = 0;
+			if (a.status) a.status[b] = HD_BAD_DATA;
+		}
+		return;
+	}
 	uint8_t *dst = a.out + a.out_off[b];
 	const uint32_t cap = a.out_cap[b];
 	const CrcTables *ct = a.ct;

@@ -54,13 +54,19 @@ extern "C" int hipdeflate_test_build_lengths(const uint32_t *freq, uint32_t nvec
 	int r = hipdeflate_available();
 	if (r)
 		return r;
-	if (!freq || !lens_out || !nvec || nsyms < 2 || nsyms > 288 || maxbits < 1 || maxbits > 15)
+	// no length-limited code exists for more than 2^maxbits symbols (the builder's push-up loop would run off
+	// its length counters)
+	if (!freq || !lens_out || !nvec || nsyms < 2 || nsyms > 288 || maxbits < 1 || maxbits > 15 || nsyms > (1u << maxbits))
 		return HD_E_ARG;
-	uint32_t *df;
-	uint8_t *dl;
+	uint32_t *df = nullptr;
+	uint8_t *dl = nullptr;
 	const size_t n = (size_t)nvec * nsyms;
-	if (hipMalloc((void **)&df, n * 4) != hipSuccess || hipMalloc((void **)&dl, n) != hipSuccess)
+	if (hipMalloc((void **)&df, n * 4) != hipSuccess)
 		return HD_E_NOMEM;
+	if (hipMalloc((void **)&dl, n) != hipSuccess) {
+		(void)hipFree(df);
+		return HD_E_NOMEM;
+	}
 	(void)hipMemcpy(df, freq, n * 4, hipMemcpyHostToDevice);
 	hipLaunchKernelGGL(k_selftest_build, dim3(nvec), dim3(64), 0, 0, df, nsyms, maxbits, dl);
 	const hipError_t e = hipMemcpy(lens_out, dl, n, hipMemcpyDeviceToHost);

@@ -119,7 +119,9 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off,
  * in[in_off[i] .. +in_len[i]) (trailing bytes allowed), its output goes to
  * out + out_off[i], capacity out_cap[i]; out_len[i] = bytes produced,
  * crc32[i] = CRC-32 of the OUTPUT (may be NULL), status[i] = 0/1/3 as
- * hip_inflate. */
+ * hip_inflate.  One stream must be shorter than HD_INFLATE_MAX_IN (2^28 bytes, hipdeflate_params.h):
+ * the host entry points return HD_E_ARG for a longer one, the _dev entry points (which cannot see
+ * in_len) report status 1 / out_len 0 for it. */
 int hipdeflate_batch_inflate(const uint8_t *in, const uint64_t *in_off,
 			     const uint32_t *in_len, uint32_t nblocks,
 			     uint8_t *out, const uint64_t *out_off,

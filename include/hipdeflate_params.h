@@ -114,6 +114,10 @@
 	(((n) / HD_SEG_BYTES) * (HD_STORED_SIZE(HD_SEG_BYTES) + 5u) + \
 	 ((n) % HD_SEG_BYTES ? HD_STORED_SIZE((n) % HD_SEG_BYTES) + 5u : 0u) + ((flush) ? 0u : 2u))
 
+/* one compressed stream handed to the inflate kernel must be shorter than this: it keeps stream positions
+ * as 32-bit bit counts (8 n + 64 + 24 < 2^32) */
+#define HD_INFLATE_MAX_IN  (1u << 28)
+
 /* result codes of the inflate path = enum libdeflate_result
  * (lib/libdeflate/libdeflate.h:193-208), which libdeflate_inflate
  * (lib/zlibutil.c:194-204) hands straight back to the applet */

@@ -384,8 +384,10 @@ static void build_code(const uint32_t *freq_in, unsigned nsyms, unsigned maxbits
 		excess += (long)blc[bits] << (maxbits - bits);
 	while (excess > 0) {
 		unsigned bits = maxbits - 1;
-		while (blc[bits] == 0)
+		while (bits >= 1 && blc[bits] == 0)
 			bits--;
+		if (bits == 0)
+			break;                  /* only with more symbols than 2^maxbits: no such code exists */
 		blc[bits]--;
 		blc[bits + 1] += 2;
 		blc[maxbits]--;

@@ -341,3 +341,80 @@ def test_ld_preload_hook_takes_over_an_htslib_shaped_writer(tmp_path):
         pos += total
         i += 1
     assert i == 41 and pos == len(out) - 28
+
+
+def _gz_member(kind, payload, crc, isize, fname=b""):
+    """one gzip member whose extra field carries the member length in each of the five ways
+    _read_gz_header (applet/7bgzf.c:111-129) understands"""
+    import struct
+    flg = 4 | (8 if fname else 0)
+    name = fname + b"\0" if fname else b""
+    trailer = struct.pack("<II", crc, isize)
+
+    def build(extra):
+        return bytes([0x1f, 0x8b, 8, flg, 0, 0, 0, 0, 0, 0xff]) + struct.pack("<H", len(extra)) + extra + name
+    if kind == "BC":
+        total = 12 + 6 + len(name) + len(payload) + 8
+        extra = b"BC\x02\x00" + struct.pack("<H", total - 1)
+    elif kind == "MZ":
+        extra = b"MZ\x04\x00" + struct.pack("<I", len(payload))
+    elif kind == "IG1":
+        total = 12 + 20 + len(name) + len(payload) + 8
+        extra = b"IG\x10\x00" + struct.pack("<QQ", total, isize)
+    elif kind == "IG2":
+        total = 12 + 8 + len(name) + len(payload) + 8
+        extra = b"IG\x04\x00" + struct.pack("<I", total)
+    else:                                   # jerodsanto's mgzip: u24 member length, 0x7d tag
+        total = 12 + 4 + len(name) + len(payload) + 8
+        extra = struct.pack("<I", total)[:3] + b"\x7d"
+    return build(extra) + payload + trailer
+
+
+def test_decode_prescan_takes_every_member_kind_of_read_gz_header():
+    """a13: BC, MZ, IG v1, IG v2 and mgzip members (plain and with FNAME), mixed in one file, decode through
+    hd7bgzf -d; the oracle's restatement of _read_gz_header is the checker of the hand-made framing."""
+    import ctypes
+    import zlib
+    o = hdtest.oracle()
+    o.hdo_read_gz_header.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
+    s = hdtest.synth()
+    blob, want = b"", b""
+    kinds = ["BC", "MZ", "IG1", "IG2", "MG"]
+    for k in range(40):
+        kind = kinds[k % 5]
+        chunk = bytes(s.fastq_like(3000 + 1500 * k, seed=100 + k)) if k % 3 else bytes(s.text_like(40000, seed=k))
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        m = _gz_member(kind, payload, zlib.crc32(chunk), len(chunk), fname=b"chunk%03d.txt" % k if k % 2 else b"")
+        eo, el, bl = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        n = o.hdo_read_gz_header(m, min(len(m), 128), ctypes.byref(eo), ctypes.byref(el), ctypes.byref(bl))
+        assert n == len(m) - len(payload) - 8 and bl.value == len(m), (kind, n, bl.value, len(m))
+        blob += m
+        want += chunk
+    rc, back, err = run(["-d"], blob)
+    assert rc == 0 and back == want, err
+    assert gzip.decompress(blob) == want
+
+
+@pytest.mark.parametrize("bad", ["bsize_small", "bsize_tiny", "no_extra", "cut"])
+def test_decode_prescan_rejects_corrupt_headers_like_the_reference(bad):
+    """a BC member whose BSIZE + 1 is smaller than header + trailer must end as the reference's
+    "not BGZF or corrupted" (-1), never as a read in front of the buffer"""
+    import struct
+    pkg = hdtest.pkg()
+    data = bytes(hdtest.synth().fastq_like(3 * 0xff00, seed=4))
+    blob = bytearray(pkg.bgzf_compress_bytes(data, 1))
+    if bad == "bsize_small":
+        blob[16:18] = struct.pack("<H", 20)          # total 21: below header (18) + trailer (8)
+    elif bad == "bsize_tiny":
+        blob[16:18] = struct.pack("<H", 1)
+    elif bad == "no_extra":
+        blob[3] = 0
+    else:
+        blob = blob[: len(blob) // 2]
+    rc, back, err = run(["-d"], bytes(blob))
+    if bad == "cut":
+        assert rc != 0, err              # (the reference inflates the short read and fails with "inflate N")
+    else:
+        assert rc == 255 and "not BGZF or corrupted" in err, (rc, err)

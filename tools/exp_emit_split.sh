@@ -1,8 +1,9 @@
 # experiment: how much of the emit-only kernel is code construction (token loop disabled; output is wrong on purpose)
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/exp_guard.sh
+exp_guard 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
 export TMPDIR=/tmp
-sed -i 's/for (uint32_t base = 0; base < ntok_slab; base += 64) {\n\t\t\t\tconst uint32_t k = base + lane;\n\t\t\t\tconst bool valid/XX/' 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
 python3 - <<'PY'
 p='7bgzf_amd/csrc/hd_deflate_dynamic.hpp'; s=open(p).read()
 s=s.replace("			for (uint32_t base = 0; base < ntok_slab; base += 64) {\n				const uint32_t k = base + lane;\n				const bool valid","			for (uint32_t base = 0; base < (EMIT ? 0u : ntok_slab); base += 64) {\n				const uint32_t k = base + lane;\n				const bool valid")

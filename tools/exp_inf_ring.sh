@@ -1,5 +1,7 @@
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/exp_guard.sh
+exp_guard 7bgzf_amd/csrc/hd_inflate.hpp
 for cfg in "2048 10" "2048 9" "4096 9"; do
   set -- $cfg
   sed -i "s/constexpr uint32_t INF_RING    = [0-9]*;/constexpr uint32_t INF_RING    = $1;/; s/constexpr uint32_t INF_LT_BITS = [0-9]*;/constexpr uint32_t INF_LT_BITS = $2;/" 7bgzf_amd/csrc/hd_inflate.hpp

@@ -1,6 +1,8 @@
 # usage: bash tools/exp_params.sh "<WIN> <HASH>" ...   -- rebuild with other L1 geometry and bench (experiment only)
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/exp_guard.sh
+exp_guard include/hipdeflate_params.h
 mkdir -p gpurun_out
 for cfg in "$@"; do
   set -- $cfg

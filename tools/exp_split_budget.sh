@@ -1,6 +1,8 @@
 # experiment: scratch budget of the split path with 1 MiB MiGz blocks (run on the GPU box)
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/exp_guard.sh
+exp_guard 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
 for g in "$@"; do
   sed -i "s/constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)[0-9]* << 20;/constexpr uint64_t SPLIT_SCRATCH_BUDGET = (uint64_t)${g} << 20;/" 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
   make -s -C 7bgzf_amd/csrc > /dev/null 2>&1

@@ -1,6 +1,8 @@
 # experiment: blocks per parse/emit launch pair of the level-2 split path (run on the GPU box)
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/exp_guard.sh
+exp_guard 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
 for g in "$@"; do
   sed -i "s/constexpr uint32_t SPLIT_SUB_BATCH = [0-9]*;/constexpr uint32_t SPLIT_SUB_BATCH = ${g};/" 7bgzf_amd/csrc/hd_deflate_dynamic.hpp
   make -s -C 7bgzf_amd/csrc > /dev/null 2>&1
