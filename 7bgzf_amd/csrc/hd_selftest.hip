@@ -31,6 +31,25 @@ __global__ __launch_bounds__(64) void k_selftest_slots(uint32_t *out)
 	}
 }
 
+// The parse publishes 64 positions per step with ONE ds_write_b16; lanes whose four bytes hash alike write the
+// same table entry in that instruction.  The encoder (and its CPU twin, which keeps the largest position)
+// relies on what gfx950's LDS does then: the highest lane's data stays.  This kernel checks exactly that,
+// for 16-bit entries, with conflict patterns from "all lanes on one entry" to "random over 1536 entries".
+__global__ __launch_bounds__(64) void k_selftest_lds_order(const uint16_t *idx, uint32_t rounds, uint16_t *out)
+{
+	__shared__ uint16_t table[1536];
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t r = 0; r < rounds; r++) {
+		for (uint32_t i = lane; i < 1536; i += 64)
+			table[i] = 0;
+		__syncthreads();
+		const uint16_t h = idx[(blockIdx.x * rounds + r) * 64 + lane];
+		table[h] = (uint16_t)(lane + 1);
+		__syncthreads();
+		out[(blockIdx.x * rounds + r) * 64 + lane] = table[h];
+	}
+}
+
 // one wavefront per frequency vector through the encoder's Huffman construction
 __global__ __launch_bounds__(64) void k_selftest_build(const uint32_t *freq, uint32_t nsyms, uint32_t maxbits, uint8_t *lens)
 {
@@ -110,6 +129,42 @@ extern "C" int hipdeflate_selftest(void)
 		}
 		(void)hipFree(dx);
 		(void)hipFree(di);
+	}
+	// ---- LDS write arbitration: of the lanes that store to one entry in one instruction, the highest stays ----
+	{
+		const uint32_t nb = 16, rounds = 32, n = nb * rounds * 64;
+		uint16_t *hx = (uint16_t *)malloc(n * 2), *ho = (uint16_t *)malloc(n * 2), *dx, *dout;
+		uint32_t seed = 777;
+		for (uint32_t i = 0; i < n; i++) {
+			seed = seed * 1664525u + 1013904223u;
+			const uint32_t pat = (i / 64) % 8, l = i % 64;
+			// 0: one entry; 1: pairs; 2: two entries alternating; 3: 8 distinct, same bank; 4..7: random over 2^k
+			hx[i] = pat == 0 ? 5 : pat == 1 ? (uint16_t)(l / 2) : pat == 2 ? (uint16_t)(l & 1)
+				: pat == 3 ? (uint16_t)((l & 7) * 64) : (uint16_t)((seed >> 16) % (pat == 4 ? 4u : pat == 5 ? 16u : pat == 6 ? 64u : 1536u));
+		}
+		if (hipMalloc((void **)&dx, n * 2) != hipSuccess || hipMalloc((void **)&dout, n * 2) != hipSuccess)
+			return HD_E_NOMEM;
+		(void)hipMemcpy(dx, hx, n * 2, hipMemcpyHostToDevice);
+		hipLaunchKernelGGL(k_selftest_lds_order, dim3(nb), dim3(64), 0, 0, dx, rounds, dout);
+		(void)hipMemcpy(ho, dout, n * 2, hipMemcpyDeviceToHost);
+		int bad = 0;
+		for (uint32_t g = 0; g < n; g += 64)
+			for (uint32_t l = 0; l < 64; l++) {
+				uint32_t top = l;
+				for (uint32_t k = l + 1; k < 64; k++)
+					if (hx[g + k] == hx[g + l])
+						top = k;
+				if (ho[g + l] != top + 1) {
+					if (bad++ < 5)
+						fprintf(stderr, "hipdeflate selftest: LDS store arbitration: group %u lane %u entry %u holds lane %u, "
+							"highest writer is %u\n", g / 64, l, hx[g + l], ho[g + l] - 1, top);
+				}
+			}
+		fails += bad;
+		free(hx);
+		free(ho);
+		(void)hipFree(dx);
+		(void)hipFree(dout);
 	}
 	// ---- slot arithmetic vs RFC 1951 3.2.5 tables ---------------------------
 	{
