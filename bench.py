@@ -463,7 +463,7 @@ def main():
 
     # ---- the other GPU configs of BASELINE.json, same run (default invocation, one GPU) ----------
     default_run = (args.mode == "encode" and level == 1 and args.data == "fastq" and not args.block_kib
-                   and world == 1 and not args.no_extra and not args.slot)
+                   and world == 1 and not args.no_extra and not args.slot and args.gib == 16.0)
     if default_run:
         xs, xw = min(args.steps, 5), 1
         configs = {}
