@@ -108,6 +108,38 @@ void build_crc_tables(CrcTables *t)
 				s = t->T[0][s & 0xff] ^ (s >> 8);
 			t->B[k][i] = s;
 		}
+	// SL: static litlen codes (RFC 1951 3.2.6), bit-reversed, length extra bits appended, bit count << 16
+	{
+		auto rev = [](uint32_t c, int bits) {
+			uint32_t r = 0;
+			for (int i = 0; i < bits; i++)
+				r |= ((c >> i) & 1u) << (bits - 1 - i);
+			return r;
+		};
+		auto litlen = [&](uint32_t sym, uint32_t &code, uint32_t &bits) {
+			if (sym < 144) { code = rev(0x30 + sym, 8); bits = 8; }
+			else if (sym < 256) { code = rev(0x190 + (sym - 144), 9); bits = 9; }
+			else if (sym < 280) { code = rev(sym - 256, 7); bits = 7; }
+			else { code = rev(0xC0 + (sym - 280), 8); bits = 8; }
+		};
+		static const uint16_t lbase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
+						    67, 83, 99, 115, 131, 163, 195, 227, 258 };
+		static const uint8_t lext[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
+						  4, 4, 4, 4, 5, 5, 5, 5, 0 };
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t c, b;
+			litlen(i, c, b);
+			t->SL[i] = c | (b << 16);
+		}
+		for (uint32_t len = 3; len <= 258; len++) {
+			uint32_t slot = 28;
+			while (lbase[slot] > len)
+				slot--;
+			uint32_t c, b;
+			litlen(257 + slot, c, b);
+			t->SL[256 + len - 3] = (c | ((len - lbase[slot]) << b)) | ((b + lext[slot]) << 16);
+		}
+	}
 	// K[q] = x^(128 q): appending 16 q zero bytes to the state 0x80000000 (= x^0)
 	uint32_t s = 0x80000000u;
 	for (int q = 0; q < 64; q++) {

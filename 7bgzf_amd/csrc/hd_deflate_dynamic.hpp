@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 			f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 			const bool can = p + HD_MIN_MATCH <= n;
-			const uint32_t h = can ? HD_TABLE_INDEX((f.v * HD_HASH_MUL) >> (32 - HASH_BITS), WIN_BITS, HASH_BITS) : HS;
+			const uint32_t h = can ? HD_HASH_SLOT(f.v, HS) : HS;
 			const uint16_t mine = (uint16_t)(p + 1);
 			const uint32_t e = table[h];
 			table[h] = mine;
@@ -458,14 +458,8 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				const uint32_t d = intra_step_distance<INTRA>(f.v, lane);
 				f.c = (can && d) ? p + 1 - d : f.c;
 			}
-			for (;;) {
-				const uint16_t now = table[h];
-				const bool again = can && (uint16_t)(mine - now) - 1u < 0x7fffu;
-				if (!__ballot(again))
-					break;
-				if (again)
-					table[h] = mine;
-			}
+			// (lanes that hash alike stored to one entry in that one instruction: the highest lane stays,
+			// hd_deflate_static.hpp fetch())
 			return f;
 		};
 		struct Probed {

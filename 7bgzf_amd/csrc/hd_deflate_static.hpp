@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 
 	Fn8Ident fid;
 	fid.init(lane);
+	HashConsts hk;
+	hk.init(HS);
 	CrcLanes crc;
 	crc.init(lane, n);
 	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// bits that spill over (zero when the token does not cross a dword)
 		const uint32_t bp = bitpos + incl - nbits;
 		const uint32_t sh = bp & 31, i = (bp >> 5) & (STG - 1);
-		const uint64_t wide = (uint64_t)(nbits ? code : 0u) << sh;
+		const uint64_t wide = (uint64_t)code << sh;                    // callers pass code = 0 where nbits = 0
 		atomicOr(&stage[i], (uint32_t)wide);
 		atomicOr(&stage[(i + 1) & (STG - 1)], (uint32_t)(wide >> 32));
 		bitpos += total;
@@ -358,11 +360,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const bool can = INNER || p + HD_MIN_MATCH <= n;
 		// (a lane past the end of the block publishes nothing; it reads slot 0, harmlessly)
-		const uint32_t h = can ? HD_TABLE_INDEX((f.v * HD_HASH_MUL) >> (32 - HASH_BITS), WIN_BITS, HASH_BITS) : 0u;
+		const uint32_t ha = hash_slot_addr(f.v, hk);             // byte offset of the entry
+		uint16_t *const slot = (uint16_t *)((uint8_t *)table + (can ? ha : 0u));
 		const uint16_t mine = (uint16_t)(p + 1);
-		const uint32_t e = table[h];
+		const uint32_t e = *slot;
 		if (can)
-			table[h] = mine;
+			*slot = mine;
 		if (INNER) {
 			f.c = e;                                         // position + 1 itself: nothing has wrapped
 		} else {
@@ -408,10 +411,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	auto emit_tokens = [&](uint32_t count) -> bool {
 		const uint32_t t = tokbuf[(qhead + lane) & (TOKQ - 1)];
 		qhead += count;
+		if (!use_static)
+			return false;                            // given up earlier in this group of steps: nothing more is made
 		if (TOK) {
 			// queued tokens -> slab (one coalesced 4 B/lane store) + symbol histograms
 			if (ntok_slab + count > lay.cap_tok)
-				return false;                        // more tokens than the slab holds: the fused kernel's block
+				return use_static = false;           // more tokens than the slab holds: the fused kernel's block
 			if (lane < count) {
 				slab[ntok_slab + lane] = t;
 				if (t & HD_TOKEN_MATCH) {
@@ -427,31 +432,20 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			ntok_slab += count;
 			return true;
 		}
-		const bool is_match = (t & HD_TOKEN_MATCH) != 0;
-		uint32_t code, nbits;
-		{
-			uint32_t ls, leb, lev, ds, deb, dev;
-			len_slot(((t >> 16) & 0xff) + 3, ls, leb, lev);
-			off_slot((t & 0xffff) + 1, ds, deb, dev);
-			// litlen symbols 257..279: 7 bits (sym-256); 280..287: 8 bits 0xC0+(sym-280)
-			const uint32_t lc = ls < 23 ? __brev(ls + 1) >> 25 : __brev(0xC0 + (ls - 23)) >> 24;
-			const uint32_t ln7 = ls < 23 ? 7u : 8u;
-			uint32_t mc = lc | (lev << ln7);
-			uint32_t mn = ln7 + leb;
-			mc |= (__brev(ds) >> 27) << mn;
-			mn += 5;
-			mc |= dev << mn;
-			mn += deb;
-			const uint32_t byte = t & 0xff;
-			const uint32_t lcode = byte < 144 ? __brev(0x30 + byte) >> 24 : __brev(0x190 + (byte - 144)) >> 23;
-			const uint32_t lbits = byte < 144 ? 8u : 9u;
-			code = is_match ? mc : lcode;
-			nbits = lane < count ? (is_match ? mn : lbits) : 0u;
-		}
+		// literal / length: one table load (CrcTables::SL); offset: slot arithmetic, 5-bit code + extra bits
+		const uint64_t mmask = __ballot((int32_t)t < 0);
+		const uint64_t vmask = count >= 64 ? ~0ull : (1ull << (count & 63)) - 1;
+		const uint32_t e0 = ct->SL[sel(mmask, (t >> 16) & 0x1ff, t & 0xff)];
+		uint32_t ds, deb, dev;
+		off_slot((t & 0xffff) + 1, ds, deb, dev);
+		const uint32_t dpart = (__brev(ds) >> 27) | (dev << 5);
+		const uint32_t nb0 = e0 >> 16;
+		const uint32_t code = sel(vmask, sel(mmask, (e0 & 0xffff) | (dpart << nb0), e0 & 0xffff), 0u);
+		const uint32_t nbits = sel(vmask, sel(mmask, nb0 + 5 + deb, nb0), 0u);
 		const uint32_t incl = wave_incl_scan(nbits);
 		const uint32_t total = readlane(incl, 63);
 		if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit)
-			return false;
+			return use_static = false;
 		put(code, nbits, incl, total);
 		flush_ready();
 		return true;
@@ -459,7 +453,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 
 	// BFINAL = 1 (0 in flush form), BTYPE = 01
 	if (!TOK)
-		put(flush ? 2u : 3u, lane == 0 ? 3u : 0u, 3u, 3u);
+		put(lane == 0 ? (flush ? 2u : 3u) : 0u, lane == 0 ? 3u : 0u, 3u, 3u);
 
 	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
 	Probed q0 = { 0, 0, 0 };
@@ -488,25 +482,31 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f1 = fetch(inner_tag, S + 128);
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
+		// Conditions live as 64-bit lane masks in scalar registers (hd_device.hpp "lane masks"): each is the
+		// ballot of ONE compare, they are combined by s_and / s_andn2 and reach the lanes again through sel().
+		const uint64_t lanem = (INNER || lanes == 64) ? ~0ull : (1ull << (lanes & 63)) - 1;   // lanes inside the block
 		const uint32_t p = S + lane;
-		const bool can = INNER || p + HD_MIN_MATCH <= n;
-		const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
-		const bool had = can && fc.c != 0 && cp >= lo;
+		const uint32_t cv0 = fc.v, cvh0 = fc.vh, c = fc.c, cp = c - 1;
 		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
 		const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
 		const uint32_t x = cvh ^ cvh0;
-		const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-		const uint32_t room = n - p;                  // >= 4 where ok
-		uint32_t mylen = INNER ? 4 + eqb : (4 + eqb < room ? 4 + eqb : room);
-		bool ok = had && cv == cv0 && (MINLEN <= HD_MIN_MATCH || mylen >= (uint32_t)MINLEN);
+		const uint64_t xm = __ballot(cvh == cvh0);                            // all eight bytes agree
+		const uint32_t len8 = sel(xm, 8u, 4u + ((uint32_t)__builtin_ctz(x) >> 3));     // (x == 0: not selected)
+		const uint32_t room = n - p;                  // >= 4 where a match can start
+		const uint32_t mylen = INNER ? len8 : (len8 < room ? len8 : room);     // <= 8 until a capped match is extended
+		// candidate inside the window (c == 0, no candidate, makes cp = -1: one signed compare covers both;
+		// this kernel never sees a block of 2 GiB), its four bytes equal
+		uint64_t okm = __ballot((int32_t)cp >= (int32_t)lo) & __ballot(cv == cv0);
+		if (!INNER)
+			okm &= __ballot(p + HD_MIN_MATCH <= n);
+		if (MINLEN > HD_MIN_MATCH)
+			okm &= __ballot(mylen >= (uint32_t)MINLEN);
 		if (LAZY) {
 			// a candidate steps aside when its right neighbour's 8-byte length is longer
-			const uint32_t l8 = ok ? (mylen < 8 ? mylen : 8u) : 0u;
+			const uint32_t l8 = sel(okm, mylen, 0u);
 			const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l8, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-			const bool defer = ok && lane + 1 < lanes && nx > l8;
-			ok = ok && !defer;
+			okm &= ~(__ballot(nx > l8) & (lanem >> 1));                      // (lane + 1 < lanes)
 		}
-		const uint32_t dist = ok ? p - cp : 1u;
 
 		if (carry >= lanes) {                // the whole step lies inside the last match
 			carry -= lanes;
@@ -524,27 +524,31 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// whose first 8 bytes all agree ("capped") are rare; when the scan
 		// takes one it is extended cooperatively and the scan is redone for
 		// the lanes behind it.
-		const bool capped = ok && eqb == 4 && (INNER || room > 8);
-		const uint32_t jump8 = ok ? (mylen < 8 ? mylen : 8u) : 1u;   // token length as the scan sees it
+		const uint64_t capmask = INNER ? (okm & xm) : (okm & xm & __ballot(room > 8));
+		const uint32_t jump8 = sel(okm, mylen, 1u);                  // token length as the scan sees it
+		uint32_t lenv = jump8;                                       // ... and with capped matches extended
+		const uint64_t livem = ~0ull << carry;                       // lanes the last match does not cover (carry < 64)
 		uint64_t starts;
 		{
-			const Fn8 w = fn8_scan(fn8_make(lane >= carry, jump8 - 1), fid);
-			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1
-			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(w.lo & 0xff), 0x138 /* wave_shr:1 */,
-										   0xf, 0xf, false);
-			starts = __ballot(sin == 0 && lane >= carry);
+			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on covered lanes
+			Fn8 f;
+			f.lo = sel(livem, jump8 + 0x0200ffffu, 0x03020100u);
+			f.hi = sel(livem, 0x06050403u, 0x07060504u);
+			const Fn8 w = fn8_scan(f, fid);
+			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1 (0 enters lane 0)
+			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+			starts = __ballot((sin & 0xff) == 0) & livem;
 		}
 		// Capped matches the scan took: extend each (left to right) to its true
 		// length, drop the token starts it now covers, and re-thread the chain
 		// behind it.  Two parses that start a token on the same lane coincide
 		// from there on, so the walk stops at the first old start it lands on
 		// (a few hops) instead of re-scanning the wave.
-		const uint64_t capmask = __ballot(capped);
 		uint64_t cm = starts & capmask;
 		while (cm) {
 			const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
-			const uint32_t dm = readlane(dist, m);
 			const uint32_t pm = S + m;
+			const uint32_t dm = pm + 1 - readlane(c, m);
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
 			uint32_t len = 8;
 			for (;;) {
@@ -560,51 +564,49 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			}
 			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
 			if (len > 8) {
-				if (lane == m)
-					mylen = len;
+				lenv = lane == m ? len : lenv;
 				const uint32_t q = m + len;                   // first lane behind the match
 				uint64_t fresh = 0;
-				uint32_t x = q;
-				while (x < 64 && !((starts >> x) & 1)) {
-					fresh |= 1ull << x;
-					x += readlane(jump8, x);
+				uint32_t xq = q;
+				while (xq < 64 && !((starts >> xq) & 1)) {
+					fresh |= 1ull << xq;
+					xq += readlane(jump8, xq);
 				}
-				const uint64_t below_x = x >= 64 ? ~0ull : ((1ull << x) - 1);
+				const uint64_t below_x = xq >= 64 ? ~0ull : ((1ull << xq) - 1);
 				starts = (starts & (upto_m | ~below_x)) | fresh;
 			}
 			cm = starts & capmask & ~upto_m;
 		}
 		// coverage behind the last token of the step
 		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
-		const uint32_t E = last + (readlane(ok ? mylen : 1u, last));
-		const bool is_start = (starts >> lane) & 1;
-		const bool is_match = is_start && ok;
-		const bool is_lit = is_start && !ok && (INNER || lane < lanes);
-		carry = ((INNER || lanes == 64) && E > 64) ? E - 64 : 0;   // tail step: matches are clipped to n
+		const uint32_t E = last + readlane(lenv, last);
+		const uint64_t mm = starts & okm;                  // matches
+		const uint64_t tm = starts & lanem;                // tokens: matches + literals inside the block
+		carry = (INNER || lanes == 64) ? E - (E < 64 ? E : 64u) : 0;   // max(E - 64, 0), kept in scalar registers; tail step: matches are clipped to n
 
 		// ---- 5. queue the step's tokens in position order -------------------
-		// token word: literal byte, or HD_TOKEN_MATCH | (len - 3) << 16 | (dist - 1).
+		// token word: literal byte, or HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c.
 		// The code generation and the bit packing below cost the same for 1 or 64
 		// tokens, and DNA-like input yields only ~14 tokens per step: they wait in
 		// a small LDS ring until 64 are there.
 		{
-			const bool is_tok = is_match || is_lit;
-			const uint64_t tm = __ballot(is_tok);
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
-			const uint32_t tw = is_match ? (HD_TOKEN_MATCH | ((mylen - 3) << 16) | (dist - 1)) : (cv0 & 0xff);
+			const uint32_t mw = (lenv << 16) + ((p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c);
+			const uint32_t tw = sel(mm, mw, cv0 & 0xff);
+			const uint32_t qslot = (qtail + rank) & (TOKQ - 1);
 			if (TOK) {
-				if (is_tok)
-					tokbuf[(qtail + rank) & (TOKQ - 1)] = tw;
+				if ((tm >> lane) & 1)
+					tokbuf[qslot] = tw;
 			} else {
-				tokbuf[is_tok ? ((qtail + rank) & (TOKQ - 1)) : TOKQ + (lane & 31)] = tw;
+				tokbuf[sel(tm, qslot, TOKQ + (lane & 31))] = tw;
 			}
 			qtail += (uint32_t)__popcll(tm);
 		}
-		if (qtail - qhead >= 64 && !emit_tokens(64)) {
-			use_static = false;
-			return false;
-		}
-		return true;
+		// (a failed pass -- the stream would pass `limit`, or the slab is full -- clears use_static and the
+		// passes after it do nothing: the steps of a group need no exits between them)
+		if (qtail - qhead >= 64)
+			emit_tokens(64);
+		return use_static;
 	};
 	// fetch runs two steps ahead: a step is INNER when the lanes of step S + 128 still have 9 bytes
 	const bool small = n < 65536;
@@ -626,14 +628,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	};
 	// a DEFLATE block closes at the first step boundary with >= 32768 tokens (as the fused kernel)
 	auto step_boundary = [&](uint32_t S) -> bool {
-		if (TOK && ntok_slab + (qtail - qhead) - db_start >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
-			if (qtail != qhead && !emit_tokens(qtail - qhead)) {
-				use_static = false;
+		if (TOK && use_static && ntok_slab + (qtail - qhead) - db_start >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
+			if (qtail != qhead && !emit_tokens(qtail - qhead))
 				return false;
-			}
 			close_deflate_block();
 		}
-		return true;
+		return use_static;
 	};
 	// The ring is refilled one 1 KiB piece at a time, in the step that would otherwise run out of lookahead:
 	// S = 704, 1728, ... (filled == S + 320).  From there the next 16 steps need no refill, and while all
@@ -644,19 +644,15 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	while (S < n && use_static) {
 		if (small && filled < n && filled < S + HD_LOOKAHEAD && S + 15 * 64 + 192 + 8 <= n) {
 			fill_piece();
-			bool ok_group = true;
 #pragma unroll 1
-			for (uint32_t g = 0; g < 4 && ok_group; g++) {
+			for (uint32_t g = 0; g < 4 && use_static; g++) {
 #pragma unroll
 				for (uint32_t u = 0; u < 4; u++) {
-					if (ok_group) {
-						ok_group = step(std::true_type{}, std::true_type{}, S) && step_boundary(S);
-						S += 64;
-					}
+					step(std::true_type{}, std::true_type{}, S);
+					step_boundary(S);
+					S += 64;
 				}
 			}
-			if (!ok_group)
-				break;
 			continue;
 		}
 		const bool ok_step = (small && S + 192 + 8 <= n) ? step(std::true_type{}, std::false_type{}, S)
@@ -665,8 +661,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			break;
 		S += 64;
 	}
-	if (use_static && qtail != qhead && !emit_tokens(qtail - qhead))
-		use_static = false;
+	if (use_static && qtail != qhead)
+		emit_tokens(qtail - qhead);
 
 	// the CRC needs every piece, also when the static stream was abandoned
 	while (filled < n) {

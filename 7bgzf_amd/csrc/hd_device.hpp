@@ -14,10 +14,15 @@ namespace hd {
 //   T[k][v] : slicing-by-4 tables of the reflected IEEE polynomial
 //   B[k][v] : "append 1008 zero bytes" to the state byte v << 8k
 //   K[q]    : x^(128 q) mod P, q = 0..63, for the final per-lane alignment
+//   SL[i]   : the static litlen code of RFC 1951 3.2.6, ready to OR into an LSB-first stream:
+//             bits 0..15 the codeword (bit-reversed) and, for lengths, its extra bits behind it, bits 16..20
+//             the bit count.  i < 256: literal i; i = 256 + (len - 3): match length len.  One load per
+//             token in the level-1 emit pass replaces ~40 instructions of slot arithmetic and bit reversal.
 struct CrcTables {
 	uint32_t T[4][256];
 	uint32_t B[4][256];
 	uint32_t K[64];
+	uint32_t SL[512];
 };
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -145,6 +150,46 @@ __device__ __forceinline__ uint32_t readlane(uint32_t v, uint32_t l)
 __device__ __forceinline__ uint32_t uniform(uint32_t v)
 {
 	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// ---- lane masks ---------------------------------------------------------------
+// A condition that is ONE compare reaches scalar code as a v_cmp straight into an SGPR pair (__ballot of the
+// compare); conditions are then combined with s_and / s_or on the 64-bit masks and come back to the lanes
+// through v_cndmask with the mask as its selector.  (A __ballot of an already combined bool costs a
+// v_cndmask 0/1 + v_cmp_ne on top, and `(mask >> lane) & 1` three more VALU instructions.)
+// d = lane's bit of `mask` ? a : b
+__device__ __forceinline__ uint32_t sel(uint64_t mask, uint32_t a, uint32_t b)
+{
+	uint32_t d;
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
+	return d;
+}
+
+// ---- hash -> table slot ---------------------------------------------------------
+// HD_HASH_SLOT (hipdeflate_params.h) in four full-rate instructions; returns the BYTE offset of the 16-bit
+// entry, 2 * slot.  k2 / k1 / e2 / m are the constants in registers (SDWA takes no literals).
+struct HashConsts {
+	uint32_t k1, k2, e2, m;
+	__device__ __forceinline__ void init(uint32_t entries)
+	{
+		k1 = HD_HASH_K1;
+		k2 = HD_HASH_K2;
+		e2 = 2 * entries;
+		m = 0xfffeu;
+	}
+};
+__device__ __forceinline__ uint32_t hash_slot_addr(uint32_t v, const HashConsts &k)
+{
+	uint32_t t1, t, x, a;
+	asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(t1) : "v"(v), "v"(k.k2));
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(v), "v"(k.k1), "v"(t1));
+	// ((t >> 16) * 2 entries >> 16) & ~1 = 2 * (((t >> 16) * entries) >> 16)
+	asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(x) : "v"(t), "v"(k.e2));
+	asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(a) : "v"(x), "v"(k.m));
+	return a;
 }
 
 // ---- CRC-32 ---------------------------------------------------------------

@@ -64,19 +64,25 @@
 #define HD_L9_HASH_BITS    13
 #define HD_L9_MIN_LEN      5
 
-#define HD_HASH_MUL        0x9E3779B1u /* Fibonacci hashing constant        */
-/* Entries of the hash table.  The levels with 11 hash bits (1..4) keep three quarters of 2^11 -- the hash's
- * 11 bits scaled by 3/4 --: LDS is granted in 1280-byte units and 1536 entries are what brings the level-1
- * kernel from 8 units to 7, 18 waves per CU instead of 16 (measured: 220 -> 228 GB/s for 1.2 % more output),
- * and the parse of levels 3..4 from 11 waves to 12 (level 3: 141 -> 147 GB/s for 0.8 % more output).
- * Levels 5..6 (8 KiB ring, 12 hash bits) keep five eighths of 2^12 = 2560 entries: 12 units instead of 14,
- * 10 parse waves instead of 9 (level 6: 106 -> 116 GB/s on the FASTQ-like set at the same ratio, 89 -> 99 on
- * text for 1.6 % more output; MiGz 1 MiB text 86 -> 96).  Level 9 (16 KiB ring, 13 hash bits) keeps three
- * quarters of 2^13: 24 units instead of 27, 5 parse waves instead of 4 (text: 46 -> 54 GB/s for 0.7 % more output). */
+/* Hash of the four bytes v -> table slot, in 24-bit multiplies (full rate on CDNA; a 32-bit v_mul_lo is
+ * quarter rate) and scaled to ANY table size without a power-of-two step:
+ *     t    = v[23:0] * K1 + v[31:16] * K2          (mod 2^32: v_mul_u32_u24 + v_mad_u32_u24)
+ *     slot = ((t >> 16) * entries) >> 16            (v_mul_u32_u24 on the high word)
+ * Four VALU instructions with SDWA word selects (hd_device.hpp hash_slot_addr) where the round-1 hash
+ * (v * 0x9E3779B1 >> shift, then * 3 / 4) cost eight issue slots -- and the FASTQ-like set comes out 1.5 %
+ * smaller at level 1 (0.4578 -> 0.4508), text the same: the uniform scaling wastes no slot. */
+#define HD_HASH_K1         0x9E3779u
+#define HD_HASH_K2         0xC2B2AEu
+#define HD_HASH_SLOT(v, entries) \
+	((((((uint32_t)(v) & 0xffffffu) * HD_HASH_K1 + ((uint32_t)(v) >> 16) * HD_HASH_K2) >> 16) * (uint32_t)(entries)) >> 16)
+/* Entries of the hash table.  LDS is granted in 1280-byte units, so the table sizes are what fills the units the ring
+ * leaves: 1536 entries with the 4 KiB ring of levels 1..2 (7 units, 18 waves per CU instead of 16 with 2048) and the
+ * 8 KiB ring of levels 3..4 (12 parse waves instead of 11), 2560 with the 8 KiB ring of levels 5..6 (10 parse waves
+ * instead of 9 with 4096: level 6 106 -> 116 GB/s on the FASTQ-like set at the same ratio), 6144 at level 9 (5 waves
+ * instead of 4 with 8192).  hash_bits only names the geometry (11: 1536, 12: 2560 / 4096, 13: 6144). */
 #define HD_TABLE_34(win_bits, hash_bits)      (((win_bits) <= 13 && (hash_bits) == 11) || ((win_bits) == 14 && (hash_bits) == 13))
 #define HD_TABLE_58(win_bits, hash_bits)      ((win_bits) == 13 && (hash_bits) == 12)
 #define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? (3u << ((hash_bits) - 2)) : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
-#define HD_TABLE_INDEX(h, win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? ((h) * 3u) >> 2 : HD_TABLE_58(win_bits, hash_bits) ? ((h) * 5u) >> 3 : (h))
 
 /* Besides the hash table, which only knows earlier steps, a lane takes the lane just before it as its
  * candidate when that one holds the same four bytes (a run of five equal bytes): the latest occurrence,
@@ -97,6 +103,8 @@
 #define HD_SEG_BYTES       0xff00u     /* not a power of two: waves that start together must not meet on one HBM channel */
 #define HD_SEG_LIMIT       (320u << 10)
 #define HD_TOKEN_MATCH     0x80000000u /* token: literal byte | MATCH | (len-3)<<16 | (dist-1) */
+#define HD_TOKEN_MATCH_TAG 0x81000000u /* what a match token is built with: bit 24 makes bits 16..24 of the word
+                                        * 256 + (len - 3), the index of the length in the static code table */
 #define HD_LITLEN_MAXBITS  15
 #define HD_OFFSET_MAXBITS  15
 #define HD_PRECODE_MAXBITS 7

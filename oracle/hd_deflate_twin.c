@@ -136,12 +136,10 @@ static uint32_t load32(const uint8_t *p)
 	return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-/* table slot of the four bytes v: the hash, scaled to the 1536 entries the 4 KiB-ring levels keep
- * (HD_TABLE_INDEX, include/hipdeflate_params.h) */
+/* table slot of the four bytes v (HD_HASH_SLOT, include/hipdeflate_params.h) */
 static uint32_t mf_index(const mf_t *mf, uint32_t v)
 {
-	const uint32_t h = (v * HD_HASH_MUL) >> (32 - mf->hash_bits);
-	return HD_TABLE_INDEX(h, (unsigned)__builtin_ctz(mf->win), mf->hash_bits);
+	return HD_HASH_SLOT(v, HD_TABLE_ENTRIES((unsigned)__builtin_ctz(mf->win), mf->hash_bits));
 }
 
 static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
