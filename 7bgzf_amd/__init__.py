@@ -22,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhipdeflate.so")
 
 FRAME_RAW, FRAME_BGZF, FRAME_MIGZ, FRAME_RAW_FLUSH, FRAME_ZLIB, FRAME_GZIP = 0, 1, 2, 3, 4, 5
+FRAME_LATENCY = 0x100        # OR'ed into a frame: several wavefronts per block (include/hipdeflate.h)
 DEFLATE_HIP = 11
 HD_E_NODEVICE, HD_E_ARG, HD_E_NOMEM = 100, 101, 102
 
@@ -47,6 +48,7 @@ EXPORTS = [
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
     "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
     "hipdeflate_compact_span_dev",
+    "hipdeflate_lat_open", "hipdeflate_lat_input", "hipdeflate_lat_run", "hipdeflate_lat_output", "hipdeflate_lat_close",
 ]
 
 
@@ -125,6 +127,15 @@ def lib():
     L.hipdeflate_unpipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p]
     L.hipdeflate_unpipe_close.restype = None
     L.hipdeflate_unpipe_close.argtypes = [_vp]
+    L.hipdeflate_lat_open.restype = _vp
+    L.hipdeflate_lat_open.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    L.hipdeflate_lat_input.restype = _vp
+    L.hipdeflate_lat_input.argtypes = [_vp, ctypes.c_uint32]
+    L.hipdeflate_lat_run.argtypes = [_vp, _vp, ctypes.c_uint32]
+    L.hipdeflate_lat_output.restype = _vp
+    L.hipdeflate_lat_output.argtypes = [_vp, ctypes.c_uint32, _vp, _vp, _vp]
+    L.hipdeflate_lat_close.restype = None
+    L.hipdeflate_lat_close.argtypes = [_vp]
     L.hipdeflate_test_build_lengths.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]
     _lib = L
     return L

@@ -6,18 +6,25 @@
  * shadowed through the PLT, so samtools/bcftools must link libhts.so
  * (readme.md:9-14).  Differences, all forced by the device:
  *
- *  - the only method served is "hip" (BGZF_METHOD=hip, hip1 ... hip9; the
- *    trailing digits are the level, parsed as bgzf_compress.c:60-70 does).
- *    Anything else returns -1, the reference's "coder missing" value
- *    (bgzf_compress.c:136): this library holds no CPU codec to fall back to.
+ *  - The only coder here is "hip" (BGZF_METHOD=hip, hip1 ... hip9; the trailing
+ *    digits are the level, parsed as bgzf_compress.c:60-70 does; no digits = level 1,
+ *    hip's default as each method has one at :102-112).  BGZF_METHOD unset or empty
+ *    means that default too: preloading this library IS the choice of coder (the
+ *    reference's default is its zlib at level 6, :54,:102).  A BGZF_METHOD that
+ *    names anything else -- the reference's CPU coders, or an unknown name, which
+ *    the reference silently runs as zlib -- returns -1, the reference's "coder
+ *    missing" value (:136): this library holds no CPU codec, and coding with another
+ *    method than the one NAMED would be the worse surprise.
  *  - htslib calls the hook once per 0xff00-byte block from each of its worker
- *    threads.  One block per launch cannot feed a GPU, so concurrent calls are
- *    micro-batched: the first caller becomes the leader, waits up to
- *    HIPDEFLATE_BATCH_US microseconds (default 200) for the other workers'
- *    blocks, and compresses them all with ONE hipdeflate_batch_deflate call in
- *    HD_FRAME_BGZF mode (the kernel writes header, BSIZE, CRC32 and ISIZE, i.e.
- *    bgzf_compress.c:191-197).  A lone caller (batch of 1 last time) does not
- *    wait at all.  The call stays synchronous, as the reference's is.
+ *    threads and waits for the member.  Calls that arrive together share one
+ *    latency-mode batch (hipdeflate_lat_*, HD_FRAME_LATENCY: 16 wavefronts per block
+ *    at level 1, members framed by the kernel: header, BSIZE, CRC32, ISIZE, i.e.
+ *    bgzf_compress.c:191-197).  Every caller copies its own block into the batch's
+ *    pinned memory and its own member out of it, outside any lock; the first caller
+ *    of a batch (its leader) waits until the batch is as large as the previous one
+ *    or HIPDEFLATE_BATCH_US microseconds (default 60) have passed, launches, and
+ *    wakes the others.  HOOK_CTX batches can be in flight at once (one collecting,
+ *    the others on the device).  A lone caller does not wait at all.
  */
 #include <errno.h>
 #include <pthread.h>
@@ -27,37 +34,37 @@
 #include <strings.h>
 #include <time.h>
 #include "hipdeflate.h"
+#include "hipdeflate_params.h"
 
 #define HOOK_MAX_BATCH 256
-#define HOOK_SLOT 65536
+#define HOOK_CTX 3
+#define HOOK_BLOCK 0xff00u           /* what a latency-mode BGZF slot takes (16 x 4080); htslib's BGZF_BLOCK_SIZE */
 
-struct hook_req {
-	const void *src;
-	size_t slen;
-	void *dst;
-	size_t cap;
-	size_t out;
-	int ret;
-	int done;
+struct hook_batch {
+	hipdeflate_lat *lat;
+	int state;                   /* 0 free, 1 collecting, 2 closed (waiting for copies / on the device), 3 done */
+	int n, ready, taken;         /* blocks reserved, copied in, copied out */
+	int rc;
+	uint32_t len[HOOK_MAX_BATCH];
 };
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t g_full = PTHREAD_COND_INITIALIZER;   /* queue reached the batch size */
-static pthread_cond_t g_done = PTHREAD_COND_INITIALIZER;   /* a batch finished */
-static struct hook_req *g_queue[HOOK_MAX_BATCH];
-static int g_qn;
-static int g_leader;          /* a leader is collecting */
-static int g_last_batch = 1;  /* size of the previous batch: 1 => do not wait */
+static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;     /* any state change */
+static struct hook_batch g_batch[HOOK_CTX];
+static int g_open = -1;       /* the batch that is collecting, -1 = none */
+static int g_last_batch = 1;  /* size of the previous batch: what a leader waits for */
 static int g_method = -1;     /* -1 unparsed, 0 not ours, 1 hip */
 static int g_level = 1;
-static long g_window_us = 200;
-static int g_batch_target = 64;
+static long g_window_us = 60;
+static int g_batch_target = HOOK_MAX_BATCH;
+static int g_failed;
 
 static void parse_env(void)
 {
 	/* bgzf_compress.c:53-113: name = prefix, level = trailing decimal digits */
 	const char *s = getenv("BGZF_METHOD");
-	g_method = 0;
+	g_method = 1;                       /* unset / empty: this library's one coder */
+	g_level = 1;
 	if (s && *s) {
 		size_t l = strlen(s), i = l;
 		int level = -1, digit = 1;
@@ -68,10 +75,10 @@ static void parse_env(void)
 			digit *= 10;
 			i--;
 		}
-		if (i == 3 && !strncasecmp(s, "hip", 3)) {
-			g_method = 1;
+		if (i == 3 && !strncasecmp(s, "hip", 3))
 			g_level = level >= 0 ? level : 1;
-		}
+		else
+			g_method = 0;
 	}
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
@@ -86,48 +93,26 @@ static void parse_env(void)
 	}
 }
 
-/* compress `n` queued requests with one launch; called WITHOUT g_mu held */
-static void run_batch(struct hook_req **reqs, int n)
+/* a block the latency slots do not take (longer than 0xff00 bytes: not from htslib): one ordinary call */
+static int code_alone(void *dst, size_t *dlen, const void *src, size_t slen)
 {
-	static __thread unsigned char *in_buf, *out_buf;
-	static __thread size_t in_cap, out_cap;
-	uint64_t off[HOOK_MAX_BATCH];
-	uint32_t len[HOOK_MAX_BATCH], olen[HOOK_MAX_BATCH];
-	int32_t st[HOOK_MAX_BATCH];
-	size_t total = 0;
-	for (int i = 0; i < n; i++) {
-		off[i] = total;
-		len[i] = (uint32_t)reqs[i]->slen;
-		total += (reqs[i]->slen + 15) & ~(size_t)15;
+	uint64_t off = 0;
+	uint32_t len = (uint32_t)slen, olen = 0;
+	int32_t st = 0;
+	unsigned char *tmp = (unsigned char *)malloc(65536);
+	if (!tmp)
+		return -1;
+	int rc = hipdeflate_batch_deflate((const uint8_t *)src, &off, &len, 1, g_level, HD_FRAME_BGZF, tmp, 65536, 65536, &olen,
+					  NULL, &st);
+	int ret = rc ? -1 : (st || olen > *dlen) ? 1 : 0;
+	if (ret == 1)
+		fprintf(stderr, "hip_deflate %d\n", st ? st : 1);
+	if (!ret) {
+		memcpy(dst, tmp, olen);
+		*dlen = olen;
 	}
-	if (total > in_cap) {
-		free(in_buf);
-		in_buf = (unsigned char *)malloc(in_cap = total + 65536);
-	}
-	if ((size_t)n * HOOK_SLOT > out_cap) {
-		free(out_buf);
-		out_buf = (unsigned char *)malloc(out_cap = (size_t)n * HOOK_SLOT);
-	}
-	int rc = HD_E_NOMEM;
-	if (in_buf && out_buf) {
-		for (int i = 0; i < n; i++)
-			memcpy(in_buf + off[i], reqs[i]->src, reqs[i]->slen);
-		rc = hipdeflate_batch_deflate(in_buf, off, len, (uint32_t)n, g_level, HD_FRAME_BGZF, out_buf, HOOK_SLOT,
-					      HOOK_SLOT, olen, NULL, st);
-	}
-	for (int i = 0; i < n; i++) {
-		struct hook_req *r = reqs[i];
-		if (rc) {
-			r->ret = -1;                    /* coder missing */
-		} else if (st[i] || olen[i] > r->cap) {
-			fprintf(stderr, "hip_deflate %d\n", st[i] ? st[i] : 1);
-			r->ret = 1;                     /* codec error, bgzf_compress.c:163-169 */
-		} else {
-			memcpy(r->dst, out_buf + (size_t)i * HOOK_SLOT, olen[i]);
-			r->out = olen[i];
-			r->ret = 0;
-		}
-	}
+	free(tmp);
+	return ret;
 }
 
 int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int level_unused)
@@ -152,7 +137,7 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 		parse_env();
 	if (g_method != 1) {
 		pthread_mutex_unlock(&g_mu);
-		fprintf(stderr, "hipdeflate: BGZF_METHOD must be hip<level>; no other coder in this library\n");
+		fprintf(stderr, "hipdeflate: BGZF_METHOD must be hip<level> (or unset); no other coder in this library\n");
 		return -1;
 	}
 	if (*_dlen < 26) {                          /* bgzf_compress.c:116 */
@@ -163,41 +148,105 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 		pthread_mutex_unlock(&g_mu);
 		return 1;
 	}
-	struct hook_req me = { src, slen, _dst, *_dlen, 0, 0, 0 };
-	while (g_qn >= HOOK_MAX_BATCH)              /* queue full: wait for a batch to drain */
-		pthread_cond_wait(&g_done, &g_mu);
-	g_queue[g_qn++] = &me;
-	if (g_qn >= g_batch_target)
-		pthread_cond_signal(&g_full);
-	if (!g_leader) {
-		g_leader = 1;
-		if (g_window_us > 0 && (g_last_batch > 1 || g_qn > 1)) {
+	if (slen > HOOK_BLOCK || g_failed) {
+		const int failed = g_failed;
+		pthread_mutex_unlock(&g_mu);
+		return failed ? -1 : code_alone(_dst, _dlen, src, slen);
+	}
+	/* ---- join the collecting batch, or open one ---------------------------------------------- */
+	struct hook_batch *b;
+	for (;;) {
+		if (g_open >= 0) {
+			b = &g_batch[g_open];
+			break;
+		}
+		int k;
+		for (k = 0; k < HOOK_CTX && g_batch[k].state != 0; k++)
+			;
+		if (k < HOOK_CTX) {
+			b = &g_batch[k];
+			if (!b->lat) {
+				b->lat = hipdeflate_lat_open(g_level, HD_FRAME_BGZF | HD_FRAME_LATENCY, HOOK_MAX_BATCH, HOOK_BLOCK);
+				if (!b->lat) {
+					g_failed = 1;
+					pthread_mutex_unlock(&g_mu);
+					return -1;                          /* coder missing */
+				}
+			}
+			b->state = 1;
+			b->n = b->ready = b->taken = 0;
+			g_open = k;
+			break;
+		}
+		pthread_cond_wait(&g_cv, &g_mu);        /* every context is busy: wait for one to drain */
+	}
+	const int idx = b->n++;
+	const int leader = idx == 0;
+	b->len[idx] = (uint32_t)slen;
+	if (b->n >= g_batch_target || b->n >= HOOK_MAX_BATCH || (!leader && b->n >= g_last_batch)) {
+		b->state = 2;                               /* full, or as large as the last one: close it */
+		g_open = -1;
+		pthread_cond_broadcast(&g_cv);
+	}
+	pthread_mutex_unlock(&g_mu);
+
+	memcpy(hipdeflate_lat_input(b->lat, (uint32_t)idx), src, slen);      /* own block, no lock held */
+
+	pthread_mutex_lock(&g_mu);
+	b->ready++;
+	if (leader) {
+		if (b->state == 1 && g_window_us > 0 && g_last_batch > 1) {
 			struct timespec ts;
 			clock_gettime(CLOCK_REALTIME, &ts);
 			ts.tv_nsec += g_window_us * 1000L;
 			ts.tv_sec += ts.tv_nsec / 1000000000L;
 			ts.tv_nsec %= 1000000000L;
-			while (g_qn < g_batch_target)
-				if (pthread_cond_timedwait(&g_full, &g_mu, &ts) == ETIMEDOUT)
+			while (b->state == 1)
+				if (pthread_cond_timedwait(&g_cv, &g_mu, &ts) == ETIMEDOUT)
 					break;
 		}
-		struct hook_req *batch[HOOK_MAX_BATCH];
-		int n = g_qn;
-		memcpy(batch, g_queue, sizeof(batch[0]) * (size_t)n);
-		g_qn = 0;
-		g_leader = 0;
+		if (b->state == 1) {                        /* window over (or nobody to wait for) */
+			b->state = 2;
+			g_open = -1;
+		}
+		while (b->ready < b->n)                     /* the others are still copying in */
+			pthread_cond_wait(&g_cv, &g_mu);
+		const int n = b->n;
 		g_last_batch = n;
 		pthread_mutex_unlock(&g_mu);
-		run_batch(batch, n);
+		const int rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
 		pthread_mutex_lock(&g_mu);
-		for (int i = 0; i < n; i++)
-			batch[i]->done = 1;
-		pthread_cond_broadcast(&g_done);
+		b->rc = rc;
+		b->state = 3;
+		pthread_cond_broadcast(&g_cv);
+	} else {
+		if (b->ready == b->n)
+			pthread_cond_broadcast(&g_cv);          /* the leader may be waiting for this copy */
+		while (b->state != 3)
+			pthread_cond_wait(&g_cv, &g_mu);
 	}
-	while (!me.done)
-		pthread_cond_wait(&g_done, &g_mu);
+	const int rc = b->rc;
 	pthread_mutex_unlock(&g_mu);
-	if (me.ret == 0)
-		*_dlen = me.out;
-	return me.ret;
+
+	int ret;
+	uint32_t olen = 0;
+	int32_t st = 0;
+	const uint8_t *m = hipdeflate_lat_output(b->lat, (uint32_t)idx, &olen, NULL, &st);
+	if (rc || !m) {
+		ret = -1;                                   /* coder missing */
+	} else if (st || olen > *_dlen) {
+		fprintf(stderr, "hip_deflate %d\n", st ? st : 1);
+		ret = 1;                                    /* codec error, bgzf_compress.c:163-169 */
+	} else {
+		memcpy(_dst, m, olen);                      /* own member, no lock held */
+		*_dlen = olen;
+		ret = 0;
+	}
+	pthread_mutex_lock(&g_mu);
+	if (++b->taken == b->n) {
+		b->state = 0;                               /* drained: the context can collect again */
+		pthread_cond_broadcast(&g_cv);
+	}
+	pthread_mutex_unlock(&g_mu);
+	return ret;
 }

@@ -221,8 +221,7 @@ int launch_deflate(const hd::DeflateArgs &a, int level, hipStream_t st)
 {
 	if (a.nblocks == 0)
 		return 0;
-	// slots that could hold a block longer than HD_SEG_LIMIT: such blocks are coded in segments
-	int r = (level >= 1 && a.split_max > HD_SEG_LIMIT)
+	int r = a.seg_limit
 			? hd::launch_deflate_segmented(a, level, st, [&](const hd::DeflateArgs &x) { return code_batch(x, level, st); })
 			: code_batch(a, level, st);
 	if (r)
@@ -270,8 +269,10 @@ void hipdeflate_shutdown(void)
 	g.ready = false;
 }
 
-static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level)
+static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level, bool latency)
 {
+	if (level >= 1 && latency && cap > HD_LAT_SEG_BYTES(level))
+		return hd::segmented_scratch_bytes(nblocks, cap, level, HD_LAT_SEG_BYTES(level));
 	if (level >= 1 && cap > HD_SEG_LIMIT)
 		return hd::segmented_scratch_bytes(nblocks, cap, level);
 	return level < 2 ? 0 : hd::dynamic_scratch_bytes(nblocks, cap, level);
@@ -279,13 +280,15 @@ static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level)
 
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level)
 {
-	return scratch_need(nblocks, max_block, level);
+	return scratch_need(nblocks, max_block, level, false);
 }
 
 uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
 {
-	const uint64_t payload = (level >= 1 && block_bytes > HD_SEG_LIMIT) ? HD_SEG_WORST(block_bytes, 0)
-									    : block_bytes + 5 * (block_bytes / 65535 + 1) + 5;
+	// (latency mode included: its segments are the smallest, their worst case the largest)
+	const uint32_t lat = HD_LAT_SEG_BYTES(level);
+	const uint64_t payload = (level >= 1 && block_bytes > lat) ? HD_SEGN_WORST(block_bytes, lat, 0)
+								   : block_bytes + 5 * (block_bytes / 65535 + 1) + 5;
 	return (payload + 32 + 15) & ~(uint64_t)15;       // + the longest container (20 + 8 bytes)
 }
 
@@ -298,6 +301,8 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	int r = ensure();
 	if (r)
 		return r;
+	const bool latency = (frame & HD_FRAME_LATENCY) != 0;
+	frame &= ~HD_FRAME_LATENCY;
 	if (frame < HD_FRAME_RAW || frame > HD_FRAME_GZIP || (out_stride & 15) || ((uintptr_t)out & 15) || !out_len)
 		return HD_E_ARG;
 	hd::DeflateArgs a;
@@ -320,8 +325,12 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	a.skip_small = 0;
 	a.split_max = hd::split_max_block(out_stride, out_cap);
 	a.split_ovf = nullptr;
-	a.seg_limit = 0;
-	const uint64_t need = scratch_need(nblocks, a.split_max, level);
+	// slots that could hold a block longer than the segment limit (HD_SEG_LIMIT; the segment size itself in latency
+	// mode): such blocks are coded in segments, the ordinary coding leaves them alone
+	const uint32_t seg_lim = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
+	a.seg_bytes = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
+	a.seg_limit = (level >= 1 && a.split_max > seg_lim) ? seg_lim : 0;
+	const uint64_t need = scratch_need(nblocks, a.split_max, level, latency);
 	if (need) {
 		// token slabs of the dynamic levels, segment slots of large blocks: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);
@@ -462,7 +471,8 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 		return r;
 	if (nblocks == 0)
 		return 0;
-	if (!in_off || !in_len || !out || !out_len || frame < HD_FRAME_RAW || frame > HD_FRAME_GZIP)
+	if (!in_off || !in_len || !out || !out_len || (frame & ~HD_FRAME_LATENCY) < HD_FRAME_RAW ||
+	    (frame & ~HD_FRAME_LATENCY) > HD_FRAME_GZIP)
 		return HD_E_ARG;
 	std::lock_guard<std::mutex> lk(g.mu);
 	if ((r = bind_device()))
@@ -1007,6 +1017,139 @@ void hipdeflate_unpipe_close(hipdeflate_unpipe *p)
 	delete p;
 }
 
+/* ---- latency contexts: small synchronous batches ------------------------------------
+ * Everything a call needs is allocated once: pinned, device-visible memory for the blocks, the members and the
+ * tables (the kernels read the input and write the members over PCIe themselves -- no copy engine, no staging
+ * copy under a lock), device scratch for the segments, one stream.  run() = a handful of launches + one
+ * synchronisation.  Contexts are independent: two of them overlap on the device. */
+struct hipdeflate_lat {
+	int level = 1, frame = HD_FRAME_BGZF;
+	uint32_t max_blocks = 0, in_stride = 0, slot = 0;
+	hipStream_t st = nullptr;
+	Buf h_in{ nullptr, 0, true }, h_out{ nullptr, 0, true }, h_meta{ nullptr, 0, true };
+	Buf d_scratch;
+	uint8_t *din = nullptr, *dout = nullptr, *dmeta = nullptr;      // device views of the pinned buffers
+	bool latency = true;
+};
+
+hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes)
+{
+	if (ensure() || bind_device())
+		return nullptr;
+	const int fr = frame & ~HD_FRAME_LATENCY;
+	if (fr < HD_FRAME_RAW || fr > HD_FRAME_GZIP || !max_blocks || max_blocks > 65536 || !max_block_bytes ||
+	    max_block_bytes > (64u << 20))
+		return nullptr;
+	hipdeflate_lat *c = new hipdeflate_lat;
+	c->level = level;
+	c->frame = fr;
+	c->latency = (frame & HD_FRAME_LATENCY) != 0;
+	c->max_blocks = max_blocks;
+	c->in_stride = (uint32_t)up16(max_block_bytes);
+	c->slot = (uint32_t)hipdeflate_bound(max_block_bytes, level);
+	if (fr == HD_FRAME_BGZF && c->slot > 65536)
+		c->slot = 65536;
+	const size_t meta = (size_t)max_blocks * (8 + 4 + 4 + 4 + 4) + 64;
+	const uint64_t scr = scratch_need(max_blocks, c->slot, level, c->latency);
+	if (c->h_in.reserve((size_t)max_blocks * c->in_stride) || c->h_out.reserve((size_t)max_blocks * c->slot) ||
+	    c->h_meta.reserve(meta) || (scr && c->d_scratch.reserve(scr)) ||
+	    hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&c->din, c->h_in.p, 0) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&c->dout, c->h_out.p, 0) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&c->dmeta, c->h_meta.p, 0) != hipSuccess) {
+		hipdeflate_lat_close(c);
+		return nullptr;
+	}
+	memset(c->h_meta.p, 0, meta);
+	uint64_t *off = (uint64_t *)c->h_meta.p;
+	for (uint32_t i = 0; i < max_blocks; i++)
+		off[i] = (uint64_t)i * c->in_stride;
+	return c;
+}
+
+uint8_t *hipdeflate_lat_input(hipdeflate_lat *c, uint32_t i)
+{
+	return c && i < c->max_blocks ? (uint8_t *)c->h_in.p + (size_t)i * c->in_stride : nullptr;
+}
+
+int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
+{
+	if (!c || n > c->max_blocks || (n && !in_len))
+		return HD_E_ARG;
+	if (!n)
+		return 0;
+	int r = bind_device();
+	if (r)
+		return r;
+	const uint32_t mb = c->max_blocks;
+	uint32_t *h_len = (uint32_t *)((uint64_t *)c->h_meta.p + mb);
+	for (uint32_t i = 0; i < n; i++) {
+		if (in_len[i] > c->in_stride)
+			return HD_E_ARG;
+		h_len[i] = in_len[i];
+	}
+	uint64_t *d_off = (uint64_t *)c->dmeta;
+	uint32_t *d_len = (uint32_t *)(d_off + mb), *d_olen = d_len + mb, *d_crc = d_olen + mb;
+	int32_t *d_st = (int32_t *)(d_crc + mb);
+	hd::DeflateArgs a;
+	a.in = c->din;
+	a.in_off = d_off;
+	a.in_len = d_len;
+	a.nblocks = n;
+	a.frame = c->frame;
+	a.level = c->level;
+	a.out = c->dout;
+	a.out_stride = c->slot;
+	a.out_cap = c->slot;
+	a.out_len = d_olen;
+	a.crc = d_crc;
+	a.status = d_st;
+	a.ct = g.d_ct;
+	a.scratch = (uint8_t *)c->d_scratch.p;
+	a.first = 0;
+	a.count = 0;
+	a.skip_small = 0;
+	a.split_max = hd::split_max_block(c->slot, c->slot);
+	a.split_ovf = nullptr;
+	const uint32_t seg_lim = c->latency ? HD_LAT_SEG_BYTES(c->level) : HD_SEG_LIMIT;
+	a.seg_bytes = c->latency ? HD_LAT_SEG_BYTES(c->level) : HD_SEG_BYTES;
+	a.seg_limit = (c->level >= 1 && a.split_max > seg_lim) ? seg_lim : 0;
+	if ((r = launch_deflate(a, c->level, c->st)))
+		return r;
+	HD_CHECK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+const uint8_t *hipdeflate_lat_output(hipdeflate_lat *c, uint32_t i, uint32_t *out_len, uint32_t *crc32, int32_t *status)
+{
+	if (!c || i >= c->max_blocks)
+		return nullptr;
+	const uint32_t mb = c->max_blocks;
+	const uint32_t *h_olen = (const uint32_t *)((const uint64_t *)c->h_meta.p + mb) + mb;
+	if (out_len)
+		*out_len = h_olen[i];
+	if (crc32)
+		*crc32 = h_olen[mb + i];
+	if (status)
+		*status = (int32_t)h_olen[2 * mb + i];
+	return (const uint8_t *)c->h_out.p + (size_t)i * c->slot;
+}
+
+void hipdeflate_lat_close(hipdeflate_lat *c)
+{
+	if (!c)
+		return;
+	if (c->st) {
+		(void)hipStreamSynchronize(c->st);
+		(void)hipStreamDestroy(c->st);
+	}
+	c->h_in.release();
+	c->h_out.release();
+	c->h_meta.release();
+	c->d_scratch.release();
+	delete c;
+}
+
 /* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */
 
 static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level,
@@ -1018,6 +1161,11 @@ static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	uint32_t len = (uint32_t)sourceLen, olen = 0;
 	int32_t st = 0;
 	const size_t cap = *destLen > 0xfffffff0u ? 0xfffffff0u : *destLen;
+	// One block per call: latency mode (several wavefronts for the block) whenever the room covers its worst case;
+	// the ordinary form otherwise, so that -- as libdeflate_deflate -- the call succeeds whenever the stored form fits
+	const uint32_t lat = HD_LAT_SEG_BYTES(level);
+	if (level >= 1 && sourceLen > lat && cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH))
+		frame |= HD_FRAME_LATENCY;
 	// the slot stride handed to the batch call only needs to cover `cap`
 	int r = hipdeflate_batch_deflate(source, &off, &len, 1, level, frame, dest, up16(cap) ? up16(cap) : 16,
 					 (uint32_t)cap, &olen, nullptr, &st);

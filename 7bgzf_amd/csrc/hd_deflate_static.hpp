@@ -52,6 +52,7 @@ struct DeflateArgs {
 	uint32_t split_max;             // split path: largest block it takes (sizes the scratch layout)
 	uint32_t *split_ovf;            // split path: per block, 1 = left to the fused kernel (too many tokens)
 	uint32_t seg_limit;             // level-1 and fused dynamic kernel: != 0 = leave longer blocks alone (hd_segment.hpp codes them)
+	uint32_t seg_bytes;             // ... as segments of this size (HD_SEG_BYTES, or HD_LAT_SEG_BYTES in latency mode)
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -528,6 +529,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t jump8 = sel(okm, mylen, 1u);                  // token length as the scan sees it
 		uint32_t lenv = jump8;                                       // ... and with capped matches extended
 		const uint64_t livem = ~0ull << carry;                       // lanes the last match does not cover (carry < 64)
+		// (token words are prepared here, ahead of the scan: independent work for the wait states between its
+		// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
+		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
+		const uint32_t lit = cv0 & 0xff;
 		uint64_t starts;
 		{
 			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on covered lanes
@@ -582,7 +587,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t E = last + readlane(lenv, last);
 		const uint64_t mm = starts & okm;                  // matches
 		const uint64_t tm = starts & lanem;                // tokens: matches + literals inside the block
-		carry = (INNER || lanes == 64) ? E - (E < 64 ? E : 64u) : 0;   // max(E - 64, 0), kept in scalar registers; tail step: matches are clipped to n
+		// max(E, 64) - 64 in scalar registers (written in C the compiler makes a v_sub ... clamp + v_readfirstlane of
+		// it); tail step: matches are clipped to n
+		if (INNER || lanes == 64)
+			asm("s_max_u32 %0, %1, 64\n\ts_sub_u32 %0, %0, 64" : "=s"(carry) : "s"(E) : "scc");
+		else
+			carry = 0;
 
 		// ---- 5. queue the step's tokens in position order -------------------
 		// token word: literal byte, or HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c.
@@ -591,8 +601,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// a small LDS ring until 64 are there.
 		{
 			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
-			const uint32_t mw = (lenv << 16) + ((p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c);
-			const uint32_t tw = sel(mm, mw, cv0 & 0xff);
+			const uint32_t tw = sel(mm, (lenv << 16) + mw_base, lit);
 			const uint32_t qslot = (qtail + rank) & (TOKQ - 1);
 			if (TOK) {
 				if ((tm >> lane) & 1)

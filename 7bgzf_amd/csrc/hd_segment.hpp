@@ -1,7 +1,9 @@
 // hd_segment.hpp -- levels >= 1, blocks longer than HD_SEG_LIMIT (a 1 MiB MiGz member, a large
 // zlibutil buffer): the block is coded as independent HD_SEG_BYTES segments, every one in
 // full-flush form, an empty final block behind the last (include/hipdeflate_params.h; the CPU
-// twin's twin_segmented()).  One member is then work for 17 wavefronts instead of 40 ms of a single
+// twin's twin_segmented()).  LATENCY MODE (HD_FRAME_LATENCY) is the same machinery with segments
+// of HD_LAT_SEG_BYTES(level) for every block longer than that: 16 (8) wavefronts per BGZF block
+// when the batch is a handful of blocks from htslib's worker threads.  One member is then work for 17 wavefronts instead of 40 ms of a single
 // one, and wavefronts that start together no longer read 1 MiB apart (one HBM channel for all).  Three small launches wrap the ordinary dynamic
 // path: a segment table, the coding of the segments into scratch slots, and a stitch (sizes, header,
 // trailer, CRC-32 of the whole from the CRCs of the parts) followed by the gather of the payloads.
@@ -11,13 +13,15 @@
 
 namespace hd {
 
-constexpr uint32_t SEG_STRIDE = (HD_STORED_SIZE(HD_SEG_BYTES) + 5u + 32u + 15u) & ~15u;   // a slot holds any segment's worst case
+// a slot holds any segment's worst case
+__host__ __device__ inline uint32_t seg_stride(uint32_t seg) { return (HD_STORED_SIZE(seg) + 5u + 32u + 15u) & ~15u; }
 constexpr uint32_t SEG_ROUND_MAX = 65536;                                       // segments coded per round (4.3 GB of slots)
 
 struct SegArgs {
 	DeflateArgs a;               // the members: the caller's arrays
 	uint32_t first, count;       // blocks of this round
 	uint32_t S;                  // segment slots per block
+	uint32_t seg, limit;         // segment bytes; blocks longer than `limit` are segmented
 	uint64_t *seg_off;           // [count * S] each
 	uint32_t *seg_len;
 	uint32_t *seg_olen;
@@ -27,9 +31,9 @@ struct SegArgs {
 };
 
 // segment slots per block: enough for the longest block whose worst case fits the slot
-inline uint32_t seg_slots_per_block(uint32_t cap)
+inline uint32_t seg_slots_per_block(uint32_t cap, uint32_t seg)
 {
-	const uint32_t full = HD_STORED_SIZE(HD_SEG_BYTES) + 5u;
+	const uint32_t full = HD_STORED_SIZE(seg) + 5u;
 	// (a raw frame has no header: the count may be one high for the others, never low)
 	return cap / full + (cap % full >= 13u ? 1u : 0u);
 }
@@ -43,19 +47,19 @@ inline uint32_t seg_round_blocks(uint32_t nblocks, uint32_t S)
 }
 
 // bytes per round: tables + slots (the coding's own scratch comes behind)
-inline uint64_t seg_round_bytes(uint32_t round_blocks, uint32_t S)
+inline uint64_t seg_round_bytes(uint32_t round_blocks, uint32_t S, uint32_t seg)
 {
 	const uint64_t nseg = (uint64_t)round_blocks * S;
-	return nseg * (8 + 4 + 4 + 4 + 4 + 8) + 64 + nseg * SEG_STRIDE;
+	return nseg * (8 + 4 + 4 + 4 + 4 + 8) + 64 + nseg * seg_stride(seg);
 }
 
 // level 1 needs the tables and slots only; the dynamic levels add the small blocks' and the segments' token scratch
-inline uint64_t segmented_scratch_bytes(uint32_t nblocks, uint32_t cap, int level)
+inline uint64_t segmented_scratch_bytes(uint32_t nblocks, uint32_t cap, int level, uint32_t seg = HD_SEG_BYTES)
 {
-	const uint32_t S = seg_slots_per_block(cap), rb = seg_round_blocks(nblocks, S);
+	const uint32_t S = seg_slots_per_block(cap, seg), rb = seg_round_blocks(nblocks, S);
 	if (level < 2)
-		return seg_round_bytes(rb, S) + 64;
-	return dynamic_scratch_bytes(nblocks, cap, level) + seg_round_bytes(rb, S) + dynamic_scratch_bytes(rb * S, SEG_STRIDE, level) + 64;
+		return seg_round_bytes(rb, S, seg) + 64;
+	return dynamic_scratch_bytes(nblocks, cap, level) + seg_round_bytes(rb, S, seg) + dynamic_scratch_bytes(rb * S, seg_stride(seg), level) + 64;
 }
 
 __global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
@@ -65,9 +69,9 @@ __global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
 		return;
 	const uint32_t i = g.first + t / g.S, k = t % g.S;
 	const uint32_t len = g.a.in_len[i];
-	const uint64_t o = (uint64_t)k * HD_SEG_BYTES;
-	// blocks up to the limit are not segmented (the fused kernel takes them): all their slots stay empty
-	const uint32_t sl = (len > HD_SEG_LIMIT && o < len) ? (len - o < HD_SEG_BYTES ? (uint32_t)(len - o) : HD_SEG_BYTES) : 0u;
+	const uint64_t o = (uint64_t)k * g.seg;
+	// blocks up to the limit are not segmented (the ordinary coding takes them): all their slots stay empty
+	const uint32_t sl = (len > g.limit && o < len) ? (len - o < g.seg ? (uint32_t)(len - o) : g.seg) : 0u;
 	g.seg_off[t] = g.a.in_off[i] + (sl ? o : 0);
 	g.seg_len[t] = sl;
 }
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 	const DeflateArgs &a = g.a;
 	const uint32_t i = g.first + t, len = a.in_len[i];
 	const uint64_t base = (uint64_t)t * g.S;
-	if (len <= HD_SEG_LIMIT) {
+	if (len <= g.limit) {
 		for (uint32_t k = 0; k < g.S; k++) {
 			g.seg_olen[base + k] = 0;               // nothing of this block's to gather
 			g.seg_dst[base + k] = 0;
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 	uint64_t cap = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
 	if (a.frame == HD_FRAME_BGZF && cap > 65536)
 		cap = 65536;
-	const uint32_t nseg = HD_SEG_COUNT(len);
-	bool ok = nseg <= g.S && (uint64_t)hdr + HD_SEG_WORST((uint64_t)len, flush) + trl <= cap;
+	const uint32_t nseg = HD_SEGN_COUNT(len, g.seg);
+	bool ok = nseg <= g.S && (uint64_t)hdr + HD_SEGN_WORST((uint64_t)len, g.seg, flush) + trl <= cap;
 	for (uint32_t k = 0; ok && k < nseg; k++)
 		ok = g.seg_st[base + k] == 0;
 	if (!ok) {
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 	}
 	uint8_t *dst = a.out + (uint64_t)i * a.out_stride;
 	uint32_t pos = hdr, crc = 0;
-	const uint32_t xfull = gf_xpow(8ull * HD_SEG_BYTES);
+	const uint32_t xfull = gf_xpow(8ull * g.seg);
 	for (uint32_t k = 0; k < g.S; k++) {
 		if (k >= nseg) {
 			g.seg_olen[base + k] = 0;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 		g.seg_dst[base + k] = (uint64_t)i * a.out_stride + pos;
 		pos += g.seg_olen[base + k];
 		const uint32_t sl = g.seg_len[base + k];
-		crc = k == 0 ? g.seg_crc[base] : gf_mul(sl == HD_SEG_BYTES ? xfull : gf_xpow(8ull * sl), crc) ^ g.seg_crc[base + k];
+		crc = k == 0 ? g.seg_crc[base] : gf_mul(sl == g.seg ? xfull : gf_xpow(8ull * sl), crc) ^ g.seg_crc[base + k];
 	}
 	if (!flush) {
 		dst[pos] = 0x03;                                // the empty final block
@@ -161,10 +165,10 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 {
 	const uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
 	const uint32_t cap = cap64 > 0x7fffffffu ? 0x7fffffffu : (uint32_t)cap64;
-	const uint32_t S = seg_slots_per_block(cap), rb = seg_round_blocks(a.nblocks, S);
-	DeflateArgs f = a;
-	f.seg_limit = HD_SEG_LIMIT;
-	int r = code(f);
+	const uint32_t seg = a.seg_bytes, stride = seg_stride(seg);
+	const uint32_t S = seg_slots_per_block(cap, seg), rb = seg_round_blocks(a.nblocks, S);
+	// a.seg_limit is set: this launch takes the blocks up to the limit and leaves the longer ones alone
+	int r = code(a);
 	if (r)
 		return r;
 
@@ -173,6 +177,8 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 	SegArgs g;
 	g.a = a;
 	g.S = S;
+	g.seg = seg;
+	g.limit = a.seg_limit;
 	const uint64_t nseg_round = (uint64_t)rb * S;
 	g.seg_off = (uint64_t *)p;
 	g.seg_dst = g.seg_off + nseg_round;
@@ -181,7 +187,7 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 	g.seg_crc = g.seg_olen + nseg_round;
 	g.seg_st = (int32_t *)(g.seg_crc + nseg_round);
 	uint8_t *slots = (uint8_t *)(((uintptr_t)(g.seg_st + nseg_round) + 15) & ~(uintptr_t)15);
-	uint8_t *inner = slots + nseg_round * SEG_STRIDE;
+	uint8_t *inner = slots + nseg_round * stride;
 	inner = (uint8_t *)(((uintptr_t)inner + 15) & ~(uintptr_t)15);
 	for (uint32_t first = 0; first < a.nblocks; first += rb) {
 		g.first = first;
@@ -194,18 +200,18 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		s.nblocks = ns;
 		s.frame = HD_FRAME_RAW_FLUSH;
 		s.out = slots;
-		s.out_stride = SEG_STRIDE;
-		s.out_cap = SEG_STRIDE;
+		s.out_stride = stride;
+		s.out_cap = stride;
 		s.out_len = g.seg_olen;
 		s.crc = g.seg_crc;
 		s.status = g.seg_st;
 		s.scratch = inner;
-		s.split_max = SEG_STRIDE;
+		s.split_max = stride;
 		s.seg_limit = 0;
 		if ((r = code(s)))
 			return r;
 		hipLaunchKernelGGL(k_seg_stitch, dim3((g.count + 63) / 64), dim3(64), 0, st, g);
-		hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)SEG_STRIDE,
+		hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)stride,
 				   (const uint32_t *)g.seg_olen, (const uint64_t *)g.seg_dst, ns, a.out);
 	}
 	return 0;

@@ -55,6 +55,13 @@ extern "C" {
 #define HD_FRAME_GZIP  5     /* RFC 1952 as lib/zlibutil.c:379-405: 1f 8b 08 00 <mtime = 0> 02 00, raw
                               * DEFLATE, CRC32, ISIZE (the reference stamps time(NULL); a batch has no clock) */
 
+/* OR'ed into `frame`: LATENCY MODE for batches far smaller than the machine (hipdeflate_params.h, HD_LAT_SEG_BYTES):
+ * levels >= 1 code every block longer than 4080 (level 1) / 8160 (levels >= 2) bytes as independent flushed segments
+ * of that size, one wavefront each, stitched on the device -- a 0xff00-byte block is done in about a tenth of the
+ * time one wavefront needs for it.  The bytes differ from the throughput form (both are what the CPU twin gives for
+ * the same mode); bgzf_compress, hip_deflate and hip_deflate_flush use this mode. */
+#define HD_FRAME_LATENCY 0x100
+
 /* ---- lifetime ---------------------------------------------------------- */
 
 /* Select the device (-1: HIPDEFLATE_DEVICE env, else LOCAL_RANK env, else 0) and
@@ -225,6 +232,24 @@ int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const
  * (1 bad data / 3 does not fit, also used when a member is shorter than out_size), or HD_E_* */
 int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t *nbytes);
 void hipdeflate_unpipe_close(hipdeflate_unpipe *p);
+
+/* ---- latency contexts: small synchronous batches ----------------------------------
+ * For callers that hold a FEW blocks and wait for them: the LD_PRELOAD hook (htslib's worker threads hand over
+ * one 0xff00-byte block each), the per-block codecs, a thread-per-block loop like applet/7bgzf.c:159-277 ported
+ * as it stands.  A context owns pinned device-visible buffers and a stream: the caller writes block i straight
+ * into hipdeflate_lat_input(c, i), hipdeflate_lat_run() codes n blocks (frame | HD_FRAME_LATENCY: several
+ * wavefronts per block) and returns when the members are in hipdeflate_lat_output(c, i, ...).  No staging copy,
+ * no copy-engine transfer: the kernels read and write the pinned memory themselves.  One thread at a time per
+ * context; different contexts run concurrently. */
+typedef struct hipdeflate_lat hipdeflate_lat;
+hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes);
+/* where block i's input goes (max_block_bytes of pinned memory, 16-byte aligned); NULL if i is out of range */
+uint8_t *hipdeflate_lat_input(hipdeflate_lat *c, uint32_t i);
+/* code blocks 0..n-1 of in_len[i] bytes; synchronous; 0 if the batch ran (per-block status via _output) */
+int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n);
+/* member i of the last run: its bytes (pinned, valid until the next run), size, CRC-32 of the input, status */
+const uint8_t *hipdeflate_lat_output(hipdeflate_lat *c, uint32_t i, uint32_t *out_len, uint32_t *crc32, int32_t *status);
+void hipdeflate_lat_close(hipdeflate_lat *c);
 
 /* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level <= 1): the token slabs of the
  * fused kernel plus, for blocks up to 256 KiB (max_block = the slot stride), the tokens and histograms of one

@@ -115,12 +115,21 @@
 
 /* stored-block framing cost: 5 bytes per <=65535-byte block, at least one */
 #define HD_STORED_SIZE(n)  ((n) + 5u * ((n) == 0 ? 1u : (((n) + 65534u) / 65535u)))
-/* worst-case payload of a segmented block of n bytes: every segment stored (two stored blocks per full
- * segment) + its flush suffix; `flush` = the member itself is in flush form (no 03 00 behind) */
-#define HD_SEG_COUNT(n)    (((n) + HD_SEG_BYTES - 1u) / HD_SEG_BYTES)
-#define HD_SEG_WORST(n, flush) \
-	(((n) / HD_SEG_BYTES) * (HD_STORED_SIZE(HD_SEG_BYTES) + 5u) + \
-	 ((n) % HD_SEG_BYTES ? HD_STORED_SIZE((n) % HD_SEG_BYTES) + 5u : 0u) + ((flush) ? 0u : 2u))
+/* worst-case payload of a block of n bytes coded as `seg`-byte segments: every segment stored (5 bytes per <= 65535
+ * bytes) + its flush suffix; `flush` = the member itself is in flush form (no 03 00 behind) */
+#define HD_SEGN_COUNT(n, seg)  (((n) + (seg) - 1u) / (seg))
+#define HD_SEGN_WORST(n, seg, flush) \
+	(((n) / (seg)) * (HD_STORED_SIZE(seg) + 5u) + \
+	 ((n) % (seg) ? HD_STORED_SIZE((n) % (seg)) + 5u : 0u) + ((flush) ? 0u : 2u))
+#define HD_SEG_COUNT(n)        HD_SEGN_COUNT(n, HD_SEG_BYTES)
+#define HD_SEG_WORST(n, flush) HD_SEGN_WORST(n, HD_SEG_BYTES, flush)
+/* LATENCY MODE (HD_FRAME_LATENCY in the frame argument; the LD_PRELOAD hook and the per-block codecs use it): a batch
+ * too small to fill 4608 resident wavefronts -- htslib's 4..16 worker threads hand the hook one 0xff00-byte block each
+ * -- is coded with SEVERAL wavefronts per block: every block longer than HD_LAT_SEG_BYTES(level) becomes independent
+ * segments of that size, coded, flushed and stitched exactly as the long blocks above.  A 0xff00-byte block is 16
+ * segments at level 1 (4080 bytes: the 4 KiB window never held more) and 8 at the dynamic levels; its worst case,
+ * 16 x 4090 + 2 + 26, still fits a BGZF member. */
+#define HD_LAT_SEG_BYTES(level) ((level) <= 1 ? 4080u : 8160u)
 
 /* one compressed stream handed to the inflate kernel must be shorter than this: it keeps stream positions
  * as 32-bit bit counts (8 n + 64 + 24 < 2^32) */

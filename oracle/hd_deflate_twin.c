@@ -660,20 +660,22 @@ void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, u
 	memcpy(lens_out, h.len, nsyms);
 }
 
-static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush);
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat);
 
-/* levels >= 1, blocks longer than HD_SEG_LIMIT (include/hipdeflate_params.h): independent segments in
- * flush form one behind the other, then the empty final block unless the member itself is a flush form.
- * The room has to cover the worst case of every segment, whatever the data turns out to need. */
-static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
+/* levels >= 1, blocks longer than HD_SEG_LIMIT (include/hipdeflate_params.h) -- or, in latency mode, longer than
+ * `seg` = HD_LAT_SEG_BYTES(level): independent `seg`-byte segments in flush form one behind the other, then the empty
+ * final block unless the member itself is a flush form.  The room has to cover the worst case of every segment,
+ * whatever the data turns out to need. */
+static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush,
+			  unsigned seg)
 {
-	if (*destLen < HD_SEG_WORST((uint64_t)sourceLen, flush))
+	if (*destLen < HD_SEGN_WORST((uint64_t)sourceLen, seg, flush))
 		return 1;
 	size_t o = 0;
-	for (size_t s = 0; s < sourceLen; s += HD_SEG_BYTES) {
-		size_t n = sourceLen - s < HD_SEG_BYTES ? sourceLen - s : HD_SEG_BYTES;
+	for (size_t s = 0; s < sourceLen; s += seg) {
+		size_t n = sourceLen - s < seg ? sourceLen - s : seg;
 		size_t room = *destLen - o;
-		int r = twin(dest + o, &room, source + s, n, level, 1);
+		int r = twin(dest + o, &room, source + s, n, level, 1, 0);
 		if (r)
 			return r;
 		o += room;
@@ -686,10 +688,16 @@ static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source,
 	return 0;
 }
 
-static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush)
+/* lat: latency mode (HD_FRAME_LATENCY) */
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat)
 {
+	/* (the per-block codecs and the hook take the latency form only when the room covers its worst case, and the
+	 * ordinary form otherwise -- as libdeflate_deflate they succeed whenever the stored form fits) */
+	if (level >= 1 && lat && sourceLen > HD_LAT_SEG_BYTES(level) &&
+	    *destLen >= HD_SEGN_WORST((uint64_t)sourceLen, HD_LAT_SEG_BYTES(level), flush))
+		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_LAT_SEG_BYTES(level));
 	if (level >= 1 && sourceLen > HD_SEG_LIMIT)
-		return twin_segmented(dest, destLen, source, sourceLen, level, flush);
+		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_SEG_BYTES);
 	if (level <= 0)
 		return write_stored(dest, destLen, source, sourceLen, flush);   /* level 0 = the stored branch */
 	if (level == 1)
@@ -716,12 +724,23 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 0);
+	return twin(dest, destLen, source, sourceLen, level, 0, 0);
 }
 
 /* the same encoder in HD_FRAME_RAW_FLUSH form (include/hipdeflate.h) */
 int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			   size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 1);
+	return twin(dest, destLen, source, sourceLen, level, 1, 0);
+}
+
+/* ... in latency mode (HD_FRAME_LATENCY): what bgzf_compress, hip_deflate and hip_deflate_flush produce */
+int hdo_deflate_twin_lat(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
+{
+	return twin(dest, destLen, source, sourceLen, level, 0, 1);
+}
+
+int hdo_deflate_twin_lat_flush(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
+{
+	return twin(dest, destLen, source, sourceLen, level, 1, 1);
 }

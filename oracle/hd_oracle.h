@@ -70,6 +70,13 @@ void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, u
 int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			   size_t sourceLen, int level);
 
+/* ... in latency mode (HD_FRAME_LATENCY, include/hipdeflate.h): blocks longer than HD_LAT_SEG_BYTES(level) as
+ * independent flushed segments -- what bgzf_compress, hip_deflate and hip_deflate_flush produce */
+int hdo_deflate_twin_lat(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			 size_t sourceLen, int level);
+int hdo_deflate_twin_lat_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
+			       size_t sourceLen, int level);
+
 /* BGZF member framing exactly as applet/7bgzf.c:255-272 and
  * bgzf_compress.c:191-197 write it: 18-byte header, payload, CRC32, ISIZE.
  * Returns total member size, 0 if it does not fit in 65536 or in cap. */

@@ -131,6 +131,16 @@ def oracle_twin_flush(data, level, cap=None):
     return call_enc(oracle().hdo_deflate_twin_flush, data, level, cap)
 
 
+def codec_twin(data, level, cap=None):
+    """what hip_deflate / bgzf_compress give: the latency form (HD_FRAME_LATENCY: blocks longer than 4080 /
+    8160 bytes as independent flushed segments) when the room covers its worst case, else the ordinary form"""
+    return call_enc(oracle().hdo_deflate_twin_lat, data, level, cap)
+
+
+def codec_twin_flush(data, level, cap=None):
+    return call_enc(oracle().hdo_deflate_twin_lat_flush, data, level, cap)
+
+
 def oracle_crc32(data):
     a = as_u8(data)
     return oracle().hdo_crc32(0, _ptr(a), len(a))

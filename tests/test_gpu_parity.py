@@ -88,7 +88,7 @@ def test_encode_flush_form_matches_twin_and_reference_rule(pkg, level):
     assert zlib.decompressobj(-15).decompress(cat + b"\x03\x00") == b"".join(corpus[k] for k in names)
     for k in ("fastq_777", "text_5000", "random_100", "empty"):
         r, z = pkg.hip_deflate_flush(corpus[k], level)
-        assert r == 0 and z == hdtest.oracle_twin_flush(corpus[k], level)[1], k
+        assert r == 0 and z == hdtest.codec_twin_flush(corpus[k], level)[1], k
         # capacity: 5 bytes short of the result never fits
         r, _ = pkg.hip_deflate_flush(corpus[k], level, cap=max(len(z) - 5, 0))
         assert r != 0, k
@@ -333,8 +333,8 @@ def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, l
         if r == 0:
             assert members[i] == twin
     assert st[0] != 0 and st[3] == 0
-    r, z = pkg.hip_deflate(big, level)
-    assert r == 0 and z == hdtest.oracle_twin(big, level)[1]
+    r, z = pkg.hip_deflate(big, level)                   # one block per call: the latency form
+    assert r == 0 and z == hdtest.codec_twin(big, level)[1]
     outs, dcrc, dst = pkg.batch_inflate([z], [len(big)])
     assert dst[0] == 0 and outs[0] == big
 
@@ -402,14 +402,17 @@ def test_encode_capacity_errors(pkg):
     r, _ = pkg.hip_deflate(data, 1, cap=5004)
     assert r != 0
     text = bytes(hdtest.synth().text_like(5000))
+    # 5000 bytes: two latency segments when the room covers their worst case (5022), one ordinary stream below it
     r, z = pkg.hip_deflate(text, 1)
-    rt, twin = hdtest.oracle_twin(text, 1)
-    assert r == 0 and z == twin
-    r2, z2 = pkg.hip_deflate(text, 1, cap=len(z))
-    assert r2 == 0 and z2 == z
-    r3, _ = pkg.hip_deflate(text, 1, cap=len(z) - 1)
-    rt3, _ = hdtest.oracle_twin(text, 1, cap=len(z) - 1)
-    assert (r3 != 0) == (rt3 != 0)
+    rt, twin = hdtest.codec_twin(text, 1)
+    assert r == 0 and z == twin and z != hdtest.oracle_twin(text, 1)[1]
+    for cap in (5022, 5021, len(z), len(z) - 1, 2500):
+        r2, z2 = pkg.hip_deflate(text, 1, cap=cap)
+        rt2, twin2 = hdtest.codec_twin(text, 1, cap=cap)
+        assert (r2 != 0) == (rt2 != 0), cap
+        if r2 == 0:
+            assert z2 == twin2 and zlib.decompress(z2, -15) == text, cap
+    assert pkg.hip_deflate(text, 1, cap=5021)[1] == hdtest.oracle_twin(text, 1)[1]      # the ordinary form
 
 
 # ---- decode ----------------------------------------------------------------------
@@ -542,8 +545,8 @@ def test_hook(pkg):
         assert r == 0
         assert m[:16] == bytes.fromhex("1f8b08040000000000ff060042430200")
         assert int.from_bytes(m[16:18], "little") == len(m) - 1
-        r2, twin = hdtest.oracle_twin(blocks[i], 1, cap=65536 - 26)
-        assert m[18:-8] == twin
+        r2, twin = hdtest.codec_twin(blocks[i], 1, cap=65536 - 26)        # 16 flushed segments + 03 00
+        assert m[18:-8] == twin and zlib.decompress(m[18:-8], -15) == blocks[i]
         assert int.from_bytes(m[-8:-4], "little") == hdtest.oracle_crc32(blocks[i])
         assert int.from_bytes(m[-4:], "little") == len(blocks[i])
     assert pkg.bgzf_compress_hook(blocks[0], cap=20)[0] == -1     # bgzf_compress.c:116
@@ -682,3 +685,121 @@ def test_device_huffman_construction_matches_oracle_on_adversarial_frequencies(p
             row = np.ascontiguousarray(freq[i])
             o.hdo_build_lengths(row.ctypes.data, nsym, maxbits, want.ctypes.data)
             assert np.array_equal(got[i], want), (nsym, i)
+
+
+# ---- latency mode: several wavefronts per block ----------------------------------------
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 6, 9])
+def test_latency_mode_members_match_twin(pkg, level):
+    """HD_FRAME_LATENCY: every block longer than HD_LAT_SEG_BYTES(level) is coded as independent flushed segments
+    (4080 bytes at level 1, 8160 above), one wavefront each, stitched on the device.  Member == CPU twin in the
+    same mode, == input after zlib, CRC-32 folded from the segments' == zlib.crc32; blocks up to the segment
+    size are the ordinary form; in BGZF, RAW and flush framing."""
+    s = hdtest.synth()
+    blocks = [bytes(s.fastq_like(0xff00, seed=60)), bytes(s.text_like(0xff00, seed=61)), bytes(s.random_bytes(0xff00, seed=62)),
+              bytes(0xff00), bytes(s.fastq_like(4080, seed=63)), bytes(s.fastq_like(4081, seed=64)),
+              bytes(s.text_like(8160, seed=65)), bytes(s.text_like(8161, seed=66)), bytes(s.text_like(30000, seed=67)),
+              b"", b"a", bytes(s.fastq_like(12345, seed=68)), (b"abc" * 30000)[:0xff00]]
+    blob = b"".join(b + bytes(-len(b) % 16) for b in blocks)
+    offs, pos = [], 0
+    for b in blocks:
+        offs.append(pos)
+        pos += len(b) + (-len(b) % 16)
+    lens = [len(b) for b in blocks]
+    seg = 4080 if level <= 1 else 8160
+    for frame, hdr, trl in ((pkg.FRAME_BGZF, 18, 8), (pkg.FRAME_RAW, 0, 0), (pkg.FRAME_RAW_FLUSH, 0, 0)):
+        members, crc, st = pkg.batch_deflate(blob, offs, lens, level, frame | pkg.FRAME_LATENCY, slot=65536)
+        for i, b in enumerate(blocks):
+            assert st[i] == 0, (i, frame)
+            m = members[i]
+            fn = hdtest.codec_twin_flush if frame == pkg.FRAME_RAW_FLUSH else hdtest.codec_twin
+            r, twin = fn(b, level, cap=65536 - hdr - trl)
+            assert r == 0 and m[hdr:len(m) - trl] == twin, (i, frame, level, len(m), len(twin))
+            assert int(crc[i]) == zlib.crc32(b), i
+            if len(b) > seg:                                 # really segmented: a flush marker inside
+                assert twin != (hdtest.oracle_twin_flush if frame == pkg.FRAME_RAW_FLUSH else hdtest.oracle_twin)(b, level)[1]
+            if frame == pkg.FRAME_BGZF:
+                assert int.from_bytes(m[16:18], "little") == len(m) - 1 and len(m) <= 65536
+                assert int.from_bytes(m[-8:-4], "little") == zlib.crc32(b) and int.from_bytes(m[-4:], "little") == len(b)
+                assert zlib.decompress(m[18:-8], -15) == b
+            elif frame == pkg.FRAME_RAW:
+                assert zlib.decompress(m, -15) == b
+            else:
+                assert zlib.decompressobj(-15).decompress(m + b"\x03\x00") == b
+        # the device inflater takes the members back
+        if frame == pkg.FRAME_RAW:
+            outs, dcrc, dst = pkg.batch_inflate(members, lens)
+            assert all(dst[i] == 0 and outs[i] == blocks[i] for i in range(len(blocks)))
+
+
+def test_latency_context_api(pkg):
+    """hipdeflate_lat_*: pinned in/out buffers, n blocks per synchronous run, two contexts side by side from two
+    threads; members == the batch API's in latency mode == twin."""
+    import ctypes
+    import threading
+    L = pkg.lib()
+    s = hdtest.synth()
+    results = {}
+
+    def work(tid, level):
+        c = L.hipdeflate_lat_open(level, pkg.FRAME_BGZF | pkg.FRAME_LATENCY, 32, 0xff00)
+        assert c
+        got = []
+        for rnd in range(3):
+            blocks = [bytes(s.fastq_like(0xff00 - 100 * k, seed=1000 * tid + 10 * rnd + k)) for k in range(1 + 5 * rnd)]
+            lens = np.array([len(b) for b in blocks], dtype=np.uint32)
+            for i, b in enumerate(blocks):
+                ctypes.memmove(L.hipdeflate_lat_input(c, i), b, len(b))
+            assert L.hipdeflate_lat_run(c, lens.ctypes.data_as(ctypes.c_void_p), len(blocks)) == 0
+            for i, b in enumerate(blocks):
+                n, crc, st = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int32()
+                p = L.hipdeflate_lat_output(c, i, ctypes.byref(n), ctypes.byref(crc), ctypes.byref(st))
+                assert st.value == 0 and crc.value == zlib.crc32(b)
+                got.append((b, level, ctypes.string_at(p, n.value)))
+        assert L.hipdeflate_lat_input(c, 32) is None
+        L.hipdeflate_lat_close(c)
+        results[tid] = got
+
+    th = [threading.Thread(target=work, args=(t, lv)) for t, lv in enumerate((1, 6, 1))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert sorted(results) == [0, 1, 2]
+    for got in results.values():
+        for b, level, m in got:
+            r, twin = hdtest.codec_twin(b, level, cap=65536 - 26)
+            assert r == 0 and m[18:-8] == twin and zlib.decompress(m[18:-8], -15) == b
+
+
+def test_hook_method_table():
+    """BGZF_METHOD as the hook reads it (bgzf_compress.c:53-113 parses it once per process, so every case is its own
+    process): hip<l> and hip -> that level; unset / empty -> hip at its default level 1 (preloading the library is the
+    choice of coder); a method this library does not hold -- the reference's CPU coders, unknown names the reference
+    would silently run as zlib -- -> -1, "coder missing"."""
+    import subprocess
+    import sys
+    prog = r'''
+import os, sys, importlib, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hdtest
+pkg = importlib.import_module("7bgzf_amd")
+blk = bytes(hdtest.synth().fastq_like(0xff00, seed=77))
+r, m = pkg.bgzf_compress_hook(blk)
+lvl = int(sys.argv[1])
+if lvl < 0:
+    assert r == -1, r
+else:
+    assert r == 0 and m[18:-8] == hdtest.codec_twin(blk, lvl, cap=65536 - 26)[1] and zlib.decompress(m[18:-8], -15) == blk
+assert pkg.bgzf_compress_hook(b"")[1] == pkg.BGZF_EOF
+print("ok")
+''' % (hdtest.ROOT, os.path.join(hdtest.ROOT, "tests"))
+    for method, want in ((None, 1), ("", 1), ("hip", 1), ("HIP3", 3), ("hip6", 6), ("hip0", 0), ("libdeflate6", -1),
+                         ("zlib", -1), ("nosuchcoder7", -1), ("hipster2", -1)):
+        env = dict(os.environ)
+        env.pop("BGZF_METHOD", None)
+        if method is not None:
+            env["BGZF_METHOD"] = method
+        p = subprocess.run([sys.executable, "-c", prog, str(want)], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "ok" in p.stdout, (method, p.stdout[-300:], p.stderr[-600:])

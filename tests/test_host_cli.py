@@ -313,7 +313,7 @@ def test_ld_preload_hook_takes_over_an_htslib_shaped_writer(tmp_path):
     The image has no htslib, so tests/native/fakehts.c stands in for libhts.so: an exported default
     bgzf_compress() and a threaded BGZF writer in the same shared object calling it through the PLT.
     Without the preload the stand-in's stored-block members come out; with it every member must be
-    OUR level-1 member (payload == CPU twin), produced by the micro-batching hook under 8 threads."""
+    OUR level-1 member (payload == CPU twin in latency mode), produced by the batching hook under 8 threads."""
     import zlib
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
     so, exe = str(tmp_path / "libfakehts.so"), str(tmp_path / "hts_client")
@@ -334,7 +334,7 @@ def test_ld_preload_hook_takes_over_an_htslib_shaped_writer(tmp_path):
         total = int.from_bytes(out[pos + 16:pos + 18], "little") + 1
         member = out[pos:pos + total]
         chunk = data[i * 0xff00:(i + 1) * 0xff00]
-        r, twin = hdtest.oracle_twin(chunk, 1, cap=65536 - 26)
+        r, twin = hdtest.codec_twin(chunk, 1, cap=65536 - 26)             # the hook codes in latency mode
         assert r == 0 and member[18:-8] == twin, i
         assert int.from_bytes(member[-8:-4], "little") == zlib.crc32(chunk) and \
             int.from_bytes(member[-4:], "little") == len(chunk), i

@@ -64,15 +64,46 @@ def test_inflate_differential_fuzz(ref):
 
 
 def test_twin_output_accepted_by_all_reference_inflaters(ref):
-    """SURVEY.md section 4 property (i): inflate(our_deflate(x)) == x using the oracle
-    inflaters -- libdeflate, igzip (the default build's zlibutil_auto_inflate) and zlib."""
-    for name, data in hdtest.corpus_small().items():
-        for level in (0, 1):
-            r, z = hdtest.oracle_twin(data, level)
-            assert r == 0
-            for dec in (ref.libdeflate_inflate, ref.igzip_inflate, ref.zlib_inflate, ref.zlibutil_auto_inflate):
-                r2, out = hdtest.call_dec(dec, z + bytes(8), len(data))
-                assert r2 == 0 and out == data, (name, level)
+    """SURVEY.md section 4 property (i): inflate(our_deflate(x)) == x using the reference's own inflaters --
+    libdeflate (the strictest on incomplete codes, deflate_decompress.c:799-853), igzip (the default build's
+    zlibutil_auto_inflate) and zlib -- at EVERY level the encoder has, in the ordinary and the latency form
+    (flushed segments), on the corpus and on fuzz blocks: one-distance-code blocks, no-match blocks, stored
+    fallbacks, multi-block members."""
+    rng = np.random.default_rng(12)
+    s = hdtest.synth()
+    inputs = dict(hdtest.corpus_small())
+    fq, tx = bytes(s.fastq_like(0xff00, seed=5)), bytes(s.text_like(0xff00, seed=6))
+    for k in range(24):                                     # corpus_fuzz: spliced, mutated, periodic, sparse
+        kind = k % 6
+        n = int(rng.integers(1, 0xff00))
+        if kind == 0:
+            b = fq[:n]
+        elif kind == 1:
+            b = tx[:n // 2] + bytes(rng.integers(0, 256, n - n // 2, dtype=np.uint8))
+        elif kind == 2:
+            per = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+            b = (per * (n // len(per) + 1))[:n]
+        elif kind == 3:
+            a = np.zeros(n, dtype=np.uint8)
+            a[rng.integers(0, n, n // 50 + 1)] = rng.integers(1, 256, n // 50 + 1)
+            b = bytes(a)
+        elif kind == 4:
+            b = bytes(rng.integers(0, 4, n, dtype=np.uint8) + 65)          # four symbols: one-bit-ish codes
+        else:
+            b = bytes([int(rng.integers(0, 256))]) * n                    # one symbol, one distance code
+        inputs["fuzz%d" % k] = b
+    decs = (ref.libdeflate_inflate, ref.igzip_inflate, ref.zlib_inflate, ref.zlibutil_auto_inflate)
+    n_checked = 0
+    for name, data in inputs.items():
+        for level in (0, 1, 2, 3, 4, 6, 7, 9):
+            for enc in (hdtest.oracle_twin, hdtest.codec_twin):
+                r, z = enc(data, level)
+                assert r == 0, (name, level)
+                for dec in decs:
+                    r2, out = hdtest.call_dec(dec, z + bytes(8), len(data))
+                    assert r2 == 0 and out == data, (name, level, enc.__name__, dec)
+                n_checked += 1
+    assert n_checked >= 8 * 2 * 40
 
 
 def test_checksums_vs_reference(ref):

@@ -1,0 +1,124 @@
+/*
+ * hook_bench.c -- throughput of the LD_PRELOAD hook as htslib drives it: T threads, each calling
+ * bgzf_compress() (bgzf_compress.c:39) on one 0xff00-byte block at a time and waiting for the member.
+ *
+ *   hook_bench <input file> [threads=8] [seconds=2] [block=65280]
+ *
+ * Links against whatever provides bgzf_compress: libhipdeflate.so (BGZF_METHOD=hip1) or the reference's
+ * own hook built from bgzf_compress.c (oracle/_ref/libref.so, BGZF_METHOD=libdeflate1) -- the same binary
+ * source measures both sides.  Prints one JSON line.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
+
+static unsigned char *g_data;
+static size_t g_size, g_block = 0xff00;
+static volatile int g_stop;
+static double g_secs = 2.0;
+
+struct worker {
+	pthread_t th;
+	int id, nthreads;
+	uint64_t in_bytes, out_bytes, calls;
+	int err;
+};
+
+static double now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+
+static void *run(void *arg)
+{
+	struct worker *w = (struct worker *)arg;
+	unsigned char *dst = (unsigned char *)malloc(0x10000);
+	const size_t nblk = g_size / g_block;
+	size_t k = (size_t)w->id * 7919u % nblk;
+	while (!g_stop) {
+		size_t dlen = 0x10000;
+		int r = bgzf_compress(dst, &dlen, g_data + k * g_block, g_block, -1);
+		if (r) {
+			w->err = r;
+			break;
+		}
+		w->in_bytes += g_block;
+		w->out_bytes += dlen;
+		w->calls++;
+		k = (k + (size_t)w->nthreads) % nblk;
+	}
+	free(dst);
+	return NULL;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 2) {
+		fprintf(stderr, "usage: %s <input file> [threads] [seconds] [block]\n", argv[0]);
+		return 2;
+	}
+	int T = argc > 2 ? atoi(argv[2]) : 8;
+	if (argc > 3)
+		g_secs = atof(argv[3]);
+	if (argc > 4)
+		g_block = (size_t)atol(argv[4]);
+	FILE *f = fopen(argv[1], "rb");
+	if (!f) {
+		perror(argv[1]);
+		return 2;
+	}
+	fseek(f, 0, SEEK_END);
+	g_size = (size_t)ftell(f);
+	fseek(f, 0, SEEK_SET);
+	g_data = (unsigned char *)malloc(g_size);
+	if (fread(g_data, 1, g_size, f) != g_size || g_size < g_block) {
+		fprintf(stderr, "short input\n");
+		return 2;
+	}
+	fclose(f);
+	/* warm-up: first call initialises the device, pins memory ... */
+	{
+		unsigned char *dst = (unsigned char *)malloc(0x10000);
+		size_t dlen = 0x10000;
+		int r = bgzf_compress(dst, &dlen, g_data, g_block, -1);
+		if (r) {
+			fprintf(stderr, "bgzf_compress failed: %d\n", r);
+			return 1;
+		}
+		free(dst);
+	}
+	struct worker *w = (struct worker *)calloc((size_t)T, sizeof(*w));
+	const double t0 = now();
+	for (int i = 0; i < T; i++) {
+		w[i].id = i;
+		w[i].nthreads = T;
+		pthread_create(&w[i].th, NULL, run, &w[i]);
+	}
+	struct timespec d = { (time_t)g_secs, (long)((g_secs - (time_t)g_secs) * 1e9) };
+	nanosleep(&d, NULL);
+	g_stop = 1;
+	uint64_t in = 0, out = 0, calls = 0;
+	int err = 0;
+	for (int i = 0; i < T; i++) {
+		pthread_join(w[i].th, NULL);
+		in += w[i].in_bytes;
+		out += w[i].out_bytes;
+		calls += w[i].calls;
+		err |= w[i].err;
+	}
+	const double el = now() - t0;
+	const char *m = getenv("BGZF_METHOD");
+	printf("{\"threads\": %d, \"method\": \"%s\", \"block\": %zu, \"seconds\": %.3f, \"calls\": %llu, \"GBps_in\": %.4f, "
+	       "\"ratio\": %.4f, \"us_per_call\": %.1f, \"error\": %d}\n",
+	       T, m ? m : "", g_block, el, (unsigned long long)calls, in / el / 1e9, in ? (double)out / in : 0.0,
+	       calls ? el * 1e6 * T / calls : 0.0, err);
+	return err ? 1 : 0;
+}
