@@ -21,10 +21,12 @@
  *    at level 1, members framed by the kernel: header, BSIZE, CRC32, ISIZE, i.e.
  *    bgzf_compress.c:191-197).  Every caller copies its own block into the batch's
  *    pinned memory and its own member out of it, outside any lock; the first caller
- *    of a batch (its leader) waits until the batch is as large as the previous one
- *    or HIPDEFLATE_BATCH_US microseconds (default 60) have passed, launches, and
- *    wakes the others.  HOOK_CTX batches can be in flight at once (one collecting,
- *    the others on the device).  A lone caller does not wait at all.
+ *    of a batch (its leader) waits until every caller that is inside the hook and not
+ *    in a batch on the device has joined, nobody has joined for HIPDEFLATE_LINGER_US
+ *    (8) or HIPDEFLATE_BATCH_US microseconds (default 60) have passed, launches, and
+ *    publishes the result; the others spin on the batch's state (HIPDEFLATE_SPIN_US,
+ *    default 400, then they sleep).  HOOK_CTX batches can be in flight at once (one
+ *    collecting, the others on the device).  A lone caller does not wait at all.
  */
 #include <errno.h>
 #include <pthread.h>
@@ -33,6 +35,7 @@
 #include <string.h>
 #include <strings.h>
 #include <time.h>
+#include <unistd.h>
 #include "hipdeflate.h"
 #include "hipdeflate_params.h"
 
@@ -42,22 +45,62 @@
 
 struct hook_batch {
 	hipdeflate_lat *lat;
-	int state;                   /* 0 free, 1 collecting, 2 closed (waiting for copies / on the device), 3 done */
-	int n, ready, taken;         /* blocks reserved, copied in, copied out */
+	pthread_mutex_t mu;          /* sleepers of THIS batch only (members that spun long enough) */
+	pthread_cond_t cv;
+	int sleepers;
+	/* state: 0 free, 1 collecting, 2 closed (copies in flight / on the device), 3 done.  Changed under g_mu
+	 * (0 -> 1 -> 2, 3 -> 0) or by the batch's leader (2 -> 3); read with acquire loads by spinning members */
+	int state;
+	int n;                       /* blocks reserved (under g_mu while collecting, fixed afterwards) */
+	int ready, taken;            /* blocks copied in / members copied out (atomic counters) */
 	int rc;
 	uint32_t len[HOOK_MAX_BATCH];
 };
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER;     /* any state change */
+static pthread_cond_t g_cv_free = PTHREAD_COND_INITIALIZER;  /* a context became free */
 static struct hook_batch g_batch[HOOK_CTX];
 static int g_open = -1;       /* the batch that is collecting, -1 = none */
-static int g_last_batch = 1;  /* size of the previous batch: what a leader waits for */
+static int g_active;          /* callers inside the hook right now (atomic) */
+static int g_running;         /* blocks of the batches that are closed and not yet done (under g_mu) */
 static int g_method = -1;     /* -1 unparsed, 0 not ours, 1 hip */
 static int g_level = 1;
-static long g_window_us = 60;
+static long g_window_us = 60; /* a leader never waits longer than this for the batch to fill */
+static long g_linger_us = 8;  /* ... nor longer than this after the last caller joined */
+static long g_spin_us = 400;  /* a member spins this long for its batch before it sleeps */
 static int g_batch_target = HOOK_MAX_BATCH;
 static int g_failed;
+static int g_ncpu = 1;
+/* HIPDEFLATE_HOOK_STATS=1: where the time of a call goes, printed at exit (ns sums; tools/hook_bench.c reads it) */
+static int g_stats;
+static int64_t st_calls, st_batches, st_blocks, st_copy_in, st_window, st_ready, st_run, st_member_wait, st_copy_out, st_ctx_wait;
+
+__attribute__((destructor)) static void hook_stats_print(void)
+{
+	if (!g_stats || !st_calls)
+		return;
+	fprintf(stderr, "hipdeflate hook: %lld calls in %lld batches (%.1f blocks each); us per call: wait for a context %.1f, copy in %.1f, "
+		"copy out %.1f, member waits for its batch %.1f; us per batch: leader's window %.1f, others' copies %.1f, device %.1f\n",
+		(long long)st_calls, (long long)st_batches, st_batches ? (double)st_blocks / st_batches : 0.0,
+		st_ctx_wait / 1e3 / st_calls, st_copy_in / 1e3 / st_calls, st_copy_out / 1e3 / st_calls,
+		st_member_wait / 1e3 / (st_calls - st_batches ? st_calls - st_batches : 1), st_window / 1e3 / (st_batches ? st_batches : 1),
+		st_ready / 1e3 / (st_batches ? st_batches : 1), st_run / 1e3 / (st_batches ? st_batches : 1));
+}
+#define ST_ADD(var, ns) do { if (g_stats) __atomic_add_fetch(&(var), (ns), __ATOMIC_RELAXED); } while (0)
+
+static inline int64_t now_ns(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#endif
+}
 
 static void parse_env(void)
 {
@@ -83,6 +126,16 @@ static void parse_env(void)
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
 		g_window_us = atol(w);
+	const long nc = sysconf(_SC_NPROCESSORS_ONLN);
+	g_ncpu = nc > 0 ? (int)nc : 1;
+	const char *lg = getenv("HIPDEFLATE_LINGER_US");
+	if (lg && *lg)
+		g_linger_us = atol(lg);
+	const char *hs = getenv("HIPDEFLATE_HOOK_STATS");
+	g_stats = hs && *hs && *hs != '0';
+	const char *sp = getenv("HIPDEFLATE_SPIN_US");
+	if (sp && *sp)
+		g_spin_us = atol(sp);
 	const char *t = getenv("HIPDEFLATE_BATCH_BLOCKS");
 	if (t && *t) {
 		g_batch_target = atoi(t);
@@ -115,6 +168,8 @@ static int code_alone(void *dst, size_t *dlen, const void *src, size_t slen)
 	return ret;
 }
 
+static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen);
+
 int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int level_unused)
 {
 	(void)level_unused;
@@ -132,6 +187,14 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 		       28);
 		return 0;
 	}
+	__atomic_add_fetch(&g_active, 1, __ATOMIC_RELAXED);
+	const int ret = hook_compress(_dst, _dlen, src, slen);
+	__atomic_sub_fetch(&g_active, 1, __ATOMIC_RELAXED);
+	return ret;
+}
+
+static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen)
+{
 	pthread_mutex_lock(&g_mu);
 	if (g_method < 0)
 		parse_env();
@@ -155,6 +218,7 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 	}
 	/* ---- join the collecting batch, or open one ---------------------------------------------- */
 	struct hook_batch *b;
+	const int64_t t_enter = g_stats ? now_ns() : 0;
 	for (;;) {
 		if (g_open >= 0) {
 			b = &g_batch[g_open];
@@ -172,61 +236,111 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 					pthread_mutex_unlock(&g_mu);
 					return -1;                          /* coder missing */
 				}
+				pthread_mutex_init(&b->mu, NULL);
+				pthread_cond_init(&b->cv, NULL);
 			}
-			b->state = 1;
-			b->n = b->ready = b->taken = 0;
+			b->n = 0;
+			__atomic_store_n(&b->ready, 0, __ATOMIC_RELAXED);
+			__atomic_store_n(&b->taken, 0, __ATOMIC_RELAXED);
+			__atomic_store_n(&b->state, 1, __ATOMIC_RELEASE);
 			g_open = k;
 			break;
 		}
-		pthread_cond_wait(&g_cv, &g_mu);        /* every context is busy: wait for one to drain */
+		pthread_cond_wait(&g_cv_free, &g_mu);   /* every context is busy: wait for one to drain */
 	}
 	const int idx = b->n++;
 	const int leader = idx == 0;
 	b->len[idx] = (uint32_t)slen;
-	if (b->n >= g_batch_target || b->n >= HOOK_MAX_BATCH || (!leader && b->n >= g_last_batch)) {
-		b->state = 2;                               /* full, or as large as the last one: close it */
+	/* Everybody who could join has: the callers inside the hook that are not in a batch on the device are all here
+	 * (callers released together by the previous batch come back within microseconds of each other, and count
+	 * as inside while they copy their members out).  Or the batch is full. */
+	const int want = __atomic_load_n(&g_active, __ATOMIC_RELAXED) - g_running;
+	if (b->n >= g_batch_target || b->n >= HOOK_MAX_BATCH || b->n >= want) {
+		__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
+		g_running += b->n;
 		g_open = -1;
-		pthread_cond_broadcast(&g_cv);
 	}
 	pthread_mutex_unlock(&g_mu);
 
+	const int64_t t_joined = g_stats ? now_ns() : 0;
 	memcpy(hipdeflate_lat_input(b->lat, (uint32_t)idx), src, slen);      /* own block, no lock held */
+	__atomic_add_fetch(&b->ready, 1, __ATOMIC_RELEASE);
+	const int64_t t_copied = g_stats ? now_ns() : 0;
+	ST_ADD(st_calls, 1);
+	ST_ADD(st_ctx_wait, t_joined - t_enter);
+	ST_ADD(st_copy_in, t_copied - t_joined);
 
-	pthread_mutex_lock(&g_mu);
-	b->ready++;
 	if (leader) {
-		if (b->state == 1 && g_window_us > 0 && g_last_batch > 1) {
-			struct timespec ts;
-			clock_gettime(CLOCK_REALTIME, &ts);
-			ts.tv_nsec += g_window_us * 1000L;
-			ts.tv_sec += ts.tv_nsec / 1000000000L;
-			ts.tv_nsec %= 1000000000L;
-			while (b->state == 1)
-				if (pthread_cond_timedwait(&g_cv, &g_mu, &ts) == ETIMEDOUT)
+		/* Others join while the window is open; whoever completes the batch (above) closes it.  The leader closes
+		 * it himself when nobody has joined for g_linger_us although callers are missing (they are busy elsewhere),
+		 * or when the window is over. */
+		if (g_window_us > 0) {
+			const int64_t t0 = now_ns(), deadline = t0 + g_window_us * 1000;
+			int64_t t_last = t0;
+			int seen = 1;
+			while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) == 1) {
+				const int64_t t = now_ns();
+				const int cur = __atomic_load_n(&b->n, __ATOMIC_RELAXED);
+				if (cur != seen) {
+					seen = cur;
+					t_last = t;
+				}
+				if (t >= deadline || t - t_last >= g_linger_us * 1000)
 					break;
+				cpu_relax();
+			}
 		}
-		if (b->state == 1) {                        /* window over (or nobody to wait for) */
-			b->state = 2;
+		pthread_mutex_lock(&g_mu);
+		if (b->state == 1) {                        /* window over */
+			__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
+			g_running += b->n;
 			g_open = -1;
 		}
-		while (b->ready < b->n)                     /* the others are still copying in */
-			pthread_cond_wait(&g_cv, &g_mu);
 		const int n = b->n;
-		g_last_batch = n;
 		pthread_mutex_unlock(&g_mu);
-		const int rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
+		const int64_t t_closed = g_stats ? now_ns() : 0;
+		while (__atomic_load_n(&b->ready, __ATOMIC_ACQUIRE) < n)     /* the others are still copying in */
+			cpu_relax();
+		const int64_t t_ready = g_stats ? now_ns() : 0;
+		b->rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
 		pthread_mutex_lock(&g_mu);
-		b->rc = rc;
-		b->state = 3;
-		pthread_cond_broadcast(&g_cv);
+		g_running -= n;
+		pthread_mutex_unlock(&g_mu);
+		__atomic_store_n(&b->state, 3, __ATOMIC_RELEASE);
+		if (g_stats) {
+			ST_ADD(st_batches, 1);
+			ST_ADD(st_blocks, n);
+			ST_ADD(st_window, t_closed - t_copied);
+			ST_ADD(st_ready, t_ready - t_closed);
+			ST_ADD(st_run, now_ns() - t_ready);
+		}
+		pthread_mutex_lock(&b->mu);
+		if (b->sleepers)
+			pthread_cond_broadcast(&b->cv);
+		pthread_mutex_unlock(&b->mu);
 	} else {
-		if (b->ready == b->n)
-			pthread_cond_broadcast(&g_cv);          /* the leader may be waiting for this copy */
-		while (b->state != 3)
-			pthread_cond_wait(&g_cv, &g_mu);
+		/* spin for the batch (all members see it within a cache miss of the leader's store; a condition variable
+		 * hands its waiters over one by one, microseconds each), sleep only when it takes long */
+		/* (more callers than cores: spinning members would keep the leaders off the CPUs -- sleep at once) */
+		const int64_t deadline = now_ns() + (__atomic_load_n(&g_active, __ATOMIC_RELAXED) > g_ncpu ? 0 : g_spin_us * 1000);
+		int spins = 0;
+		while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) != 3) {
+			cpu_relax();
+			if ((++spins & 63) == 0 && now_ns() > deadline) {
+				pthread_mutex_lock(&b->mu);
+				b->sleepers++;
+				while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) != 3)
+					pthread_cond_wait(&b->cv, &b->mu);
+				b->sleepers--;
+				pthread_mutex_unlock(&b->mu);
+			}
+		}
+		if (g_stats)
+			ST_ADD(st_member_wait, now_ns() - t_copied);
 	}
+	const int64_t t_done = g_stats ? now_ns() : 0;
 	const int rc = b->rc;
-	pthread_mutex_unlock(&g_mu);
+	const int nb = b->n;
 
 	int ret;
 	uint32_t olen = 0;
@@ -242,11 +356,13 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 		*_dlen = olen;
 		ret = 0;
 	}
-	pthread_mutex_lock(&g_mu);
-	if (++b->taken == b->n) {
-		b->state = 0;                               /* drained: the context can collect again */
-		pthread_cond_broadcast(&g_cv);
+	if (g_stats)
+		ST_ADD(st_copy_out, now_ns() - t_done);
+	if (__atomic_add_fetch(&b->taken, 1, __ATOMIC_ACQ_REL) == nb) {
+		pthread_mutex_lock(&g_mu);
+		__atomic_store_n(&b->state, 0, __ATOMIC_RELEASE);   /* drained: the context can collect again */
+		pthread_cond_broadcast(&g_cv_free);
+		pthread_mutex_unlock(&g_mu);
 	}
-	pthread_mutex_unlock(&g_mu);
 	return ret;
 }

@@ -140,6 +140,36 @@ void build_crc_tables(CrcTables *t)
 			t->SL[256 + len - 3] = (c | ((len - lbase[slot]) << b)) | ((b + lext[slot]) << 16);
 		}
 	}
+	// P2[j]: 2^j zero bytes appended (each the square of the one before); SM[s][m-1]: m segments' worth
+	{
+		auto apply = [](const uint32_t (*Z)[256], uint32_t v) {
+			return Z[0][v & 0xff] ^ Z[1][(v >> 8) & 0xff] ^ Z[2][(v >> 16) & 0xff] ^ Z[3][v >> 24];
+		};
+		for (int k = 0; k < 4; k++)
+			for (uint32_t i = 0; i < 256; i++) {
+				const uint32_t v = i << (8 * k);
+				t->P2[0][k][i] = t->T[0][v & 0xff] ^ (v >> 8);
+			}
+		for (int j = 1; j < 24; j++)
+			for (int k = 0; k < 4; k++)
+				for (uint32_t i = 0; i < 256; i++)
+					t->P2[j][k][i] = apply(t->P2[j - 1], t->P2[j - 1][k][i]);
+		static const uint32_t segs[3] = { HD_LAT_SEG_BYTES(1), HD_LAT_SEG_BYTES(2), HD_SEG_BYTES };
+		for (int si = 0; si < 3; si++) {
+			for (int k = 0; k < 4; k++)
+				for (uint32_t i = 0; i < 256; i++) {
+					uint32_t v = i << (8 * k);
+					for (int j = 0; j < 24; j++)
+						if (segs[si] & (1u << j))
+							v = apply(t->P2[j], v);
+					t->SM[si][0][k][i] = v;
+				}
+			for (int m = 1; m < 16; m++)                 // (the one-segment operator is complete by now)
+				for (int k = 0; k < 4; k++)
+					for (uint32_t i = 0; i < 256; i++)
+						t->SM[si][m][k][i] = apply(t->SM[si][0], t->SM[si][m - 1][k][i]);
+		}
+	}
 	// K[q] = x^(128 q): appending 16 q zero bytes to the state 0x80000000 (= x^0)
 	uint32_t s = 0x80000000u;
 	for (int q = 0; q < 64; q++) {
@@ -330,6 +360,9 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	const uint32_t seg_lim = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	a.seg_bytes = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
 	a.seg_limit = (level >= 1 && a.split_max > seg_lim) ? seg_lim : 0;
+	a.hint = 0;
+	a.host_seg_off = nullptr;
+	a.host_seg_len = nullptr;
 	const uint64_t need = scratch_need(nblocks, a.split_max, level, latency);
 	if (need) {
 		// token slabs of the dynamic levels, segment slots of large blocks: library-owned, grow-only
@@ -1030,6 +1063,8 @@ struct hipdeflate_lat {
 	Buf d_scratch;
 	uint8_t *din = nullptr, *dout = nullptr, *dmeta = nullptr;      // device views of the pinned buffers
 	bool latency = true;
+	uint32_t seg = 0, seg_limit = 0, S = 0;                         // segment bytes, limit, segment slots per block
+	size_t meta_seg = 0;                                            // offset of the segment table in the meta buffer
 };
 
 hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes)
@@ -1049,7 +1084,13 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 	c->slot = (uint32_t)hipdeflate_bound(max_block_bytes, level);
 	if (fr == HD_FRAME_BGZF && c->slot > 65536)
 		c->slot = 65536;
-	const size_t meta = (size_t)max_blocks * (8 + 4 + 4 + 4 + 4) + 64;
+	const uint32_t seg_lim = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
+	c->seg = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
+	c->seg_limit = (level >= 1 && c->slot > seg_lim) ? seg_lim : 0;
+	c->S = c->seg_limit ? hd::seg_slots_per_block(c->slot, c->seg) : 0;
+	// [ in_off u64 | in_len, out_len, crc, status u32 | seg_off u64 [max_blocks * S] | seg_len u32 [max_blocks * S] ]
+	c->meta_seg = (((size_t)max_blocks * (8 + 4 + 4 + 4 + 4)) + 15) & ~(size_t)15;
+	const size_t meta = c->meta_seg + (size_t)max_blocks * c->S * 12 + 64;
 	const uint64_t scr = scratch_need(max_blocks, c->slot, level, c->latency);
 	if (c->h_in.reserve((size_t)max_blocks * c->in_stride) || c->h_out.reserve((size_t)max_blocks * c->slot) ||
 	    c->h_meta.reserve(meta) || (scr && c->d_scratch.reserve(scr)) ||
@@ -1083,10 +1124,22 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 		return r;
 	const uint32_t mb = c->max_blocks;
 	uint32_t *h_len = (uint32_t *)((uint64_t *)c->h_meta.p + mb);
+	uint32_t hint = hd::HD_HINT_NO_WHOLE | hd::HD_HINT_NO_SEG;
+	uint64_t *h_soff = (uint64_t *)((uint8_t *)c->h_meta.p + c->meta_seg);
+	uint32_t *h_slen = (uint32_t *)(h_soff + (size_t)mb * c->S);
 	for (uint32_t i = 0; i < n; i++) {
 		if (in_len[i] > c->in_stride)
 			return HD_E_ARG;
 		h_len[i] = in_len[i];
+		const bool segd = c->seg_limit && in_len[i] > c->seg_limit;
+		hint &= segd ? ~hd::HD_HINT_NO_SEG : ~hd::HD_HINT_NO_WHOLE;
+		// the segment table k_seg_table would make (hd_segment.hpp), straight into device-visible memory
+		for (uint32_t k = 0; k < c->S; k++) {
+			const uint64_t o = (uint64_t)k * c->seg;
+			const uint32_t sl = (segd && o < in_len[i]) ? (in_len[i] - o < c->seg ? (uint32_t)(in_len[i] - o) : c->seg) : 0u;
+			h_soff[(size_t)i * c->S + k] = (uint64_t)i * c->in_stride + (sl ? o : 0);
+			h_slen[(size_t)i * c->S + k] = sl;
+		}
 	}
 	uint64_t *d_off = (uint64_t *)c->dmeta;
 	uint32_t *d_len = (uint32_t *)(d_off + mb), *d_olen = d_len + mb, *d_crc = d_olen + mb;
@@ -1111,9 +1164,11 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 	a.skip_small = 0;
 	a.split_max = hd::split_max_block(c->slot, c->slot);
 	a.split_ovf = nullptr;
-	const uint32_t seg_lim = c->latency ? HD_LAT_SEG_BYTES(c->level) : HD_SEG_LIMIT;
-	a.seg_bytes = c->latency ? HD_LAT_SEG_BYTES(c->level) : HD_SEG_BYTES;
-	a.seg_limit = (c->level >= 1 && a.split_max > seg_lim) ? seg_lim : 0;
+	a.seg_bytes = c->seg;
+	a.seg_limit = c->seg_limit;
+	a.hint = c->seg_limit ? hint : 0;
+	a.host_seg_off = c->seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;
+	a.host_seg_len = c->seg_limit ? (const uint32_t *)((const uint64_t *)(c->dmeta + c->meta_seg) + (size_t)mb * c->S) : nullptr;
 	if ((r = launch_deflate(a, c->level, c->st)))
 		return r;
 	HD_CHECK(hipStreamSynchronize(c->st));

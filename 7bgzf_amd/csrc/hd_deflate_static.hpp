@@ -31,6 +31,9 @@
 
 namespace hd {
 
+constexpr uint32_t HD_HINT_NO_WHOLE = 1;   // no block is short enough to be coded whole
+constexpr uint32_t HD_HINT_NO_SEG = 2;     // no block is long enough to be coded in segments
+
 struct DeflateArgs {
 	const uint8_t *in;
 	const uint64_t *in_off;
@@ -53,6 +56,11 @@ struct DeflateArgs {
 	uint32_t *split_ovf;            // split path: per block, 1 = left to the fused kernel (too many tokens)
 	uint32_t seg_limit;             // level-1 and fused dynamic kernel: != 0 = leave longer blocks alone (hd_segment.hpp codes them)
 	uint32_t seg_bytes;             // ... as segments of this size (HD_SEG_BYTES, or HD_LAT_SEG_BYTES in latency mode)
+	// host side only (latency contexts, which see the lengths): launches known to have nothing to do are left out,
+	// and the segment table comes ready-made in device-visible memory instead of from k_seg_table
+	uint32_t hint;                  // HD_HINT_*
+	const uint64_t *host_seg_off;
+	const uint32_t *host_seg_len;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)

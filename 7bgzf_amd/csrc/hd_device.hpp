@@ -18,11 +18,16 @@ namespace hd {
 //             bits 0..15 the codeword (bit-reversed) and, for lengths, its extra bits behind it, bits 16..20
 //             the bit count.  i < 256: literal i; i = 256 + (len - 3): match length len.  One load per
 //             token in the level-1 emit pass replaces ~40 instructions of slot arithmetic and bit reversal.
+//   P2[j]   : "append 2^j zero bytes" (j < 24), SM[s][m-1] : "append m segments of zero bytes" for the three
+//             segment sizes the encoder uses (4080, 8160, 0xff00; m = 1..16), all in the byte-sliced form of B:
+//             hd_segment.hpp folds the CRC-32 of a member from its segments' with one lookup per segment.
 struct CrcTables {
 	uint32_t T[4][256];
 	uint32_t B[4][256];
 	uint32_t K[64];
 	uint32_t SL[512];
+	uint32_t P2[24][4][256];
+	uint32_t SM[3][16][4][256];
 };
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
@@ -202,6 +207,12 @@ __device__ __forceinline__ uint32_t crc_step4(const CrcTables *ct, uint32_t s, u
 __device__ __forceinline__ uint32_t crc_skip1008(const CrcTables *ct, uint32_t s)
 {
 	return ct->B[0][s & 0xff] ^ ct->B[1][(s >> 8) & 0xff] ^ ct->B[2][(s >> 16) & 0xff] ^ ct->B[3][s >> 24];
+}
+
+// one of the byte-sliced "append zero bytes" operators (P2[j], SM[s][m]) applied to a CRC state
+__device__ __forceinline__ uint32_t crc_shift(const uint32_t (*Z)[256], uint32_t s)
+{
+	return Z[0][s & 0xff] ^ Z[1][(s >> 8) & 0xff] ^ Z[2][(s >> 16) & 0xff] ^ Z[3][s >> 24];
 }
 
 __device__ __forceinline__ uint32_t crc_byte(const CrcTables *ct, uint32_t s, uint32_t b)

@@ -76,29 +76,34 @@ __global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
 	g.seg_len[t] = sl;
 }
 
-// x^n mod P (reflected): the operator that appends n/8 bytes to a CRC
-__device__ inline uint32_t gf_xpow(uint64_t n)
+// the CRC state `s` followed by n more bytes that another CRC covers: s * x^(8 n), by the P2 operators
+__device__ inline uint32_t crc_append_bytes(const CrcTables *ct, uint32_t s, uint64_t n)
 {
-	uint32_t p = 1u << 31, sq = 1u << 30;
-	for (; n; n >>= 1) {
+	for (int j = 0; n && j < 24; j++, n >>= 1)
 		if (n & 1)
-			p = gf_mul(sq, p);
-		sq = gf_mul(sq, sq);
-	}
-	return p;
+			s = crc_shift(ct->P2[j], s);
+	for (; n; n--)                                    // 16 MiB units beyond 2^24 bytes
+		s = crc_shift(ct->P2[23], crc_shift(ct->P2[23], s));
+	return s;
 }
 
-// one thread per member: where each segment's payload goes, the container bytes around them
+// One WAVEFRONT per member, lane k = segment k (members of more than 64 segments: in rounds): where each
+// segment's payload goes (a prefix sum of the segment sizes), the container bytes around them, and the
+// CRC-32 of the whole from the CRCs of the parts -- crc(A || B) = crc(A) * x^(8 |B|) ^ crc(B), so every lane
+// moves its segment's CRC to the end of the member with ONE table step (SM: m full segments behind it) and
+// the lanes are XOR-ed; a ragged last segment adds its length once, behind the sum.  (A single thread per
+// member walking the segments with bit-serial GF(2) products took 33 us -- a third of a latency-mode call.)
 __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 {
-	const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+	const uint32_t t = blockIdx.x, lane = threadIdx.x;
 	if (t >= g.count)
 		return;
 	const DeflateArgs &a = g.a;
+	const CrcTables *ct = a.ct;
 	const uint32_t i = g.first + t, len = a.in_len[i];
 	const uint64_t base = (uint64_t)t * g.S;
 	if (len <= g.limit) {
-		for (uint32_t k = 0; k < g.S; k++) {
+		for (uint32_t k = lane; k < g.S; k += 64) {
 			g.seg_olen[base + k] = 0;               // nothing of this block's to gather
 			g.seg_dst[base + k] = 0;
 		}
@@ -111,49 +116,72 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 		cap = 65536;
 	const uint32_t nseg = HD_SEGN_COUNT(len, g.seg);
 	bool ok = nseg <= g.S && (uint64_t)hdr + HD_SEGN_WORST((uint64_t)len, g.seg, flush) + trl <= cap;
-	for (uint32_t k = 0; ok && k < nseg; k++)
-		ok = g.seg_st[base + k] == 0;
+	if (ok)
+		for (uint32_t k0 = 0; k0 < nseg; k0 += 64)
+			ok = ok && !__ballot(k0 + lane < nseg && g.seg_st[base + k0 + lane] != 0);
 	if (!ok) {
-		for (uint32_t k = 0; k < g.S; k++) {
+		for (uint32_t k = lane; k < g.S; k += 64) {
 			g.seg_olen[base + k] = 0;
 			g.seg_dst[base + k] = 0;
 		}
-		a.out_len[i] = 0;
-		if (a.status) a.status[i] = 1;
-		if (a.crc) a.crc[i] = 0;
+		if (lane == 0) {
+			a.out_len[i] = 0;
+			if (a.status) a.status[i] = 1;
+			if (a.crc) a.crc[i] = 0;
+		}
 		return;
 	}
 	uint8_t *dst = a.out + (uint64_t)i * a.out_stride;
-	uint32_t pos = hdr, crc = 0;
-	const uint32_t xfull = gf_xpow(8ull * g.seg);
-	for (uint32_t k = 0; k < g.S; k++) {
-		if (k >= nseg) {
-			g.seg_olen[base + k] = 0;
-			g.seg_dst[base + k] = 0;
-			continue;
+	const int si = g.seg == HD_LAT_SEG_BYTES(1) ? 0 : g.seg == HD_LAT_SEG_BYTES(2) ? 1 : g.seg == HD_SEG_BYTES ? 2 : -1;
+	const uint32_t last_len = len - (nseg - 1) * g.seg;          // 1..seg
+	uint32_t pos = hdr, acc = 0;
+	for (uint32_t k0 = 0; k0 < g.S; k0 += 64) {
+		const uint32_t k = k0 + lane;
+		const bool in = k < nseg;
+		const uint32_t ol = in ? g.seg_olen[base + k] : 0u;
+		const uint32_t incl = wave_incl_scan(ol);
+		if (k < g.S) {
+			g.seg_dst[base + k] = in ? (uint64_t)i * a.out_stride + pos + (incl - ol) : 0;
+			if (!in)
+				g.seg_olen[base + k] = 0;
 		}
-		g.seg_dst[base + k] = (uint64_t)i * a.out_stride + pos;
-		pos += g.seg_olen[base + k];
-		const uint32_t sl = g.seg_len[base + k];
-		crc = k == 0 ? g.seg_crc[base] : gf_mul(sl == g.seg ? xfull : gf_xpow(8ull * sl), crc) ^ g.seg_crc[base + k];
+		pos += readlane(incl, 63);
+		// this segment's CRC with the m full segments between it and the last one appended
+		uint32_t c = in ? g.seg_crc[base + k] : 0u;
+		if (in && k + 1 < nseg) {
+			uint32_t m = nseg - 2 - k;
+			if (si >= 0)
+				for (; m; m -= (m < 16 ? m : 16))
+					c = crc_shift(ct->SM[si][(m < 16 ? m : 16) - 1], c);
+			else
+				c = crc_append_bytes(ct, c, (uint64_t)m * g.seg);
+		}
+		acc ^= (in && k + 1 < nseg) ? c : 0u;        // (the last segment joins below, unshifted)
 	}
-	if (!flush) {
-		dst[pos] = 0x03;                                // the empty final block
-		dst[pos + 1] = 0x00;
-		pos += 2;
+	acc = wave_xor_reduce(acc);
+	if (lane == 0) {
+		// ... then the last segment's bytes behind all of them, and its own CRC
+		uint32_t crc = nseg > 1 ? (last_len == g.seg && si >= 0 ? crc_shift(ct->SM[si][0], acc) : crc_append_bytes(ct, acc, last_len))
+					: 0u;
+		crc ^= g.seg_crc[base + nseg - 1];
+		if (!flush) {
+			dst[pos] = 0x03;                                // the empty final block
+			dst[pos + 1] = 0x00;
+			pos += 2;
+		}
+		const uint32_t paylen = pos - hdr, total = pos + trl;
+		const uint32_t sizefield = a.frame == HD_FRAME_BGZF ? total - 1 : paylen;
+		for (uint32_t o = 0; o < hdr; o++)
+			dst[o] = (uint8_t)frame_hdr_byte(a.frame, o, sizefield);
+		for (uint32_t k = 0; k < trl / 2; k++) {
+			const uint32_t f = frame_trl_field(a.frame, k, crc, len);
+			dst[pos + 2 * k] = (uint8_t)f;
+			dst[pos + 2 * k + 1] = (uint8_t)(f >> 8);
+		}
+		a.out_len[i] = total;
+		if (a.status) a.status[i] = 0;
+		if (a.crc) a.crc[i] = crc;
 	}
-	const uint32_t paylen = pos - hdr, total = pos + trl;
-	const uint32_t sizefield = a.frame == HD_FRAME_BGZF ? total - 1 : paylen;
-	for (uint32_t o = 0; o < hdr; o++)
-		dst[o] = (uint8_t)frame_hdr_byte(a.frame, o, sizefield);
-	for (uint32_t k = 0; k < trl / 2; k++) {
-		const uint32_t f = frame_trl_field(a.frame, k, crc, len);
-		dst[pos + 2 * k] = (uint8_t)f;
-		dst[pos + 2 * k + 1] = (uint8_t)(f >> 8);
-	}
-	a.out_len[i] = total;
-	if (a.status) a.status[i] = 0;
-	if (a.crc) a.crc[i] = crc;
 }
 
 // a.scratch: segmented_scratch_bytes(a.nblocks, capacity, level).  `code(args)` launches the level's
@@ -168,8 +196,8 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 	const uint32_t seg = a.seg_bytes, stride = seg_stride(seg);
 	const uint32_t S = seg_slots_per_block(cap, seg), rb = seg_round_blocks(a.nblocks, S);
 	// a.seg_limit is set: this launch takes the blocks up to the limit and leaves the longer ones alone
-	int r = code(a);
-	if (r)
+	int r = (a.hint & HD_HINT_NO_WHOLE) ? 0 : code(a);
+	if (r || (a.hint & HD_HINT_NO_SEG))
 		return r;
 
 	uint8_t *p = a.scratch + (level >= 2 ? dynamic_scratch_bytes(a.nblocks, cap, level) : 0);
@@ -193,7 +221,12 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		g.first = first;
 		g.count = a.nblocks - first < rb ? a.nblocks - first : rb;
 		const uint32_t ns = g.count * S;
-		hipLaunchKernelGGL(k_seg_table, dim3((ns + 255) / 256), dim3(256), 0, st, g);
+		if (a.host_seg_off && rb >= a.nblocks) {
+			g.seg_off = (uint64_t *)a.host_seg_off;      // made by the host (hipdeflate_lat_run)
+			g.seg_len = (uint32_t *)a.host_seg_len;
+		} else {
+			hipLaunchKernelGGL(k_seg_table, dim3((ns + 255) / 256), dim3(256), 0, st, g);
+		}
 		DeflateArgs s = a;
 		s.in_off = g.seg_off;
 		s.in_len = g.seg_len;
@@ -210,7 +243,7 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		s.seg_limit = 0;
 		if ((r = code(s)))
 			return r;
-		hipLaunchKernelGGL(k_seg_stitch, dim3((g.count + 63) / 64), dim3(64), 0, st, g);
+		hipLaunchKernelGGL(k_seg_stitch, dim3(g.count), dim3(64), 0, st, g);
 		hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)stride,
 				   (const uint32_t *)g.seg_olen, (const uint64_t *)g.seg_dst, ns, a.out);
 	}

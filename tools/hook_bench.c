@@ -17,6 +17,9 @@
 #include <time.h>
 
 int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
+#ifdef HOOK_BENCH_LAT
+#include "hipdeflate.h"
+#endif
 
 static unsigned char *g_data;
 static size_t g_size, g_block = 0xff00;
@@ -84,6 +87,32 @@ int main(int argc, char **argv)
 		return 2;
 	}
 	fclose(f);
+#ifdef HOOK_BENCH_LAT
+	if (T == 0) {
+		/* the device side alone: hipdeflate_lat_run() on n blocks, one caller, no threads */
+		const int level = getenv("HOOK_LEVEL") ? atoi(getenv("HOOK_LEVEL")) : 1;
+		hipdeflate_lat *c = hipdeflate_lat_open(level, HD_FRAME_BGZF | HD_FRAME_LATENCY, 256, 0xff00);
+		if (!c)
+			return 1;
+		uint32_t lens[256];
+		for (int n = 1; n <= 256; n *= 2) {
+			for (int i = 0; i < n; i++) {
+				memcpy(hipdeflate_lat_input(c, (uint32_t)i), g_data + (size_t)i * g_block, g_block);
+				lens[i] = (uint32_t)g_block;
+			}
+			hipdeflate_lat_run(c, lens, (uint32_t)n);
+			const int reps = 200;
+			const double t0 = now();
+			for (int r = 0; r < reps; r++)
+				if (hipdeflate_lat_run(c, lens, (uint32_t)n))
+					return 1;
+			const double us = (now() - t0) * 1e6 / reps;
+			printf("{\"lat_run_blocks\": %d, \"level\": %d, \"us\": %.1f, \"GBps_in\": %.3f}\n", n, level, us, n * g_block / us / 1e3);
+		}
+		hipdeflate_lat_close(c);
+		return 0;
+	}
+#endif
 	/* warm-up: first call initialises the device, pins memory ... */
 	{
 		unsigned char *dst = (unsigned char *)malloc(0x10000);

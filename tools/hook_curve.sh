@@ -1,4 +1,4 @@
-# usage: bash tools/hook_curve.sh <outdir>   -- hook throughput at 1/4/8/16/64 caller threads, ours (hip1, hip6) and the reference's
+# usage: bash tools/hook_curve.sh <outdir> [quick]  -- hook throughput at 1/4/8/16/64 caller threads, ours (hip1, hip6) and the reference's
 set -e
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 OUT=$1
@@ -10,16 +10,19 @@ s=importlib.import_module('7bgzf_amd.synth')
 s.fastq_like(64<<20, seed=1234).tofile('/tmp/hook_fq.bin')
 "
 : > $OUT/hook_curve.jsonl
+./7bgzf_amd/hook_bench /tmp/hook_fq.bin 0 >> $OUT/hook_curve.jsonl
+HOOK_LEVEL=6 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin 0 >> $OUT/hook_curve.jsonl
 for T in 1 4 8 16 64; do
-  BGZF_METHOD=hip1 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl
+  HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=hip1 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
 done
 for T in 8 16; do
-  BGZF_METHOD=hip6 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl
+  HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=hip6 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
 done
-if [ -x oracle/_ref/hook_bench_ref ]; then
+if [ -x oracle/_ref/hook_bench_ref ] && [ "$2" != quick ]; then
   for T in 1 4 8 16 64; do
     BGZF_METHOD=libdeflate1 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl
   done
   BGZF_METHOD=libdeflate6 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin 16 2 >> $OUT/hook_curve.jsonl
 fi
 cat $OUT/hook_curve.jsonl
+cat $OUT/hook_stats.txt
