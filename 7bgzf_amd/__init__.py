@@ -48,7 +48,7 @@ EXPORTS = [
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
     "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
     "hipdeflate_compact_span_dev",
-    "hipdeflate_lat_open", "hipdeflate_lat_input", "hipdeflate_lat_run", "hipdeflate_lat_output", "hipdeflate_lat_close",
+    "hipdeflate_pipe_members", "hipdeflate_lat_open", "hipdeflate_lat_input", "hipdeflate_lat_run", "hipdeflate_lat_output", "hipdeflate_lat_close",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
     L.hipdeflate_pipe_input.argtypes = [_vp, sz_p]
     L.hipdeflate_pipe_submit.argtypes = [_vp, ctypes.c_size_t]
     L.hipdeflate_pipe_result.argtypes = [_vp, ctypes.POINTER(_vp), sz_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.hipdeflate_pipe_members.argtypes = [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]
     L.hipdeflate_pipe_close.restype = None
     L.hipdeflate_pipe_close.argtypes = [_vp]
     L.hipdeflate_unpipe_open.restype = _vp

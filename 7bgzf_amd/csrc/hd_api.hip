@@ -849,6 +849,25 @@ int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nby
 	return bad ? 1 : 0;
 }
 
+int hipdeflate_pipe_members(hipdeflate_pipe *p, const uint32_t **out_len, const uint64_t **dst_off, const uint32_t **crc32)
+{
+	if (!p)
+		return HD_E_ARG;
+	std::lock_guard<std::mutex> lk(p->mu);
+	if (p->held < 0)
+		return HD_E_ARG;                         // no result is held
+	const PipeSlot &s = p->slots[p->held];
+	// the layout pipe_submit() copied back: olen[nb], crc[nb], status[nb], doff[nb] (u64), total (u64)
+	const uint32_t *h_olen = (const uint32_t *)s.h_meta.p;
+	if (out_len)
+		*out_len = h_olen;
+	if (crc32)
+		*crc32 = h_olen + s.nb;
+	if (dst_off)
+		*dst_off = (const uint64_t *)((const uint8_t *)s.h_meta.p + (size_t)12 * s.nb);
+	return 0;
+}
+
 void hipdeflate_pipe_close(hipdeflate_pipe *p)
 {
 	if (!p)
@@ -1113,7 +1132,10 @@ uint8_t *hipdeflate_lat_input(hipdeflate_lat *c, uint32_t i)
 	return c && i < c->max_blocks ? (uint8_t *)c->h_in.p + (size_t)i * c->in_stride : nullptr;
 }
 
-int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
+// the run with the frame, the mode and the room per member chosen by the call (the per-block codecs: a context per
+// thread serves hip_deflate and hip_deflate_flush, and falls back to the ordinary form when the caller's room is
+// below the latency form's worst case)
+static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int frame, bool latency, uint32_t out_cap)
 {
 	if (!c || n > c->max_blocks || (n && !in_len))
 		return HD_E_ARG;
@@ -1123,6 +1145,7 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 	if (r)
 		return r;
 	const uint32_t mb = c->max_blocks;
+	const uint32_t seg_limit = latency ? c->seg_limit : 0;           // (a context's slots are far below HD_SEG_LIMIT)
 	uint32_t *h_len = (uint32_t *)((uint64_t *)c->h_meta.p + mb);
 	uint32_t hint = hd::HD_HINT_NO_WHOLE | hd::HD_HINT_NO_SEG;
 	uint64_t *h_soff = (uint64_t *)((uint8_t *)c->h_meta.p + c->meta_seg);
@@ -1131,7 +1154,7 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 		if (in_len[i] > c->in_stride)
 			return HD_E_ARG;
 		h_len[i] = in_len[i];
-		const bool segd = c->seg_limit && in_len[i] > c->seg_limit;
+		const bool segd = seg_limit && in_len[i] > seg_limit;
 		hint &= segd ? ~hd::HD_HINT_NO_SEG : ~hd::HD_HINT_NO_WHOLE;
 		// the segment table k_seg_table would make (hd_segment.hpp), straight into device-visible memory
 		for (uint32_t k = 0; k < c->S; k++) {
@@ -1149,11 +1172,11 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 	a.in_off = d_off;
 	a.in_len = d_len;
 	a.nblocks = n;
-	a.frame = c->frame;
+	a.frame = frame;
 	a.level = c->level;
 	a.out = c->dout;
 	a.out_stride = c->slot;
-	a.out_cap = c->slot;
+	a.out_cap = out_cap < c->slot ? out_cap : c->slot;
 	a.out_len = d_olen;
 	a.crc = d_crc;
 	a.status = d_st;
@@ -1165,14 +1188,19 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
 	a.split_max = hd::split_max_block(c->slot, c->slot);
 	a.split_ovf = nullptr;
 	a.seg_bytes = c->seg;
-	a.seg_limit = c->seg_limit;
-	a.hint = c->seg_limit ? hint : 0;
-	a.host_seg_off = c->seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;
-	a.host_seg_len = c->seg_limit ? (const uint32_t *)((const uint64_t *)(c->dmeta + c->meta_seg) + (size_t)mb * c->S) : nullptr;
+	a.seg_limit = seg_limit;
+	a.hint = seg_limit ? hint : 0;
+	a.host_seg_off = seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;
+	a.host_seg_len = seg_limit ? (const uint32_t *)((const uint64_t *)(c->dmeta + c->meta_seg) + (size_t)mb * c->S) : nullptr;
 	if ((r = launch_deflate(a, c->level, c->st)))
 		return r;
 	HD_CHECK(hipStreamSynchronize(c->st));
 	return 0;
+}
+
+int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n)
+{
+	return c ? lat_run_ex(c, in_len, n, c->frame, c->latency, c->slot) : HD_E_ARG;
 }
 
 const uint8_t *hipdeflate_lat_output(hipdeflate_lat *c, uint32_t i, uint32_t *out_len, uint32_t *crc32, int32_t *status)
@@ -1207,11 +1235,53 @@ void hipdeflate_lat_close(hipdeflate_lat *c)
 
 /* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */
 
+// One block per call from each of the caller's threads (zlibutil_buffer_code as a pthread start routine,
+// applet/7bgzf.c:211): every thread keeps a latency context of its own for blocks up to 64 KiB -- no global lock, no
+// staging copies, ~90 us per 0xff00-byte block and thread, all threads at once.
+struct CodecCtx {
+	hipdeflate_lat *lat = nullptr;
+	int level = 0;
+	~CodecCtx() { hipdeflate_lat_close(lat); }
+};
+static thread_local CodecCtx t_codec;
+constexpr uint32_t CODEC_BLOCK = 0x10000;
+
 static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level,
 		       int frame)
 {
 	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xffffffffu - 65536u)
 		return HD_E_ARG;
+	if (sourceLen <= CODEC_BLOCK && ensure() == 0) {
+		CodecCtx &t = t_codec;
+		if (t.lat && t.level != level) {
+			hipdeflate_lat_close(t.lat);
+			t.lat = nullptr;
+		}
+		if (!t.lat) {
+			t.lat = hipdeflate_lat_open(level, HD_FRAME_RAW | HD_FRAME_LATENCY, 1, CODEC_BLOCK);
+			t.level = level;
+		}
+		if (t.lat) {
+			const size_t cap = *destLen > t.lat->slot ? t.lat->slot : *destLen;
+			const uint32_t lat = HD_LAT_SEG_BYTES(level);
+			const bool latency = level >= 1 && sourceLen > lat &&
+					     cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH);
+			if (sourceLen)
+				memcpy(hipdeflate_lat_input(t.lat, 0), source, sourceLen);
+			const uint32_t len = (uint32_t)sourceLen;
+			int r = lat_run_ex(t.lat, &len, 1, frame, latency, (uint32_t)cap);
+			if (r)
+				return r;
+			uint32_t olen = 0;
+			int32_t st = 0;
+			const uint8_t *m = hipdeflate_lat_output(t.lat, 0, &olen, nullptr, &st);
+			if (st || olen > *destLen)
+				return 1; /* !Z_OK, as libdeflate_deflate (lib/zlibutil.c:189) */
+			memcpy(dest, m, olen);
+			*destLen = olen;
+			return 0;
+		}
+	}
 	uint64_t off = 0;
 	uint32_t len = (uint32_t)sourceLen, olen = 0;
 	int32_t st = 0;

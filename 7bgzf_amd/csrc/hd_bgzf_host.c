@@ -8,6 +8,7 @@
  *     hd7bgzf -G1 < in > out.bgz        (-G<level> or -l<level>; level 0..9)
  *     hd7bgzf -d  < in.bgz > out
  *     hd7bgzf -M -b1024 -G6 < in > out.migz    (MiGz framing, block = b KiB)
+ *     hd7bgzf -G1 --index out.bgz.gzi < in > out.bgz     (+ bgzip's .gzi block index)
  *
  * What changed, and why: the reference reads one <=64 KiB block, compresses it on
  * a fresh pthread and writes it (applet/7bgzf.c:159-277); a GPU needs thousands
@@ -41,6 +42,40 @@ static uint32_t rd32(const unsigned char *p) { return rd16(p) | (rd16(p + 2) << 
 
 static size_t g_block = 0xff00;
 static int g_frame = HD_FRAME_BGZF;
+
+/* --index FILE: bgzip's .gzi -- u64 count, then (compressed offset, uncompressed offset) u64 pairs, little-endian,
+ * one per block start except the first (htslib bgzf_index_dump: "noffs - 1" records when writing; no record for
+ * the EOF member).  The compressed offsets are the device's size prefix scan of every batch + the bytes written
+ * before it: nothing walks the members on the host.  BAM virtual offsets are HIPDEFLATE_VOFFSET(coffset, uoffset). */
+static const char *g_index_path;
+static uint64_t *g_index;          /* pairs */
+static size_t g_index_n, g_index_cap;
+
+static int index_add(uint64_t coff, uint64_t uoff)
+{
+	if (g_index_n == g_index_cap) {
+		g_index_cap = g_index_cap ? g_index_cap * 2 : 4096;
+		uint64_t *q = (uint64_t *)realloc(g_index, g_index_cap * 16);
+		if (!q)
+			return 1;
+		g_index = q;
+	}
+	g_index[2 * g_index_n] = coff;
+	g_index[2 * g_index_n + 1] = uoff;
+	g_index_n++;
+	return 0;
+}
+
+static int index_write(void)
+{
+	FILE *f = fopen(g_index_path, "wb");
+	if (!f)
+		return 1;
+	const uint64_t cnt = g_index_n;        /* (this host runs on little-endian machines only: x86-64 next to an MI355X) */
+	int bad = fwrite(&cnt, 8, 1, f) != 1 || (g_index_n && fwrite(g_index, 16, g_index_n, f) != g_index_n);
+	bad |= fclose(f) != 0;
+	return bad;
+}
 
 /* compress: the reader thread fills pinned batches straight from stdin and submits
  * them, the main thread takes the finished batches (one contiguous run of members
@@ -107,6 +142,7 @@ static int do_compress(int level)
 	pthread_t rd;
 	pthread_create(&rd, NULL, reader_main, NULL);
 	int total_blocks = 0, chk = 64, fetched = 0, ret = 0;
+	uint64_t written = 0;
 	for (;;) {
 		pthread_mutex_lock(&mu);
 		while (fetched == g_submitted && !g_reader_done)
@@ -130,11 +166,24 @@ static int do_compress(int level)
 			break;
 		}
 		fetched++;
+		if (g_index_path) {
+			const uint64_t *doff;
+			if (hipdeflate_pipe_members(g_pipe, NULL, &doff, NULL)) {
+				ret = 1;
+				break;
+			}
+			for (uint32_t i = 0; i < nb; i++)
+				if (total_blocks + (int)i > 0 && index_add(written + doff[i], (uint64_t)(total_blocks + (int)i) * g_block)) {
+					ret = 1;
+					break;
+				}
+		}
 		if (write_all(data, nbytes)) {
 			fprintf(stderr, "write error\n");
 			ret = 1;
 			break;
 		}
+		written += nbytes;
 		total_blocks += (int)nb;
 		while (total_blocks >= chk) {                     /* progress as applet/7bgzf.c:278-281 */
 			fprintf(stderr, "%d\r", chk);
@@ -147,6 +196,10 @@ static int do_compress(int level)
 	hipdeflate_pipe_close(g_pipe);
 	if (g_frame == HD_FRAME_BGZF && write_all(eof_member, 28))            /* applet/7bgzf.c:283-289 */
 		return 1;
+	if (g_index_path && index_write()) {
+		fprintf(stderr, "cannot write %s\n", g_index_path);
+		return 1;
+	}
 	fprintf(stderr, "%d done.\n", total_blocks);
 	return 0;
 }
@@ -364,6 +417,8 @@ int main(int argc, char **argv)
 			g_frame = HD_FRAME_MIGZ;
 		else if (!strncmp(a, "-b", 2))
 			bsize = atoi(a + 2);
+		else if (!strcmp(a, "--index") && i + 1 < argc)
+			g_index_path = argv[++i];
 		else if (!strcmp(a, "-c") || !strncmp(a, "-@", 2))
 			;                                               /* accepted and ignored, as the reference's -c */
 		else {

@@ -213,6 +213,14 @@ int hipdeflate_pipe_submit(hipdeflate_pipe *p, size_t nbytes);
  * (cannot happen for BGZF/MiGz block sizes); HD_E_*; HD_E_ARG when nothing is pending */
 int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nbytes,
 			   uint32_t *nblocks);
+/* The members of the result last fetched (valid as long as its data): their sizes, their offsets inside the run --
+ * the device's size prefix scan, i.e. the compressed offsets a block index needs (bgzip's .gzi, BAM virtual
+ * offsets; the role of the index member of applet/7gzinga.c:173-193) -- and the CRC-32 of each block's input.
+ * Any of the three may be NULL. */
+int hipdeflate_pipe_members(hipdeflate_pipe *p, const uint32_t **out_len, const uint64_t **dst_off,
+			    const uint32_t **crc32);
+/* BAM / tabix virtual file offset of byte `uoffset` of the block whose member starts at `coffset` */
+#define HIPDEFLATE_VOFFSET(coffset, uoffset) (((uint64_t)(coffset) << 16) | (uint64_t)((uoffset) & 0xffff))
 void hipdeflate_pipe_close(hipdeflate_pipe *p);
 
 /* ---- streaming decoder: the same pipeline in the other direction -----------------

@@ -418,3 +418,44 @@ def test_decode_prescan_rejects_corrupt_headers_like_the_reference(bad):
         assert rc != 0, err              # (the reference inflates the short read and fails with "inflate N")
     else:
         assert rc == 255 and "not BGZF or corrupted" in err, (rc, err)
+
+
+def test_gzi_index_from_the_device_scan_and_random_access(tmp_path):
+    """hd7bgzf --index: bgzip's .gzi (u64 count, then (compressed, uncompressed) offset pairs for every block start
+    but the first) straight from the device's size prefix scan.  Checked against a table re-derived on the host by
+    walking BSIZE; then 100 sampled members are inflated through hipdeflate_batch_inflate using ONLY the index
+    (member = [coffset_i, coffset_{i+1}), payload behind the 18-byte header) and BAM virtual offsets are formed."""
+    import struct
+    import numpy as np
+    pkg = hdtest.pkg()
+    data = bytes(hdtest.synth().fastq_like(1500 * 0xff00 + 4321, seed=12))          # 3 pipe batches
+    idx_path = str(tmp_path / "out.bgz.gzi")
+    rc, blob, err = run(["-G1", "--index", idx_path], data)
+    assert rc == 0, err
+    raw = open(idx_path, "rb").read()
+    (cnt,) = struct.unpack_from("<Q", raw)
+    pairs = np.frombuffer(raw, dtype="<u8", offset=8).reshape(-1, 2)
+    assert cnt == len(pairs) == 1500                                            # 1501 data blocks, the first has no record
+    # the host's walk over BSIZE
+    want, pos, k = [], 0, 0
+    while pos < len(blob) - 28:
+        if k:
+            want.append((pos, k * 0xff00))
+        pos += int.from_bytes(blob[pos + 16:pos + 18], "little") + 1
+        k += 1
+    assert pos == len(blob) - 28 and k == 1501
+    assert [tuple(int(x) for x in p) for p in pairs] == want
+    # random access with nothing but the index
+    coff = [0] + [int(p[0]) for p in pairs] + [len(blob) - 28]
+    uoff = [0] + [int(p[1]) for p in pairs] + [len(data)]
+    rng = np.random.default_rng(3)
+    pick = sorted(set(int(i) for i in rng.integers(0, 1501, 100)) | {0, 1500})
+    streams = [blob[coff[i] + 18:coff[i + 1]] for i in pick]                   # payload + trailer (applet/7bgzf.c:328)
+    caps = [uoff[i + 1] - uoff[i] for i in pick]
+    outs, crc, st = pkg.batch_inflate(streams, caps)
+    for j, i in enumerate(pick):
+        assert st[j] == 0 and outs[j] == data[uoff[i]:uoff[i + 1]], i
+        assert int(crc[j]) == int.from_bytes(blob[coff[i + 1] - 8:coff[i + 1] - 4], "little")
+    # virtual offset of byte 1000 of block 7: (coffset << 16) | uoffset, as htslib's bgzf_tell
+    v = (coff[7] << 16) | 1000
+    assert v >> 16 == want[6][0] and v & 0xffff == 1000
