@@ -176,6 +176,39 @@ def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
                 "one_core": round(one, 4),
                 "sample": "%s; %d blocks (%.2f GB) of the same workload over %d threads, %.1f s CPU work"
                           % (what, threads * n_all, threads * n_all * block / 1e9, threads, wall * threads)})
+    # The same reference function on real pthreads (tools/hook_bench.c linked against oracle/_ref/libref.so): Python
+    # threads hand the GIL around between the ctypes calls and sell the reference short.  Where the harness exists
+    # its all-core figure is the reported value; the reference's LD_PRELOAD hook (bgzf_compress.c: codec + CRC-32 +
+    # framing per call) is timed the same way.
+    harness = os.path.join(ROOT, "oracle", "_ref", "hook_bench_ref")
+    if have_ref and mode == "encode" and os.path.exists(harness):
+        import subprocess
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".bin") as tf:
+            tile[: min(len(tile), 64 << 20)].tofile(tf.name)
+
+            def run(nthr, codec, env_method=None):
+                env = dict(os.environ)
+                if env_method:
+                    env["BGZF_METHOD"] = env_method
+                cmd = [harness, tf.name, str(nthr), "2", str(block)] + ([codec] if codec else [])
+                p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=120)
+                return json.loads(p.stdout.strip().split("\n")[-1])["GBps_in"] if p.returncode == 0 else None
+            try:
+                c_all = run(threads, "libdeflate_deflate:%d" % level)
+                c_one = run(1, "libdeflate_deflate:%d" % level)
+                hook = run(threads, None, "libdeflate%d" % level) if block <= 0xff00 else None
+                out["python_threads"] = {"all_cores": out["value"], "one_core": out["one_core"]}
+                if c_all:
+                    out["value"], out["one_core"] = round(c_all, 4), round(c_one or 0, 4)
+                    out["sample"] = ("libdeflate 1.23 via libdeflate_deflate (lib/zlibutil.c:179), one call per %d-byte block of "
+                                     "the same workload from %d pthreads for 2 s (tools/hook_bench.c against oracle/_ref/libref.so)"
+                                     % (block, threads))
+                if hook:
+                    out["reference_hook"] = {"all_cores": round(hook, 4), "what": "bgzf_compress (bgzf_compress.c:39) with "
+                                             "BGZF_METHOD=libdeflate%d from %d pthreads: codec + CRC-32 + framing per call" % (level, threads)}
+            except Exception as ex:
+                out["c_harness_error"] = "%s: %s" % (type(ex).__name__, ex)
     if mode == "encode":
         if have_ref:
             one, allc, _, _ = measure(reused_work, 0.3)

@@ -2,13 +2,19 @@
  * hook_bench.c -- throughput of the LD_PRELOAD hook as htslib drives it: T threads, each calling
  * bgzf_compress() (bgzf_compress.c:39) on one 0xff00-byte block at a time and waiting for the member.
  *
- *   hook_bench <input file> [threads=8] [seconds=2] [block=65280]
+ *   hook_bench <input file> [threads=8] [seconds=2] [block=65280] [codec:level]
+ *
+ * With a fifth argument the threads call that zlibutil codec (lib/zlibutil.h:47, e.g. libdeflate_deflate:1 or
+ * hip_deflate:1, looked up with dlsym) instead of the hook: the per-block function alone, a fresh 1.5 x block
+ * destination per call as zlibutil_buffer_allocate gives it -- bench.py's cpu_baseline runs the reference's
+ * libdeflate_deflate this way, on real pthreads rather than through Python.
  *
  * Links against whatever provides bgzf_compress: libhipdeflate.so (BGZF_METHOD=hip1) or the reference's
  * own hook built from bgzf_compress.c (oracle/_ref/libref.so, BGZF_METHOD=libdeflate1) -- the same binary
  * source measures both sides.  Prints one JSON line.
  */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,6 +27,9 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
 #include "hipdeflate.h"
 #endif
 
+typedef int (*codec_fn)(unsigned char *, size_t *, const unsigned char *, size_t, int);
+static codec_fn g_codec;
+static int g_codec_level = 1;
 static unsigned char *g_data;
 static size_t g_size, g_block = 0xff00;
 static volatile int g_stop;
@@ -43,12 +52,13 @@ static double now(void)
 static void *run(void *arg)
 {
 	struct worker *w = (struct worker *)arg;
-	unsigned char *dst = (unsigned char *)malloc(0x10000);
+	unsigned char *dst = (unsigned char *)malloc(g_block + g_block / 2 + 0x10000);
 	const size_t nblk = g_size / g_block;
 	size_t k = (size_t)w->id * 7919u % nblk;
 	while (!g_stop) {
-		size_t dlen = 0x10000;
-		int r = bgzf_compress(dst, &dlen, g_data + k * g_block, g_block, -1);
+		size_t dlen = g_codec ? g_block + g_block / 2 : 0x10000;
+		int r = g_codec ? g_codec(dst, &dlen, g_data + k * g_block, g_block, g_codec_level)
+				: bgzf_compress(dst, &dlen, g_data + k * g_block, g_block, -1);
 		if (r) {
 			w->err = r;
 			break;
@@ -73,6 +83,22 @@ int main(int argc, char **argv)
 		g_secs = atof(argv[3]);
 	if (argc > 4)
 		g_block = (size_t)atol(argv[4]);
+	const char *codec_name = "";
+	if (argc > 5) {
+		char name[128];
+		snprintf(name, sizeof(name), "%s", argv[5]);
+		char *c = strchr(name, ':');
+		if (c) {
+			*c = 0;
+			g_codec_level = atoi(c + 1);
+		}
+		g_codec = (codec_fn)dlsym(RTLD_DEFAULT, name);
+		if (!g_codec) {
+			fprintf(stderr, "no such codec: %s\n", name);
+			return 2;
+		}
+		codec_name = argv[5];
+	}
 	FILE *f = fopen(argv[1], "rb");
 	if (!f) {
 		perror(argv[1]);
@@ -115,9 +141,9 @@ int main(int argc, char **argv)
 #endif
 	/* warm-up: first call initialises the device, pins memory ... */
 	{
-		unsigned char *dst = (unsigned char *)malloc(0x10000);
-		size_t dlen = 0x10000;
-		int r = bgzf_compress(dst, &dlen, g_data, g_block, -1);
+		unsigned char *dst = (unsigned char *)malloc(g_block + g_block / 2 + 0x10000);
+		size_t dlen = g_codec ? g_block + g_block / 2 : 0x10000;
+		int r = g_codec ? g_codec(dst, &dlen, g_data, g_block, g_codec_level) : bgzf_compress(dst, &dlen, g_data, g_block, -1);
 		if (r) {
 			fprintf(stderr, "bgzf_compress failed: %d\n", r);
 			return 1;
@@ -145,6 +171,8 @@ int main(int argc, char **argv)
 	}
 	const double el = now() - t0;
 	const char *m = getenv("BGZF_METHOD");
+	if (g_codec)
+		m = codec_name;
 	printf("{\"threads\": %d, \"method\": \"%s\", \"block\": %zu, \"seconds\": %.3f, \"calls\": %llu, \"GBps_in\": %.4f, "
 	       "\"ratio\": %.4f, \"us_per_call\": %.1f, \"error\": %d}\n",
 	       T, m ? m : "", g_block, el, (unsigned long long)calls, in / el / 1e9, in ? (double)out / in : 0.0,
