@@ -522,20 +522,43 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			return true;
 		}
 
-		// ---- 4. long matches first, then the greedy resolution as a wave prefix scan -----
-		// Matches whose first 8 bytes all agree ("capped") may be longer than the lanes can tell.  They are taken
-		// left to right from the carry, each extended cooperatively (64 bytes per ballot) and the next looked for
-		// behind it; the ones that come out longer than 8 are BARRIERS: a token starts there whatever stands before,
-		// the lanes they cover are out of the game, and a match in front of one is clipped to end at it (dropped
-		// when that leaves it below the level's minimum).  All of that is settled in scalar code BEFORE the scan,
-		// which then needs no repair (round 1 extended after the scan and re-threaded the token chain behind every
-		// long match with a scalar walk: ~60 scalar instructions per long match, the bound of the text levels).
+		// ---- 4. greedy resolution as a wave prefix scan ---------------------
+		// The greedy parse is a little automaton walking the lanes: its state
+		// r = "lanes still covered by the current match"; a lane with r == 0
+		// starts a token and sets r = len - 1 (0 for a literal), otherwise
+		// r -= 1.  Each lane's transition f_l : {0..7} -> {0..7} is eight bytes;
+		// composing two of them is two v_perm_b32 table lookups, so the state
+		// entering every lane comes out of a 6-stage DPP scan -- no per-match
+		// serial loop (DNA-like data has ~12 matches per 64 bytes).  Matches
+		// whose first 8 bytes all agree ("capped") are rare; when the scan
+		// takes one it is extended cooperatively and the scan is redone for
+		// the lanes behind it.
 		const uint64_t capmask = INNER ? (okm & xm) : (okm & xm & __ballot(room > 8));
+		const uint32_t jump8 = sel(okm, mylen, 1u);                  // token length as the scan sees it
+		uint32_t lenv = jump8;                                       // ... and with capped matches extended
 		const uint64_t livem = ~0ull << carry;                       // lanes the last match does not cover (carry < 64)
-		uint32_t jump8 = sel(okm, mylen, 1u);                        // token length as the scan sees it (<= 8)
-		uint32_t lenv = jump8;                                       // ... and the real one
-		uint64_t barrier = 0, dead = 0;
-		for (uint64_t cm = capmask & livem; cm;) {
+		// (token words are prepared here, ahead of the scan: independent work for the wait states between its
+		// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
+		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
+		const uint32_t lit = cv0 & 0xff;
+		uint64_t starts;
+		{
+			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on covered lanes
+			Fn8 f;
+			f.lo = sel(livem, jump8 + 0x0200ffffu, 0x03020100u);
+			f.hi = sel(livem, 0x06050403u, 0x07060504u);
+			const Fn8 w = fn8_scan(f, fid);
+			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1 (0 enters lane 0)
+			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+			starts = __ballot((sin & 0xff) == 0) & livem;
+		}
+		// Capped matches the scan took: extend each (left to right) to its true
+		// length, drop the token starts it now covers, and re-thread the chain
+		// behind it.  Two parses that start a token on the same lane coincide
+		// from there on, so the walk stops at the first old start it lands on
+		// (a few hops) instead of re-scanning the wave.
+		uint64_t cm = starts & capmask;
+		while (cm) {
 			const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
 			const uint32_t pm = S + m;
 			const uint32_t dm = pm + 1 - readlane(c, m);
@@ -544,53 +567,29 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			for (;;) {
 				// (every index is masked into the ring, so lanes past maxlen may read too)
 				const uint32_t idx = len + lane;
-				const uint64_t past = maxlen - len >= 64 ? 0ull : ~0ull << (maxlen - len);   // lanes with idx >= maxlen
-				const uint64_t nq = __ballot(ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]) | past;
+				const bool diff = (idx >= maxlen) |
+						  (ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]);
+				const uint64_t nq = __ballot(diff);
 				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
 				len += k;
 				if (k < 64)
 					break;
 			}
-			const uint64_t behind_m = ~1ull << m;                  // lanes > m
+			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
 			if (len > 8) {
-				const uint32_t end = m + len;                     // first lane behind the match
-				const uint64_t from_end = end >= 64 ? 0ull : ~0ull << end;
 				lenv = lane == m ? len : lenv;
-				barrier |= 1ull << m;
-				dead |= behind_m & ~from_end;
-				cm &= from_end;
-			} else {
-				cm &= behind_m;                                   // exactly eight: an ordinary token
+				const uint32_t q = m + len;                   // first lane behind the match
+				uint64_t fresh = 0;
+				uint32_t xq = q;
+				while (xq < 64 && !((starts >> xq) & 1)) {
+					fresh |= 1ull << xq;
+					xq += readlane(jump8, xq);
+				}
+				const uint64_t below_x = xq >= 64 ? ~0ull : ((1ull << xq) - 1);
+				starts = (starts & (upto_m | ~below_x)) | fresh;
 			}
+			cm = starts & capmask & ~upto_m;
 		}
-		if (barrier) {
-			// distance to the next barrier, as far as a token can reach (8 lanes): bits lane+1 .. lane+8 of the mask
-			const uint32_t blo = (uint32_t)barrier, bhi = (uint32_t)(barrier >> 32);
-			const uint32_t w8 = (lane < 31 ? __builtin_amdgcn_alignbit(bhi, blo, (lane + 1) & 31)
-						       : __builtin_amdgcn_alignbit(0u, bhi, (lane + 1) & 31)) & 0xffu;
-			const uint32_t reach = (uint32_t)__builtin_ctz(w8 | 0x100u) + 1;     // 1..8: lanes up to the barrier; 9: none
-			const uint32_t clipped = jump8 < reach ? jump8 : reach;
-			// a clipped match below the minimum is dropped (its lanes are literals or matches of their own)
-			okm &= ~__ballot(clipped < (uint32_t)MINLEN) | barrier;
-			jump8 = sel(barrier, 8u, sel(okm, clipped, 1u));
-			lenv = sel(barrier, lenv, jump8);
-		}
-		const uint64_t scanm = livem & ~dead;                        // lanes that take part in the parse
-		uint64_t starts;
-		{
-			// (token words are prepared here, ahead of the scan: independent work for the wait states between its
-			// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
-			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on lanes out of the parse
-			Fn8 f;
-			f.lo = sel(scanm, jump8 + 0x0200ffffu, 0x03020100u);
-			f.hi = sel(scanm, 0x06050403u, 0x07060504u);
-			const Fn8 w = fn8_scan(f, fid);
-			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1 (0 enters lane 0)
-			const uint32_t sin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-			starts = __ballot((sin & 0xff) == 0) & scanm;
-		}
-		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
-		const uint32_t lit = cv0 & 0xff;
 		// coverage behind the last token of the step
 		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
 		const uint32_t E = last + readlane(lenv, last);

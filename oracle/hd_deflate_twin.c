@@ -214,50 +214,15 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 			if (defer[l])
 				ok[l] = 0;
 	}
-	/* 4. Long matches first.  The candidates whose eight bytes all agree (and that have room for more) are taken left to
-	 * right from the carry -- each is extended to its true length and the next is looked for behind it --; the ones that
-	 * come out longer than 8 are BARRIERS: a token always starts there.  Then the greedy walk over everything else, a
-	 * match in front of a barrier clipped to end at it, or dropped (literals) when that leaves it shorter than the level's
-	 * minimum.  (The kernel resolves the barriers in scalar code BEFORE its automaton scan, so that the scan needs no
-	 * repair afterwards; round 1 extended the long matches after the scan and re-threaded the token chain behind each.) */
-	unsigned E = carry;
-	uint8_t barrier[HD_WAVE] = { 0 }, dead[HD_WAVE] = { 0 };
-	uint16_t lenx[HD_WAVE];
-	for (unsigned l = carry, pos = carry; l < lanes; l++) {
-		size_t p = S + l;
-		if (l < pos || !ok[l] || cap8[l] != 8 || n - p <= 8)
+	unsigned E = carry;                             /* 4. greedy */
+	for (unsigned l = 0; l < lanes; l++) {
+		if (l < E || !ok[l])
 			continue;
+		size_t p = S + l;
 		unsigned maxlen = n - p < HD_MAX_MATCH ? (unsigned)(n - p) : HD_MAX_MATCH;
-		unsigned len = 8;
+		unsigned len = HD_MIN_MATCH;
 		while (len < maxlen && in[p + len] == in[p + len - st->dist[l]])
 			len++;
-		if (len <= 8)
-			continue;                       /* exactly eight: an ordinary token */
-		barrier[l] = 1;
-		lenx[l] = (uint16_t)len;
-		for (unsigned k = l + 1; k < l + len && k < lanes; k++)
-			dead[k] = 1;
-		pos = l + len;
-	}
-	for (unsigned l = 0; l < lanes; l++) {
-		if (l < E || dead[l])
-			continue;
-		if (barrier[l]) {
-			st->is_match[l] = 1;
-			st->len[l] = lenx[l];
-			E = l + lenx[l];
-			continue;
-		}
-		if (!ok[l])
-			continue;
-		unsigned len = cap8[l];
-		for (unsigned k = l + 1; k < l + len && k < lanes; k++)
-			if (barrier[k]) {
-				len = k - l;                /* clipped: ends in front of the barrier */
-				break;
-			}
-		if (len < minlen)
-			continue;
 		st->is_match[l] = 1;
 		st->len[l] = (uint16_t)len;
 		E = l + len;
