@@ -567,9 +567,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			for (;;) {
 				// (every index is masked into the ring, so lanes past maxlen may read too)
 				const uint32_t idx = len + lane;
-				const bool diff = (idx >= maxlen) |
-						  (ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]);
-				const uint64_t nq = __ballot(diff);
+				const uint64_t past = maxlen - len >= 64 ? 0ull : ~0ull << (maxlen - len);   // lanes with idx >= maxlen
+				const uint64_t nq = __ballot(ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]) | past;
 				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
 				len += k;
 				if (k < 64)
