@@ -154,6 +154,53 @@ def gen_ref_streams(ref):
     print("ref_streams.json:", len(out), "streams,", sum(len(o["stream"]) for o in out) * 3 // 4, "bytes")
 
 
+FULL_INPUTS = [("fastq", 101), ("fastq", 102), ("text", 103), ("text", 104), ("mixed", 105)]
+FULL_ENCODERS = [("libdeflate", 1), ("libdeflate", 6), ("libdeflate", 9), ("libdeflate", 12), ("zlib", 1), ("zlib", 6),
+                 ("zlib", 9), ("slz", 1), ("miniz", 1)]
+
+
+def full_input(kind, seed):
+    """the 0xff00-byte inputs of ref_streams_full.json: regenerated from (kind, seed) by the tests, not stored"""
+    s = hdtest.synth()
+    if kind == "fastq":
+        return bytes(s.fastq_like(0xff00, seed=seed))
+    if kind == "text":
+        return bytes(s.text_like(0xff00, seed=seed))
+    # mixed: text, a far repeat of it (32 KiB-class distances), DNA-like, noise, zeros
+    t = bytes(s.text_like(20000, seed=seed))
+    return (t + bytes(s.fastq_like(14000, seed=seed + 1)) + t[:12000] + bytes(s.random_bytes(6000, seed=seed + 2)) +
+            bytes(3000) + t[5000:])[:0xff00].ljust(0xff00, b"x")
+
+
+def gen_ref_streams_full(ref):
+    """BASELINE config 3's shape: FULL 0xff00-byte blocks through every reference encoder that the decode path
+    will meet (32 KiB-distance copies, 15-bit codes, multi-block members from the 8,192-sequence cap).  Only the
+    STREAM and the SHA-256 of its inflation are stored; plus one 1 MiB MiGz member made by the real `7migz -l6
+    -b1024` (oracle/_ref/cielbox_ref)."""
+    import subprocess
+    import tempfile
+    out = []
+    for kind, seed in FULL_INPUTS:
+        data = full_input(kind, seed)
+        for name, level in FULL_ENCODERS:
+            z = ref_encode(ref, name, level, data)
+            r, o = hdtest.call_dec(ref.libdeflate_inflate, z, len(data))
+            assert r == 0 and o == data
+            out.append({"kind": kind, "seed": seed, "encoder": name, "level": level, "stream": b64(z),
+                        "out_len": len(data), "out_sha256": hdtest.sha(data)})
+    box = os.path.join(ROOT, "oracle", "_ref", "cielbox_ref")
+    text = bytes(hdtest.synth().text_like(1 << 20, seed=106))
+    p = subprocess.run([box, "7migz", "-l6", "-b1024"], input=text, capture_output=True, check=True)
+    m = p.stdout
+    assert m[:4] == b"\x1f\x8b\x08\x04" and m[12:16] == b"MZ\x04\x00"
+    paylen = int.from_bytes(m[16:20], "little")
+    assert 20 + paylen + 8 == len(m)
+    out.append({"kind": "migz_text_1mib", "seed": 106, "encoder": "7migz(libdeflate)", "level": 6, "stream": b64(m[20:20 + paylen]),
+                "member_header": m[:20].hex(), "member_trailer": m[-8:].hex(), "out_len": len(text), "out_sha256": hdtest.sha(text)})
+    json.dump(out, open(os.path.join(HERE, "ref_streams_full.json"), "w"), indent=0)
+    print("ref_streams_full.json:", len(out), "streams,", sum(len(o["stream"]) for o in out) * 3 // 4, "bytes")
+
+
 def gen_mutants(ref):
     rng = np.random.default_rng(2025)
     s = hdtest.synth()
@@ -310,6 +357,7 @@ def main():
     assert ref is not None, "build the reference first: make -C oracle ref"
     gen_std_vects(ref)
     gen_ref_streams(ref)
+    gen_ref_streams_full(ref)
     gen_mutants(ref)
     gen_boundary(ref)
     gen_full_flush(ref)

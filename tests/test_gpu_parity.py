@@ -446,6 +446,24 @@ def test_inflate_reference_streams_bit_exact(pkg):
             assert r == 3
 
 
+def test_inflate_full_size_reference_streams_bit_exact(pkg):
+    """tests/golden/ref_streams_full.json (45 full 0xff00-byte blocks through 9 reference encoders + a 1 MiB member of
+    the real 7migz): every stream in one batch, output by SHA-256, CRC-32 against the member trailer where there is one."""
+    streams = load("ref_streams_full.json")
+    zs = [base64.b64decode(s["stream"]) + b"\x55" * 8 for s in streams]
+    caps = [s["out_len"] for s in streams]
+    outs, crc, st = pkg.batch_inflate(zs, caps)
+    for i, s in enumerate(streams):
+        assert st[i] == 0, (s["kind"], s["encoder"], s["level"], int(st[i]))
+        assert len(outs[i]) == s["out_len"] and hdtest.sha(outs[i]) == s["out_sha256"], (s["kind"], s["encoder"], s["level"])
+        assert int(crc[i]) == zlib.crc32(outs[i])
+        if "member_trailer" in s:
+            assert int(crc[i]) == int.from_bytes(bytes.fromhex(s["member_trailer"])[:4], "little")
+    # one byte of room less: INSUFFICIENT_SPACE, as libdeflate_inflate
+    outs, crc, st = pkg.batch_inflate(zs[:9], [c - 1 for c in caps[:9]])
+    assert all(int(x) == 3 for x in st)
+
+
 def test_inflate_malformed_vectors_rejected(pkg):
     vects = load("inflate_std_vects.json")
     zs = [base64.b64decode(v["data"]) for v in vects]

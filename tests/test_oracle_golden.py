@@ -47,6 +47,27 @@ def test_ref_streams_inflate_bit_exact():
     assert kinds == {0, 1, 2}  # stored, static and dynamic first blocks all present
 
 
+def test_ref_streams_full_size_inflate_bit_exact():
+    """46 streams at BASELINE config 3's size: FULL 0xff00-byte FASTQ-like / text / mixed blocks through libdeflate
+    1/6/9/12, zlib 1/6/9, slz and miniz, and a 1 MiB member of the real `7migz -l6 -b1024` -- 32 KiB-class distances,
+    multi-block members, the encoders' longest codes.  The inputs are regenerated from (kind, seed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    streams = load("ref_streams_full.json")
+    assert len(streams) >= 46
+    far = 0
+    for s in streams:
+        z = base64.b64decode(s["stream"])
+        r, out = hdtest.oracle_inflate(z + bytes(8), s["out_len"])
+        assert r == 0 and len(out) == s["out_len"] and hdtest.sha(out) == s["out_sha256"], (s["kind"], s["encoder"], s["level"])
+        if s["kind"] != "migz_text_1mib":
+            assert out == mg.full_input(s["kind"], s["seed"])
+        far += s["kind"] == "mixed"
+    assert far >= 9
+
+
 def test_ref_streams_capacity_semantics():
     """libdeflate_inflate (lib/zlibutil.c:194-204): capacity larger than the data is
     fine (actual size returned); capacity one byte short is INSUFFICIENT_SPACE (3)."""
