@@ -225,7 +225,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 			break;
 		}
 		int k;
-		for (k = 0; k < HOOK_CTX && g_batch[k].state != 0; k++)
+		for (k = 0; k < HOOK_CTX && __atomic_load_n(&g_batch[k].state, __ATOMIC_ACQUIRE) != 0; k++)
 			;
 		if (k < HOOK_CTX) {
 			b = &g_batch[k];
@@ -239,7 +239,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 				pthread_mutex_init(&b->mu, NULL);
 				pthread_cond_init(&b->cv, NULL);
 			}
-			b->n = 0;
+			__atomic_store_n(&b->n, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->ready, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->taken, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->state, 1, __ATOMIC_RELEASE);
@@ -248,7 +248,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		}
 		pthread_cond_wait(&g_cv_free, &g_mu);   /* every context is busy: wait for one to drain */
 	}
-	const int idx = b->n++;
+	const int idx = __atomic_fetch_add(&b->n, 1, __ATOMIC_RELAXED);     /* (written under g_mu; the leader's window loop reads it without) */
 	const int leader = idx == 0;
 	b->len[idx] = (uint32_t)slen;
 	/* Everybody who could join has: the callers inside the hook that are not in a batch on the device are all here
@@ -291,7 +291,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 			}
 		}
 		pthread_mutex_lock(&g_mu);
-		if (b->state == 1) {                        /* window over */
+		if (__atomic_load_n(&b->state, __ATOMIC_RELAXED) == 1) {          /* window over */
 			__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
 			g_running += b->n;
 			g_open = -1;

@@ -6,25 +6,29 @@
  * (:379-405); the argument is returned so the function can be a pthread start
  * routine (applet/7bgzf.c:211).
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 #include "zlibutil_hip.h"
 
 static unsigned int crc_table[256];
-static int crc_ready;
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
+
+static void crc_init(void)
+{
+	for (unsigned int i = 0; i < 256; i++) {
+		unsigned int c = i;
+		for (int k = 0; k < 8; k++)
+			c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+		crc_table[i] = c;
+	}
+}
 
 unsigned int hd_crc32(unsigned int crc, const unsigned char *buf, size_t len)
 {
-	if (!crc_ready) {
-		for (unsigned int i = 0; i < 256; i++) {
-			unsigned int c = i;
-			for (int k = 0; k < 8; k++)
-				c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-			crc_table[i] = c;
-		}
-		__atomic_store_n(&crc_ready, 1, __ATOMIC_RELEASE);
-	}
+	/* (threads of the caller arrive here together, applet/7bgzf.c:211: a plain "ready" flag raced under TSan) */
+	pthread_once(&crc_once, crc_init);
 	crc = ~crc;
 	while (len--)
 		crc = crc_table[(crc ^ *buf++) & 0xff] ^ (crc >> 8);
