@@ -28,7 +28,7 @@ using hd::CrcTables;
 		if (e_ != hipSuccess) {                                                        \
 			fprintf(stderr, "hipdeflate: %s failed: %s (%s:%d)\n", #expr,          \
 				hipGetErrorString(e_), __FILE__, __LINE__);                    \
-			return HD_E_NODEVICE;                                                  \
+			return e_ == hipErrorOutOfMemory ? HD_E_NOMEM : HD_E_NODEVICE;         \
 		}                                                                              \
 	} while (0)
 
@@ -40,7 +40,7 @@ struct Buf {
 	{
 		if (n <= cap)
 			return 0;
-		release();
+		free_current();
 		size_t want = n + n / 4 + 4096;
 		hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
 		if (e != hipSuccess) {
@@ -53,12 +53,34 @@ struct Buf {
 		cap = want;
 		return 0;
 	}
-	void release()
+	void free_current()
 	{
 		if (p)
 			(void)(pinned ? hipHostFree(p) : hipFree(p));
 		p = nullptr;
 		cap = 0;
+	}
+	void release()
+	{
+		free_current();
+		for (void *q : retired)
+			(void)(pinned ? hipHostFree(q) : hipFree(q));
+		retired.clear();
+	}
+	// grow while launches on other streams may still use the old allocation: it is kept until release() instead of
+	// being freed behind a device-wide synchronisation (a grow-only buffer retires a handful of allocations at most)
+	std::vector<void *> retired;
+	int grow_keep_old(size_t n)
+	{
+		if (n <= cap)
+			return 0;
+		void *old = p;
+		p = nullptr;
+		cap = 0;
+		const int r = reserve(n);
+		if (old)
+			retired.push_back(old);
+		return r;
 	}
 };
 
@@ -367,12 +389,9 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	if (need) {
 		// token slabs of the dynamic levels, segment slots of large blocks: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);
-		if (g.d_tok.cap < need) {
-			// a re-allocation must not pull the rug from under launches in flight
-			HD_CHECK(hipDeviceSynchronize());
-			if (g.d_tok.reserve(need))
-				return HD_E_NOMEM;
-		}
+		// (a re-allocation must not pull the rug from under launches in flight: the old scratch stays alive)
+		if (g.d_tok.grow_keep_old(need))
+			return HD_E_NOMEM;
 		a.scratch = (uint8_t *)g.d_tok.p;
 		// the slabs are shared by every launch: launches on different streams take turns
 		if (!g.ev_tok)
@@ -448,11 +467,8 @@ int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t ba
 	const uint32_t ntiles = (nblocks + hd::SCAN_TILE - 1) / hd::SCAN_TILE;
 	// the tile buffer is one for the whole library: scans on different streams take turns
 	std::lock_guard<std::mutex> lk(g.mu_dev);
-	if (g.d_tiles.cap < (size_t)ntiles * 8) {
-		HD_CHECK(hipDeviceSynchronize());
-		if (g.d_tiles.reserve((size_t)ntiles * 8))
-			return HD_E_NOMEM;
-	}
+	if (g.d_tiles.grow_keep_old((size_t)ntiles * 8))
+		return HD_E_NOMEM;
 	uint64_t *tiles = (uint64_t *)g.d_tiles.p;
 	hipStream_t st = (hipStream_t)stream;
 	if (!g.ev_tiles)
