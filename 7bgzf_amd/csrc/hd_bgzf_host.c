@@ -9,6 +9,7 @@
  *     hd7bgzf -d  < in.bgz > out
  *     hd7bgzf -M -b1024 -G6 < in > out.migz    (MiGz framing, block = b KiB)
  *     hd7bgzf -G1 --index out.bgz.gzi < in > out.bgz     (+ bgzip's .gzi block index)
+ *     hd7bgzf -G1 -@8 -i in -o out.bgz                    (file to file: N threads pread / pwrite, batches of 8192 blocks)
  *
  * What changed, and why: the reference reads one <=64 KiB block, compresses it on
  * a fresh pthread and writes it (applet/7bgzf.c:159-277); a GPU needs thousands
@@ -21,12 +22,15 @@
  * single-thread 0x10000 + shrink-by-1024 retry (:256-262) is not needed because
  * the kernel falls back to stored blocks, which always fit.
  */
+#define _GNU_SOURCE
 #include <errno.h>
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 #include "hipdeflate.h"
@@ -203,6 +207,207 @@ static int do_compress(int level)
 	fprintf(stderr, "%d done.\n", total_blocks);
 	return 0;
 }
+
+/* ---- file to file: -i IN -o OUT [-@ N] ------------------------------------------------------------------------
+ * The stdin/stdout filter above moves ~5 GB/s: one thread read()s, and pinning 32 MiB buffers is paid per run.  With
+ * both ends seekable the host side scales: N worker threads pread() disjoint 8 MiB ranges of a batch straight into
+ * the pipe's pinned input (page cache -> pinned memory at memcpy speed on every thread), batches are up to 8192
+ * blocks so that the device is full, and the finished run of members is pwrite()n by the same workers in disjoint
+ * ranges at the offset the batches before it ended (the device's size scan).  Role of the read / code / write loop
+ * of applet/7bgzf.c:159-293 with its -@ threads, minus the thread per block. */
+struct io_task {
+	int fd, wr;
+	unsigned char *buf;
+	size_t len;
+	off_t off;
+};
+/* two channels with their own workers, so that reading batch k + 1 and writing batch k - 1 overlap: 0 = pread, 1 = pwrite */
+static struct io_chan {
+	struct io_task task[256];
+	int n, next, done, err, stop;
+	pthread_mutex_t mu;
+	pthread_cond_t cv, done_cv;
+} g_io[2] = { { .mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER, .done_cv = PTHREAD_COND_INITIALIZER },
+	      { .mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER, .done_cv = PTHREAD_COND_INITIALIZER } };
+
+static void *io_worker(void *arg)
+{
+	struct io_chan *c = (struct io_chan *)arg;
+	pthread_mutex_lock(&c->mu);
+	for (;;) {
+		while (!c->stop && c->next >= c->n)
+			pthread_cond_wait(&c->cv, &c->mu);
+		if (c->stop)
+			break;
+		const struct io_task t = c->task[c->next++];
+		pthread_mutex_unlock(&c->mu);
+		int err = 0;
+		for (size_t done = 0; done < t.len && !err;) {
+			const ssize_t r = t.wr ? pwrite(t.fd, t.buf + done, t.len - done, t.off + (off_t)done)
+					       : pread(t.fd, t.buf + done, t.len - done, t.off + (off_t)done);
+			if (r < 0 && errno == EINTR)
+				continue;
+			if (r <= 0)
+				err = 1;
+			else
+				done += (size_t)r;
+		}
+		pthread_mutex_lock(&c->mu);
+		c->err |= err;
+		if (++c->done == c->n)
+			pthread_cond_broadcast(&c->done_cv);
+	}
+	pthread_mutex_unlock(&c->mu);
+	return NULL;
+}
+
+/* move [off, off + len) between the file and buf in parallel pieces (one caller per channel) */
+static int io_parallel(int fd, int wr, unsigned char *buf, size_t len, off_t off)
+{
+	struct io_chan *c = &g_io[wr];
+	size_t piece = (size_t)8 << 20;
+	if (len / piece >= 256)
+		piece = (len / 255 + 4095) & ~(size_t)4095;
+	pthread_mutex_lock(&c->mu);
+	c->n = 0;
+	for (size_t o = 0; o < len; o += piece) {
+		struct io_task *t = &c->task[c->n++];
+		t->fd = fd;
+		t->wr = wr;
+		t->buf = buf + o;
+		t->off = off + (off_t)o;
+		t->len = len - o < piece ? len - o : piece;
+	}
+	c->next = c->done = c->err = 0;
+	pthread_cond_broadcast(&c->cv);
+	while (c->n && c->done < c->n)
+		pthread_cond_wait(&c->done_cv, &c->mu);
+	const int err = c->err;
+	c->n = c->next = 0;
+	pthread_mutex_unlock(&c->mu);
+	return err;
+}
+
+static int g_fd_in = -1, g_fd_out = -1;
+static off_t g_in_size;
+
+static void *file_reader_main(void *arg)
+{
+	(void)arg;
+	for (off_t pos = 0;;) {
+		size_t cap = 0;
+		unsigned char *buf = hipdeflate_pipe_input(g_pipe, &cap);
+		int err = buf == NULL;
+		const size_t got = (off_t)cap < g_in_size - pos ? cap : (size_t)(g_in_size - pos);
+		if (!err && got && io_parallel(g_fd_in, 0, buf, got, pos))
+			err = 2;
+		pos += (off_t)got;
+		if (!err && hipdeflate_pipe_submit(g_pipe, got))
+			err = 1;
+		const int last = err || pos >= g_in_size;
+		pthread_mutex_lock(&mu);
+		if (err)
+			g_reader_err = err;
+		else
+			g_submitted++;
+		if (last)
+			g_reader_done = 1;
+		pthread_cond_broadcast(&cv);
+		pthread_mutex_unlock(&mu);
+		if (last)
+			return NULL;
+	}
+}
+
+static int do_compress_files(int level, int nthreads)
+{
+	const size_t nblocks = (size_t)((g_in_size + (off_t)g_block - 1) / (off_t)g_block);
+	/* batches as large as the device likes them (8192 blocks), smaller for small files so that three are in flight */
+	size_t per = nblocks / 3 + 1;
+	if (per > 8192)
+		per = 8192;
+	if (g_frame == HD_FRAME_MIGZ && per * g_block > ((size_t)512 << 20))
+		per = ((size_t)512 << 20) / g_block;
+	if (per < 64)
+		per = 64;
+	g_pipe = hipdeflate_pipe_open(level, g_frame, (uint32_t)g_block, (uint32_t)per, 3);
+	if (!g_pipe) {
+		fprintf(stderr, "hip_deflate: cannot open the device pipeline\n");
+		return 1;
+	}
+	/* -@ N: N readers and N / 2 writers (the output is a fraction of the input) */
+	const int nwr = nthreads / 2 ? nthreads / 2 : 1;
+	pthread_t *io = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)(nthreads + nwr));
+	for (int i = 0; i < nthreads + nwr; i++)
+		pthread_create(&io[i], NULL, io_worker, &g_io[i >= nthreads]);
+	pthread_t rd;
+	pthread_create(&rd, NULL, file_reader_main, NULL);
+	int total_blocks = 0, fetched = 0, ret = 0;
+	off_t written = 0;
+	for (;;) {
+		pthread_mutex_lock(&mu);
+		while (fetched == g_submitted && !g_reader_done)
+			pthread_cond_wait(&cv, &mu);
+		const int more = fetched < g_submitted, err = g_reader_err;
+		pthread_mutex_unlock(&mu);
+		if (!more) {
+			if (err) {
+				fprintf(stderr, err == 2 ? "read error\n" : "hip_deflate: submit failed\n");
+				ret = 1;
+			}
+			break;
+		}
+		const uint8_t *data;
+		size_t nbytes;
+		uint32_t nb;
+		const int r = hipdeflate_pipe_result(g_pipe, &data, &nbytes, &nb);
+		if (r) {
+			fprintf(stderr, "hip_deflate %d\n", r);
+			ret = 1;
+			break;
+		}
+		fetched++;
+		if (g_index_path) {
+			const uint64_t *doff;
+			if (hipdeflate_pipe_members(g_pipe, NULL, &doff, NULL)) {
+				ret = 1;
+				break;
+			}
+			for (uint32_t i = 0; i < nb; i++)
+				if (total_blocks + (int)i > 0)
+					index_add((uint64_t)written + doff[i], (uint64_t)(total_blocks + (int)i) * g_block);
+		}
+		if (nbytes && io_parallel(g_fd_out, 1, (unsigned char *)(uintptr_t)data, nbytes, written)) {
+			fprintf(stderr, "write error\n");
+			ret = 1;
+			break;
+		}
+		written += (off_t)nbytes;
+		total_blocks += (int)nb;
+	}
+	if (ret)
+		_exit(1);
+	pthread_join(rd, NULL);
+	for (int k = 0; k < 2; k++) {
+		pthread_mutex_lock(&g_io[k].mu);
+		g_io[k].stop = 1;
+		pthread_cond_broadcast(&g_io[k].cv);
+		pthread_mutex_unlock(&g_io[k].mu);
+	}
+	for (int i = 0; i < nthreads + nwr; i++)
+		pthread_join(io[i], NULL);
+	free(io);
+	hipdeflate_pipe_close(g_pipe);
+	if (g_frame == HD_FRAME_BGZF && pwrite(g_fd_out, eof_member, 28, written) != 28)        /* applet/7bgzf.c:283-289 */
+		return 1;
+	if (g_index_path && index_write()) {
+		fprintf(stderr, "cannot write %s\n", g_index_path);
+		return 1;
+	}
+	fprintf(stderr, "%d done.\n", total_blocks);
+	return 0;
+}
+
 
 /* header walk of _read_gz_header (applet/7bgzf.c:81-131): FLG / XLEN / FNAME / FCOMMENT / FHCRC, then the
  * member length from the extra field -- BC (BGZF, u16 + 1), MZ (MiGz, payload u32 + header + 8), IG v1
@@ -404,7 +609,8 @@ static int do_decompress(void)
 
 int main(int argc, char **argv)
 {
-	int level = -1, decode = 0, bsize = 512;
+	int level = -1, decode = 0, bsize = 512, nthreads = 8;
+	const char *in_path = NULL, *out_path = NULL;
 	for (int i = 1; i < argc; i++) {
 		const char *a = argv[i];
 		if (!strcmp(a, "-d") || !strcmp(a, "--decompress"))
@@ -419,7 +625,13 @@ int main(int argc, char **argv)
 			bsize = atoi(a + 2);
 		else if (!strcmp(a, "--index") && i + 1 < argc)
 			g_index_path = argv[++i];
-		else if (!strcmp(a, "-c") || !strncmp(a, "-@", 2))
+		else if (!strcmp(a, "-i") && i + 1 < argc)
+			in_path = argv[++i];
+		else if (!strcmp(a, "-o") && i + 1 < argc)
+			out_path = argv[++i];
+		else if (!strncmp(a, "-@", 2))
+			nthreads = a[2] ? atoi(a + 2) : 8;              /* I/O threads of the file-to-file path */
+		else if (!strcmp(a, "-c"))
 			;                                               /* accepted and ignored, as the reference's -c */
 		else {
 			fprintf(stderr, "usage: %s -G<level> < dec.bin > enc.bgz   or   -d < enc.bgz > dec.bin   [-M -b<KiB>]\n",
@@ -441,6 +653,23 @@ int main(int argc, char **argv)
 	int ret;
 	if (decode) {
 		ret = do_decompress();
+	} else if (in_path && out_path) {
+		struct stat sb;
+		g_fd_in = open(in_path, O_RDONLY);
+		g_fd_out = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+		if (g_fd_in < 0 || g_fd_out < 0 || fstat(g_fd_in, &sb)) {
+			fprintf(stderr, "cannot open %s / %s\n", in_path, out_path);
+			return 1;
+		}
+		g_in_size = sb.st_size;
+		if (nthreads < 1)
+			nthreads = 1;
+		if (nthreads > 64)
+			nthreads = 64;
+		fprintf(stderr, "compression level = %d (hip)\n", level);
+		ret = do_compress_files(level, nthreads);
+		close(g_fd_in);
+		close(g_fd_out);
 	} else {
 		fprintf(stderr, "compression level = %d (hip)\n", level);     /* applet/7bgzf.c:502-524 */
 		ret = do_compress(level);

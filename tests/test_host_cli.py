@@ -459,3 +459,17 @@ def test_gzi_index_from_the_device_scan_and_random_access(tmp_path):
     # virtual offset of byte 1000 of block 7: (coffset << 16) | uoffset, as htslib's bgzf_tell
     v = (coff[7] << 16) | 1000
     assert v >> 16 == want[6][0] and v & 0xffff == 1000
+
+
+def test_file_to_file_parallel_io_path(tmp_path):
+    """hd7bgzf -i IN -o OUT -@N: worker threads pread() into the pinned batches and pwrite() the finished runs at the
+    scanned offsets; the file is byte-identical to the stdin/stdout filter's, with the same .gzi."""
+    data = bytes(hdtest.synth().fastq_like(700 * 0xff00 + 99, seed=21))
+    fi, fo, fx = str(tmp_path / "in.bin"), str(tmp_path / "out.bgz"), str(tmp_path / "out.gzi")
+    open(fi, "wb").write(data)
+    p = subprocess.run([EXE, "-G1", "-@6", "-i", fi, "-o", fo, "--index", fx], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    rc, blob, err = run(["-G1", "--index", str(tmp_path / "ref.gzi")], data)
+    assert rc == 0 and open(fo, "rb").read() == blob
+    assert open(fx, "rb").read() == open(str(tmp_path / "ref.gzi"), "rb").read()
+    assert gzip.decompress(blob) == data
