@@ -15,17 +15,24 @@ with open('$D/in.bin','wb') as f:
 "
 ls -la $D/in.bin
 : > $OUT/e2e_files.txt
+tm() { local t0=$(date +%s.%N); "${@:2}"; local t1=$(date +%s.%N); echo "$1: $(python3 -c "print('%.3f s  %.2f GB/s in' % ($t1-$t0, $3/($t1-$t0)/1e9))")" >> $OUT/e2e_files.txt; }
+SZ=$(stat -c %s $D/in.bin)
+run_files() { HD7BGZF_TIMING=1 ./7bgzf_amd/hd7bgzf -G$1 -@$2 -i $D/in.bin -o $D/out.bgz 2>> $OUT/e2e_stderr.txt; }
+run_filter() { ./7bgzf_amd/hd7bgzf -G1 < $D/in.bin > $D/out2.bgz 2>> $OUT/e2e_stderr.txt; }
+run_ref() { ./oracle/_ref/cielbox_ref 7bgzf -l1 -@16 < $D/in1g.bin > $D/ref.bgz 2>> $OUT/e2e_stderr.txt; }
 for T in 4 8 16; do
   for L in 1 6; do
-    /usr/bin/time -f "hd7bgzf -G$L -@$T file-to-file: %e s" ./7bgzf_amd/hd7bgzf -G$L -@$T -i $D/in.bin -o $D/out.bgz 2>> $OUT/e2e_files.txt
-    ls -la $D/out.bgz >> $OUT/e2e_files.txt
+    t0=$(date +%s.%N); run_files $L $T; t1=$(date +%s.%N)
+    python3 -c "print('hd7bgzf -G$L -@$T file-to-file: %.3f s  %.2f GB/s in' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
   done
 done
-/usr/bin/time -f "hd7bgzf -G1 filter (stdin/stdout): %e s" ./7bgzf_amd/hd7bgzf -G1 < $D/in.bin > $D/out2.bgz 2>> $OUT/e2e_files.txt
-cmp $D/out.bgz $D/out2.bgz || true
+t0=$(date +%s.%N); run_filter; t1=$(date +%s.%N)
+python3 -c "print('hd7bgzf -G1 filter (stdin/stdout): %.3f s  %.2f GB/s in' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
+run_files 1 8; cmp $D/out.bgz $D/out2.bgz && echo "file-to-file output == filter output" >> $OUT/e2e_files.txt
 if [ -x oracle/_ref/cielbox_ref ]; then
   head -c $((1<<30)) $D/in.bin > $D/in1g.bin
-  /usr/bin/time -f "reference 7bgzf -l1 -@16 (1 GiB): %e s" ./oracle/_ref/cielbox_ref 7bgzf -l1 -@16 < $D/in1g.bin > $D/ref.bgz 2>> $OUT/e2e_files.txt
+  t0=$(date +%s.%N); run_ref; t1=$(date +%s.%N)
+  python3 -c "print('reference 7bgzf -l1 -@16 (1 GiB): %.3f s  %.2f GB/s in' % ($t1-$t0, (1<<30)/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
 fi
 rm -rf $D
-grep -E " s$|ellapsed" $OUT/e2e_files.txt
+cat $OUT/e2e_files.txt
