@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Static instruction counts of the level-1 kernel's 16-step group loop, per 64-byte step and by phase.
+
+  python3 tools/valu_by_phase.py > profiles/r02_l1_valu_by_phase.json
+
+hipcc -S -gline-tables-only gives every instruction its source line; the lines are mapped to the phases of
+7bgzf_amd/csrc/hd_deflate_static.hpp (fetch / probe / verify / scan / long matches / queue / emit / refill + CRC).
+The loop body holds four unrolled INNER steps; phases that do not run in every step carry their measured frequency
+on the FASTQ-like set (the token queue drains once per ~4.6 steps, the refill runs once per 16)."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "7bgzf_amd", "csrc")
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "hd_api.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                        "-gline-tables-only", "-S", "--cuda-device-only", os.path.join(SRC, "hd_api.hip"), "-o", asm],
+                       check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read().split("\n")
+    files = {}
+    for l in text:
+        m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
+        if m:
+            files[int(m.group(1))] = os.path.basename(m.group(2))
+    a = next(i for i, l in enumerate(text) if l.startswith("_ZN2hd16k_deflate_staticILi12ELi11ELb0"))
+    b = next(i for i in range(a, len(text)) if text[i].startswith(".Lfunc_end"))
+    lines = text[a:b]
+    # the group loop: the first depth-2 loop header of the kernel, up to its back edge
+    h = next(i for i, l in enumerate(lines) if "This Loop Header: Depth=2" in l)
+    start = max(i for i in range(h) if re.match(r"^\.LBB\d+_\d+:", lines[i]))
+    hdr = lines[start].split(":")[0]
+    end = max(i for i in range(start + 1, len(lines)) if re.search(r"s_c?branch\S*\s+" + re.escape(hdr) + r"\b", lines[i]))
+    src = open(os.path.join(SRC, "hd_deflate_static.hpp")).read().split("\n")
+    dev = open(os.path.join(SRC, "hd_device.hpp")).read().split("\n")
+
+    def find(pat, arr):
+        return next(i + 1 for i, l in enumerate(arr) if pat in l)
+    P_FETCH, P_PROBE, P_VERIFY = "fetch: own bytes, hash, table lookup + publish", "probe: candidate bytes", "verify: window, 4 + 8 byte compare, lane masks"
+    P_SCAN, P_LONG = "scan: automaton make, 6-stage fn8 scan, starts", "long matches: cooperative extension + re-threading"
+    P_POST, P_CODES, P_PUT = "post: carry, token words, queue", "emit: static codes of 64 queued tokens", "emit: bit packing into the staging ring"
+    P_PSUM, P_FLUSH, P_FILL = "emit: bit-length prefix sum", "emit: flush of 512 staged bytes", "refill of the ring + CRC fold"
+    P_HAND, P_LOOP = "step: pipeline hand-over", "loop control, step boundary"
+    marks = sorted([(find("auto put = [&]", src), P_PUT), (find("auto flush_ready = [&]", src), P_FLUSH), (find("auto fill_piece = [&]", src), P_FILL),
+                    (find("auto fetch = [&]", src), P_FETCH), (find("auto probe = [&]", src), P_PROBE), (find("auto emit_tokens = [&]", src), P_CODES),
+                    (find("BFINAL = 1 (0 in flush form)", src), P_LOOP), (find("auto step = [&]", src), P_HAND),
+                    (find("---- 3. verify the candidate", src), P_VERIFY), (find("---- 4. greedy resolution", src), P_SCAN),
+                    (find("Capped matches the scan took", src), P_LONG), (find("coverage behind the last token", src), P_POST),
+                    (find("a failed pass -- the stream would pass", src), P_CODES), (find("fetch runs two steps ahead", src), P_LOOP)])
+    dmarks = sorted([(1, None), (find("uint32_t wave_incl_scan(", dev), P_PSUM), (find("struct Fn8 {", dev), P_SCAN),
+                     (find("uint32_t wave_xor_reduce(", dev), None), (find("uint32_t sel(", dev), None),
+                     (find("struct HashConsts", dev), P_FETCH), (find("uint32_t crc_step4(", dev), P_FILL),
+                     (find("RFC 1951 3.2.5 slot arithmetic", dev), P_CODES)])
+
+    def phase(loc, last):
+        f, ln = files.get(loc[0], ""), loc[1]
+        if f == "hd_deflate_static.hpp":
+            ph = P_LOOP
+            for m, name in marks:
+                if ln >= m:
+                    ph = name
+            return ph
+        if f == "hd_device.hpp":
+            ph = None
+            for m, name in dmarks:
+                if ln >= m:
+                    ph = name
+            return ph or last                      # sel(), dpp0(): the caller's phase
+        return last
+    cnt = collections.defaultdict(collections.Counter)
+    loc, last = (0, 0), P_LOOP
+    for i in range(start, end + 1):
+        t = lines[i].strip()
+        m = re.match(r"\.loc\s+(\d+)\s+(\d+)", t)
+        if m:
+            loc = (int(m.group(1)), int(m.group(2)))
+            continue
+        if not t or t[0] in ";." or t.startswith(";;#ASM"):
+            continue
+        op = t.split()[0]
+        kind = ("valu" if op.startswith("v_") else "lds" if op.startswith("ds_") else
+                "vmem" if op.split("_")[0] in ("global", "buffer", "flat") else
+                "branch" if op.startswith("s_cbranch") or op == "s_branch" else
+                "nop_waitcnt" if op.startswith("s_waitcnt") or op == "s_nop" else "salu" if op.startswith("s_") else "other")
+        last = phase(loc, last)
+        cnt[last][kind] += 1
+    steps = 4
+    freq = {P_CODES: 1 / 4.6, P_PUT: 1 / 4.6, P_PSUM: 1 / 4.6, P_FLUSH: 1 / 18.4, P_FILL: 0.0, P_LONG: None}
+    out = {"kernel": "k_deflate_static<12,11,false,4,0,0>",
+           "what": "static instruction counts of the 16-step group loop body (4 unrolled INNER steps), per step, by phase "
+                   "(tools/valu_by_phase.py: hipcc -S -gline-tables-only line tables).  runs_per_step: how often the phase's code "
+                   "runs on the FASTQ-like set (the refill sits outside this loop body: once per 16 steps, ~60 VALU).",
+           "per_step_static": {}}
+    tot, wtot = collections.Counter(), collections.Counter()
+    for ph, c in sorted(cnt.items(), key=lambda kv: -kv[1]["valu"]):
+        d = {k: round(v / steps, 1) for k, v in sorted(c.items())}
+        f = freq.get(ph, 1.0)
+        d["runs_per_step"] = "once per long match the parse takes" if f is None else round(f, 3)
+        out["per_step_static"][ph] = d
+        for k, v in c.items():
+            tot[k] += v / steps
+            if f:
+                wtot[k] += v / steps * f
+    out["sum_static_all_paths_per_step"] = {k: round(v, 1) for k, v in sorted(tot.items())}
+    out["sum_weighted_by_frequency_per_step"] = {k: round(v, 1) for k, v in sorted(wtot.items())}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
