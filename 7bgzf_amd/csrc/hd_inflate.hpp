@@ -50,9 +50,14 @@ constexpr uint32_t INF_FLUSHED = 1;
 #ifdef HD_INFLATE_STATS
 // experiment build only (tools/exp_inflate_stats.sh): where the tokens go
 __device__ unsigned long long g_inf_stats[8];
+__device__ unsigned long long g_inf_cycles[8];       // [0] block headers + table build, [1] windows, [2] scalar token path, [3] whole kernel
 #define INF_STAT(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats[k], (unsigned long long)(v)); } while (0)
+#define INF_T0(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
+#define INF_T1(k, t) do { if (lane == 0) atomicAdd(&g_inf_cycles[k], __builtin_amdgcn_s_memtime() - (t)); } while (0)
 #else
 #define INF_STAT(k, v) do { } while (0)
+#define INF_T0(t) do { } while (0)
+#define INF_T1(k, t) do { } while (0)
 #endif
 
 constexpr uint32_t INF_LT_BITS = 9;      // litlen direct table (8 VGPRs once loaded)
@@ -453,11 +458,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				     : "=&s"(b), "=&s"(real0), "=&s"(real1), "=&s"(wm)
 				     : "v"(s0.walk), "v"(s1.walk)
 				     : "scc");
-			// output positions; cut in front of the first token that would overrun the budget
-			const uint32_t incl0 = wave_incl_scan(((real0 >> lane) & 1) ? s0.outlen : 0u);
-			const uint32_t incl1 = wave_incl_scan(((real1 >> lane) & 1) ? s1.outlen : 0u) + readlane(incl0, 63);
-			const uint64_t over0 = __ballot(((real0 >> lane) & 1) && incl0 > budget);
-			const uint64_t over1 = __ballot(((real1 >> lane) & 1) && incl1 > budget);
+			// output positions; cut in front of the first token that would overrun the budget.  (Conditions are
+			// 64-bit lane masks: the ballot of ONE compare each, combined in scalar code, back to the lanes
+			// through sel() -- hd_device.hpp "lane masks".)
+			const uint32_t o0 = sel(real0, s0.outlen, 0u);
+			const uint32_t incl0 = wave_incl_scan(o0);
+			const uint32_t incl1 = wave_incl_scan(sel(real1, s1.outlen, 0u)) + readlane(incl0, 63);
+			const uint64_t over0 = __ballot(incl0 > budget) & real0;
+			const uint64_t over1 = __ballot(incl1 > budget) & real1;
 			if (over0 | over1) {
 				if (over0) {
 					b = (uint32_t)__ffsll((unsigned long long)over0) - 1;
@@ -477,39 +485,62 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			INF_STAT(1, __popcll(real0) + __popcll(real1));
 			const uint32_t cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
 						   : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
-			const bool mine0 = (real0 >> lane) & 1, mine1 = (real1 >> lane) & 1;
-			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid where mine
+			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid on the real tokens
 			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
 			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
-			L.ring[(mine0 && s0.is_lit) ? (opos0 & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)(s0.e >> 16);
-			L.ring[(mine1 && s1.is_lit) ? (opos1 & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)(s1.e >> 16);
+			const uint64_t lit0 = real0 & __ballot(s0.is_lit), lit1 = real1 & __ballot(s1.is_lit);
+			L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s0.e >> 16);
+			L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s1.e >> 16);
 			const uint32_t wend = pos + cum;
 			// per-lane verdicts for the matches, so that the scalar loops below only dispatch
-			const bool match0 = mine0 && s0.is_len, match1 = mine1 && s1.is_len;
+			const uint64_t match0 = real0 & __ballot(s0.is_len), match1 = real1 & __ballot(s1.is_len);
 			const uint32_t srcl0 = opos0 - s0.offset, srcl1 = opos1 - s1.offset;   // wrap when offset > opos
-			if (__ballot((match0 && s0.offset > opos0) || (match1 && s1.offset > opos1))) {   // decompress_template.h:724
+			if ((__ballot(s0.offset > opos0) & match0) | (__ballot(s1.offset > opos1) & match1)) {   // decompress_template.h:724
 				st_out = HD_BAD_DATA;
 				result = 2;
 				break;
 			}
 			// "simple": source wholly in the ring and wholly in front of this window's output,
-			// at most 64 bytes.  Nothing in the window feeds them, so they go first, in a
-			// loop with no exec juggling (lanes past the length write to a dump slot behind
-			// the ring); whatever else there is follows in stream order.
-			const uint64_t simple0 = __ballot(match0 && wend - srcl0 <= INF_RING - 64 &&
-							  s0.offset >= rel0 + s0.length && s0.length <= 64);
-			const uint64_t simple1 = __ballot(match1 && wend - srcl1 <= INF_RING - 64 &&
-							  s1.offset >= rel1 + s1.length && s1.length <= 64);
-			// (copying them two at a time, both reads ahead of both writes, measured 2 % slower: the kernel
-			// is bound by scalar issue, not by the LDS round trips)
-			for (uint64_t sm = simple0; sm;) {
+			// at most 64 bytes.  Nothing in the window feeds them, so they go first and in any order;
+			// whatever else there is follows in stream order.
+			const uint64_t simple0 = match0 & __ballot(wend - srcl0 <= INF_RING - 64) & __ballot(s0.offset >= rel0 + s0.length) &
+						 __ballot(s0.length <= 64);
+			const uint64_t simple1 = match1 & __ballot(wend - srcl1 <= INF_RING - 64) & __ballot(s1.offset >= rel1 + s1.length) &
+						 __ballot(s1.length <= 64);
+			// The short ones among them (<= 8 bytes: most matches of a DEFLATE stream) are copied EIGHT AT A TIME, a
+			// group of eight lanes per match: every owner pushes {destination, source, length} to the first lane
+			// of its group (ds_permute), the group fetches it (ds_bpermute), one byte per lane moves.  No scalar
+			// loop per match -- the scalar unit is what bounds this kernel.
+			const uint64_t tiny0 = simple0 & __ballot(s0.length <= 8), tiny1 = simple1 & __ballot(s1.length <= 8);
+			if (tiny0 | tiny1) {
+				const uint32_t nt0 = (uint32_t)__popcll(tiny0), ntiny = nt0 + (uint32_t)__popcll(tiny1);
+				const uint32_t slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny0, 0));
+				const uint32_t slot1 = nt0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny1, 0));
+				const uint32_t pk0 = (opos0 & (INF_RING - 1)) | ((srcl0 & (INF_RING - 1)) << 11) | (s0.length << 22);
+				const uint32_t pk1 = (opos1 & (INF_RING - 1)) | ((srcl1 & (INF_RING - 1)) << 11) | (s1.length << 22);
+				const uint32_t sub = lane & 7, lead = (lane & ~7u) << 2;
+				for (uint32_t base = 0; base < ntiny; base += 8) {
+					// an owner whose slot falls into this pass targets lane 8 (slot - base); everybody else an odd lane
+					// (never a group's first): what arrives there is not looked at
+					const uint32_t d0 = sel(tiny0, slot0 - base, 8u), d1 = sel(tiny1, slot1 - base, 8u);
+					const uint32_t a0 = d0 < 8 ? d0 << 5 : ((lane | 1u) << 2), a1 = d1 < 8 ? d1 << 5 : ((lane | 1u) << 2);
+					const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < 8 ? pk0 : 0u));
+					const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < 8 ? pk1 : 0u));
+					const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)(g0 | g1));
+					const uint32_t tl = w >> 22;                               // 0: no match in this group
+					const uint8_t v = L.ring[(((w >> 11) & (INF_RING - 1)) + sub) & (INF_RING - 1)];
+					L.ring[sub < tl ? (((w & (INF_RING - 1)) + sub) & (INF_RING - 1)) : INF_RING + lane] = v;
+				}
+			}
+			// (copying the longer ones two at a time, both reads ahead of both writes, measured 2 % slower)
+			for (uint64_t sm = simple0 & ~tiny0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				sm &= sm - 1;
 				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
-			for (uint64_t sm = simple1; sm;) {
+			for (uint64_t sm = simple1 & ~tiny1; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				sm &= sm - 1;
 				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
@@ -541,12 +572,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
 				}
 			};
-			for (uint64_t mm = __ballot(match0) & ~simple0; mm;) {
+			for (uint64_t mm = match0 & ~simple0; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				mm &= mm - 1;
 				copy_general(readlane(s0.outlen, m), readlane(opos0, m), readlane(srcl0, m));
 			}
-			for (uint64_t mm = __ballot(match1) & ~simple1; mm;) {
+			for (uint64_t mm = match1 & ~simple1; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				mm &= mm - 1;
 				copy_general(readlane(s1.outlen, m), readlane(opos1, m), readlane(srcl1, m));
@@ -595,7 +626,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			DT[r] = L.off[r * 64 + lane];
 	};
 
+	INF_T0(t_kernel);
 	for (;;) {
+		INF_T0(t_hdr);
 		refill();
 		lds_p0 = 0xfffffff0u;                     // header parsing reuses the LDS behind L.comp
 		const uint32_t bfinal = (uint32_t)bb & 1;
@@ -703,13 +736,17 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			}
 
 			load_tables();
+			INF_T1(0, t_hdr);
 			// ---- symbol loop ----------------------------------------------
 			for (;;) {
 				{
+					INF_T0(t_win);
 					const uint32_t wr = uniform(run_windows(st));
+					INF_T1(1, t_win);
 					if (wr)                      // 1: end of block consumed, 2: error
 						break;
 				}
+				INF_T0(t_tok);
 				// one token through the fully checked scalar path (stream edges, long codes)
 				// one flush site for the whole symbol loop (at most 1023 + 258 bytes pending)
 				if (pos - flushed >= HD_PIECE)
@@ -733,10 +770,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					// every lane stores the same byte to the same address: no exec juggling
 					L.ring[pos & (INF_RING - 1)] = (uint8_t)(e >> 16);
 					pos++;
+					INF_T1(2, t_tok);
 					continue;
 				}
 				if (kind == K_EOB) {
 					INF_STAT(5, 1);
+					INF_T1(2, t_tok);
 					break;
 				}
 				const uint32_t eb = (e >> 4) & 15;
@@ -786,6 +825,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						L.ring[(pos + i) & (INF_RING - 1)] = dst[pos - offset + i];
 				}
 				pos += length;
+				INF_T1(2, t_tok);
 			}
 			if (st != HD_OK)
 				break;
@@ -823,6 +863,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		if (a.status) a.status[b] = st;
 		if (a.crc) a.crc[b] = crcv;
 	}
+	INF_T1(3, t_kernel);
 }
 
 } // namespace hd

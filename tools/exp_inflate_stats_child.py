@@ -13,3 +13,8 @@ out = (ctypes.c_uint64 * 8)()
 pkg.lib().hipdeflate_test_inflate_stats(out)
 names = ["windows", "window_tokens", "scalar_tokens", "slow_litlen", "slow_dist", "eob", "window_empty", "-"]
 print({n: int(v) for n, v in zip(names, out)})
+cyc = (ctypes.c_uint64 * 8)()
+pkg.lib().hipdeflate_test_inflate_cycles(cyc)
+tot = max(int(cyc[3]), 1)
+print({"cycles": {"headers+tables": round(int(cyc[0]) / tot, 3), "windows": round(int(cyc[1]) / tot, 3),
+                   "scalar token path": round(int(cyc[2]) / tot, 3), "whole kernel (sum over waves)": tot}})
