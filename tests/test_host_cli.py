@@ -473,3 +473,84 @@ def test_file_to_file_parallel_io_path(tmp_path):
     assert rc == 0 and open(fo, "rb").read() == blob
     assert open(fx, "rb").read() == open(str(tmp_path / "ref.gzi"), "rb").read()
     assert gzip.decompress(blob) == data
+
+
+def _png(width, height, depth, color, interlace, raw, extra_chunks=(), idat_split=3, level=6):
+    import struct
+    import zlib as _z
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", _z.crc32(t + d))
+    z = _z.compress(raw, level)
+    cut = [len(z) * k // idat_split for k in range(idat_split + 1)]
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, color, 0, 0, interlace))
+    for t, d in extra_chunks:
+        out += chunk(t, d)
+    for k in range(idat_split):
+        out += chunk(b"IDAT", z[cut[k]:cut[k + 1]])
+    return out + chunk(b"tEXt", b"Comment\0made for the test") + chunk(b"IEND", b"")
+
+
+def _png_chunks(blob):
+    import struct
+    import zlib as _z
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, out = 8, []
+    while pos < len(blob):
+        (n,) = struct.unpack(">I", blob[pos:pos + 4])
+        t, d = blob[pos + 4:pos + 8], blob[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", blob[pos + 8 + n:pos + 12 + n])[0] == _z.crc32(t + d), t
+        out.append((t, d))
+        pos += 12 + n
+    return out
+
+
+def test_png_idat_recoder_batches_images(tmp_path):
+    """hd7png (applet/7png.c re-shaped): the IDATs of several images -- RGB, paletted with PLTE/tRNS, 16-bit RGBA,
+    Adam7-interlaced, one large enough for flushed segments -- are inflated in ONE batch and coded again in ONE batch
+    as RFC 1950 members made on the device (78 da, raw DEFLATE == CPU twin, Adler-32); every output is a valid PNG
+    (chunk CRCs), its single IDAT inflates to the same pixels, the other chunks survive (or go with -t)."""
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(5)
+    PNG = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7png")
+
+    def rows(h, rowbytes, smooth=True):
+        a = np.cumsum(rng.integers(-2, 3, (h, rowbytes)), axis=1).astype(np.uint8) if smooth else rng.integers(0, 256, (h, rowbytes), dtype=np.uint8)
+        return b"".join(b"\0" + bytes(r) for r in a)
+    adam = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    w7, h7 = 37, 29
+    raw7 = b"".join(rows(-(-(h7 - y0) // dy), -(-(w7 - x0) // dx) * 3) for x0, y0, dx, dy in adam if w7 > x0 and h7 > y0)
+    images = [
+        (640, 480, 8, 2, 0, rows(480, 640 * 3), ()),
+        (100, 60, 8, 3, 0, rows(60, 100), ((b"PLTE", bytes(range(256)) * 3), (b"tRNS", bytes(256)))),
+        (200, 90, 16, 6, 0, rows(90, 200 * 8), ((b"gAMA", b"\0\0\xb1\x8f"),)),
+        (w7, h7, 8, 2, 1, raw7, ()),
+        (1400, 900, 8, 2, 0, rows(900, 1400 * 3), ()),             # 3.8 MB of pixels: coded in flushed segments
+        (5, 3, 1, 0, 0, b"\0\xa8" * 3, ()),
+    ]
+    args, want = [], []
+    for k, (w, h, depth, color, il, raw, extra) in enumerate(images):
+        fi, fo = str(tmp_path / ("in%d.png" % k)), str(tmp_path / ("out%d.png" % k))
+        open(fi, "wb").write(_png(w, h, depth, color, il, raw, extra, idat_split=1 + k % 3))
+        args += [fi, fo]
+        want.append(raw)
+    for level, strip in ((1, False), (6, True)):
+        p = subprocess.run([PNG, "-G%d" % level] + (["-t"] if strip else []) + args, capture_output=True, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        err = p.stderr.decode()
+        assert err.count("recompressed length=") == len(images) and "Done." in err
+        for k, raw in enumerate(want):
+            src, dst = _png_chunks(open(args[2 * k], "rb").read()), _png_chunks(open(args[2 * k + 1], "rb").read())
+            idat = [d for t, d in dst if t == b"IDAT"]
+            assert len(idat) == 1 and idat[0][:2] == b"\x78\xda" and zlib.decompress(idat[0]) == raw, k
+            r, twin = hdtest.oracle_twin(raw, level, cap=len(raw) + len(raw) // 2 + 4096)
+            assert r == 0 and idat[0][2:-4] == twin, k                                # the device's member == CPU twin
+            keep = [(t, d) for t, d in src if t != b"IDAT" and (not strip or t in (b"IHDR", b"PLTE", b"tRNS", b"IEND"))]
+            assert [(t, d) for t, d in dst if t != b"IDAT"] == keep, k
+            assert dst[-1][0] == b"IEND"
+    # the filter form of the reference, and a file that is not a PNG
+    p = subprocess.run([PNG, "-G1"], input=open(args[0], "rb").read(), capture_output=True, timeout=300)
+    assert p.returncode == 0 and zlib.decompress(b"".join(d for t, d in _png_chunks(p.stdout) if t == b"IDAT")) == want[0]
+    p = subprocess.run([PNG, "-G1"], input=b"GIF89a not a png at all", capture_output=True, timeout=300)
+    assert p.returncode != 0 and b"not PNG file" in p.stderr
