@@ -34,21 +34,23 @@ for seed in seeds:
         blob += b + bytes(-len(b) % 16)
     blob = bytes(blob)
     for level in (1, 2, 3, 4, 6, 7, 9):
-        for frame, twin_fn in ((pkg.FRAME_RAW, hdtest.oracle_twin), (pkg.FRAME_RAW_FLUSH, hdtest.oracle_twin_flush)):
+        for frame, twin_fn in ((pkg.FRAME_RAW, hdtest.oracle_twin), (pkg.FRAME_RAW_FLUSH, hdtest.oracle_twin_flush),
+                               (pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin),
+                               (pkg.FRAME_RAW_FLUSH | pkg.FRAME_LATENCY, hdtest.codec_twin_flush)):
             slot = int(pkg.lib().hipdeflate_bound(max(lens), level))
             members, crc, st = pkg.batch_deflate(blob, offs, lens, level, frame, slot=slot)
-            with ThreadPoolExecutor(16) as ex:
+            with ThreadPoolExecutor(min(64, os.cpu_count() or 16)) as ex:
                 twins = list(ex.map(lambda b: twin_fn(b, level, cap=slot), blocks))
             for i, b in enumerate(blocks):
                 total += 1
                 ok = st[i] == 0 and twins[i][0] == 0 and members[i] == twins[i][1] and int(crc[i]) == zlib.crc32(b)
                 if ok:
-                    tail = b"\x03\x00" if frame == pkg.FRAME_RAW_FLUSH else b""
+                    tail = b"\x03\x00" if (frame & 0xff) == pkg.FRAME_RAW_FLUSH else b""
                     ok = zlib.decompressobj(-15).decompress(members[i] + tail) == b
                 if not ok:
                     bad += 1
                     print("MISMATCH seed %d block %d len %d level %d frame %d st %d" % (seed, i, len(b), level, frame, st[i]), flush=True)
-            if frame == pkg.FRAME_RAW:
+            if (frame & 0xff) == pkg.FRAME_RAW:
                 outs, dcrc, dst = pkg.batch_inflate(members, lens)
                 for i, b in enumerate(blocks):
                     if dst[i] != 0 or outs[i] != b:
