@@ -565,27 +565,41 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
 			uint32_t len = 8;
 			for (;;) {
-				// (every index is masked into the ring, so lanes past maxlen may read too)
+				// (every index is masked into the ring, so lanes past maxlen may read too: the length is cut
+				// to maxlen behind the loop)
 				const uint32_t idx = len + lane;
-				const uint64_t past = maxlen - len >= 64 ? 0ull : ~0ull << (maxlen - len);   // lanes with idx >= maxlen
-				const uint64_t nq = __ballot(ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]) | past;
+				const uint64_t nq = __ballot(ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]);
 				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
 				len += k;
-				if (k < 64)
+				if (k < 64 || len >= maxlen)
 					break;
 			}
+			len = len < maxlen ? len : maxlen;
 			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
 			if (len > 8) {
 				lenv = lane == m ? len : lenv;
 				const uint32_t q = m + len;                   // first lane behind the match
+				// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 3
+				// branches + one v_readlane.  The lane selects of v_readlane / s_bitcmp1 / s_bitset1 take the low
+				// 6 bits and xq < 64 is tested first; an SGPR written by the SALU needs no wait states before
+				// v_readlane uses it as lane select)
 				uint64_t fresh = 0;
-				uint32_t xq = q;
-				while (xq < 64 && !((starts >> xq) & 1)) {
-					fresh |= 1ull << xq;
-					xq += readlane(jump8, xq);
-				}
-				const uint64_t below_x = xq >= 64 ? ~0ull : ((1ull << xq) - 1);
-				starts = (starts & (upto_m | ~below_x)) | fresh;
+				uint32_t xq = q, hop;
+				asm volatile("Lhd_rethread_%=:\n\t"
+					     "s_cmp_gt_u32 %0, 63\n\t"
+					     "s_cbranch_scc1 Lhd_rethread_done_%=\n\t"
+					     "s_bitcmp1_b64 %3, %0\n\t"
+					     "s_cbranch_scc1 Lhd_rethread_done_%=\n\t"
+					     "s_bitset1_b64 %1, %0\n\t"
+					     "v_readlane_b32 %2, %4, %0\n\t"
+					     "s_add_u32 %0, %0, %2\n\t"
+					     "s_branch Lhd_rethread_%=\n"
+					     "Lhd_rethread_done_%=:"
+					     : "+s"(xq), "+s"(fresh), "=&s"(hop)
+					     : "s"(starts), "v"(jump8)
+					     : "scc");
+				const uint64_t from_x = xq >= 64 ? 0ull : ~0ull << xq;        // the old parse holds from lane xq on
+				starts = (starts & (upto_m | from_x)) | fresh;
 			}
 			cm = starts & capmask & ~upto_m;
 		}

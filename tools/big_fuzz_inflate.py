@@ -54,7 +54,7 @@ for seed in seeds:
                 caps.append(max(0, n + int(rng.integers(-2, 3)) * 40))
         outs, crc, st = pkg.batch_inflate(streams, caps, flushed=flushed)
         fn = hdtest.oracle_inflate_flushed if flushed else hdtest.oracle_inflate
-        with ThreadPoolExecutor(16) as ex:
+        with ThreadPoolExecutor(min(64, os.cpu_count() or 16)) as ex:
             want = list(ex.map(lambda a: fn(a[0], a[1]), zip(streams, caps)))
         for i in range(len(streams)):
             total += 1

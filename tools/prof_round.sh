@@ -1,14 +1,14 @@
 # Round profile: kernel trace of the default bench command + HBM traffic counters of the
 # dominant kernel at the full 16 GiB config (separate --pmc passes, MI355X_MICROARCH.md).
 set -e
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_round
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 3 --warmup 1 > $OUT/bench_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 3 --warmup 1 --no-extra > $OUT/bench_kt.log 2>&1
 grep '^{' $OUT/bench_kt.log > $OUT/bench_line.json || true
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra > $OUT/bench_write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_dec -- python3 bench.py --steps 2 --warmup 1 --mode decode --stream libdeflate6 --no-cpu > $OUT/bench_kt_dec.log 2>&1
 grep '^{' $OUT/bench_kt_dec.log > $OUT/bench_line_dec.json || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_l6 -- python3 bench.py --steps 2 --warmup 1 --level 6 --no-cpu > $OUT/bench_kt_l6.log 2>&1
@@ -32,7 +32,7 @@ fetch=acc['FETCH_SIZE']*1024*2
 write=acc['WRITE_SIZE']*1024
 json.dump({"kernel":"k_deflate_static<12,11>","input_bytes":17179869184,"fetch_bytes":fetch,"write_bytes":write,
   "hbm_bytes_per_launch":fetch+write,
-  "method":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu` (one launch); KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of 16 B/lane streaming reads at 64 B); WRITE_SIZE as is"},
+  "method":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu --no-extra` (one launch); KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of 16 B/lane streaming reads at 64 B); WRITE_SIZE as is"},
   open(out+'/traffic_encode_l1.json','w'),indent=1)
 PY
 ls $OUT
