@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// a slot: what lands there is never read)
 	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 32];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
+	const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ring32;   // LDS byte address of the ring
 
 	const uint32_t lane = threadIdx.x;
 	const uint32_t b = a.first + blockIdx.x;
@@ -564,18 +565,36 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const uint32_t dm = pm + 1 - readlane(c, m);
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
 			uint32_t len = 8;
-			for (;;) {
-				// (every index is masked into the ring, so lanes past maxlen may read too: the length is cut
-				// to maxlen behind the loop)
-				const uint32_t idx = len + lane;
-				const uint64_t nq = __ballot(ring8[(pm + idx) & (W - 1)] != ring8[(pm + idx - dm) & (W - 1)]);
-				const uint32_t k = nq ? (uint32_t)__ffsll((unsigned long long)nq) - 1 : 64;
-				len += k;
-				if (k < 64 || len >= maxlen)
-					break;
+			{
+				// 64 bytes per pass, every index masked into the ring (lanes past maxlen may read too: the length
+				// is cut to maxlen behind the loop).  Written out: left to the compiler the two exits become 11
+				// scalar instructions of cselect per pass; here 3 (mismatch found) or 4 (another pass).
+				uint32_t t0, t1, k;
+				asm volatile("Lhd_ext_%=:\n\t"
+					     "v_add_u32 %[t0], %[len], %[vb]\n\t"
+					     "v_add_u32 %[t1], %[ndm], %[t0]\n\t"
+					     "v_and_b32 %[t0], %[msk], %[t0]\n\t"
+					     "v_and_b32 %[t1], %[msk], %[t1]\n\t"
+					     "v_add_u32 %[t0], %[rb], %[t0]\n\t"
+					     "v_add_u32 %[t1], %[rb], %[t1]\n\t"
+					     "ds_read_u8 %[t0], %[t0]\n\t"
+					     "ds_read_u8 %[t1], %[t1]\n\t"
+					     "s_waitcnt lgkmcnt(0)\n\t"
+					     "v_cmp_ne_u16 vcc, %[t0], %[t1]\n\t"
+					     "s_cbranch_vccnz Lhd_ext_hit_%=\n\t"
+					     "s_add_u32 %[len], %[len], 64\n\t"
+					     "s_cmp_lt_u32 %[len], %[maxlen]\n\t"
+					     "s_cbranch_scc1 Lhd_ext_%=\n\t"
+					     "s_branch Lhd_ext_done_%=\n"
+					     "Lhd_ext_hit_%=:\n\t"
+					     "s_ff1_i32_b64 %[k], vcc\n\t"
+					     "s_add_u32 %[len], %[len], %[k]\n"
+					     "Lhd_ext_done_%=:"
+					     : [len] "+s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&s"(k)
+					     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "s"(ring_lds), [maxlen] "s"(maxlen)
+					     : "vcc", "scc", "memory");
 			}
 			len = len < maxlen ? len : maxlen;
-			const uint64_t upto_m = (2ull << m) - 1;          // lanes <= m
 			if (len > 8) {
 				lenv = lane == m ? len : lenv;
 				const uint32_t q = m + len;                   // first lane behind the match
@@ -598,10 +617,14 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					     : "+s"(xq), "+s"(fresh), "=&s"(hop)
 					     : "s"(starts), "v"(jump8)
 					     : "scc");
-				const uint64_t from_x = xq >= 64 ? 0ull : ~0ull << xq;        // the old parse holds from lane xq on
-				starts = (starts & (upto_m | from_x)) | fresh;
+				// the old parse holds from lane xq on: its starts in (m, xq) go (one s_bfm_b64: xq - m - 1 >= 8 ones
+				// from bit m + 1; xq >= 64 makes the run end at lane 63, m == 63 makes it empty)
+				const uint32_t xe = xq < 64 ? xq : 64;
+				uint64_t gone;
+				asm("s_bfm_b64 %0, %1, %2" : "=s"(gone) : "s"(xe - m - 1), "s"(m + 1));
+				starts = (starts & ~gone) | fresh;
 			}
-			cm = starts & capmask & ~upto_m;
+			cm = starts & capmask & (~1ull << m);             // lanes > m
 		}
 		// coverage behind the last token of the step
 		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
