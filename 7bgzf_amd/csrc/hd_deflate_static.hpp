@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 
 	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
 	// unaligned 8-byte read never wrap
-	__shared__ __attribute__((aligned(16))) uint32_t ring32[W / 4 + 4];
+	__shared__ __attribute__((aligned(W))) uint32_t ring32[W / 4 + 4];       // W-aligned: ring address = (x & (W - 1)) | base
 	// (position + 1) mod 2^16, 0 = empty
 	__shared__ __attribute__((aligned(16))) uint16_t table[HS];
 	// TOK: no bits are made here, the staging ring's place is taken by the symbol histograms
@@ -573,10 +573,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 				asm volatile("Lhd_ext_%=:\n\t"
 					     "v_add_u32 %[t0], %[len], %[vb]\n\t"
 					     "v_add_u32 %[t1], %[ndm], %[t0]\n\t"
-					     "v_and_b32 %[t0], %[msk], %[t0]\n\t"
-					     "v_and_b32 %[t1], %[msk], %[t1]\n\t"
-					     "v_add_u32 %[t0], %[rb], %[t0]\n\t"
-					     "v_add_u32 %[t1], %[rb], %[t1]\n\t"
+					     "v_and_or_b32 %[t0], %[t0], %[msk], %[rb]\n\t"
+					     "v_and_or_b32 %[t1], %[t1], %[msk], %[rb]\n\t"
 					     "ds_read_u8 %[t0], %[t0]\n\t"
 					     "ds_read_u8 %[t1], %[t1]\n\t"
 					     "s_waitcnt lgkmcnt(0)\n\t"
@@ -591,28 +589,29 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					     "s_add_u32 %[len], %[len], %[k]\n"
 					     "Lhd_ext_done_%=:"
 					     : [len] "+s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&s"(k)
-					     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "s"(ring_lds), [maxlen] "s"(maxlen)
+					     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "v"(ring_lds), [maxlen] "s"(maxlen)
 					     : "vcc", "scc", "memory");
 			}
 			len = len < maxlen ? len : maxlen;
 			if (len > 8) {
 				lenv = lane == m ? len : lenv;
 				const uint32_t q = m + len;                   // first lane behind the match
-				// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 3
+				// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 2
 				// branches + one v_readlane.  The lane selects of v_readlane / s_bitcmp1 / s_bitset1 take the low
 				// 6 bits and xq < 64 is tested first; an SGPR written by the SALU needs no wait states before
 				// v_readlane uses it as lane select)
 				uint64_t fresh = 0;
 				uint32_t xq = q, hop;
-				asm volatile("Lhd_rethread_%=:\n\t"
-					     "s_cmp_gt_u32 %0, 63\n\t"
-					     "s_cbranch_scc1 Lhd_rethread_done_%=\n\t"
+				asm volatile("s_cmp_gt_u32 %0, 63\n\t"
+					     "s_cbranch_scc1 Lhd_rethread_done_%=\n"
+					     "Lhd_rethread_%=:\n\t"
 					     "s_bitcmp1_b64 %3, %0\n\t"
 					     "s_cbranch_scc1 Lhd_rethread_done_%=\n\t"
 					     "s_bitset1_b64 %1, %0\n\t"
 					     "v_readlane_b32 %2, %4, %0\n\t"
 					     "s_add_u32 %0, %0, %2\n\t"
-					     "s_branch Lhd_rethread_%=\n"
+					     "s_cmp_lt_u32 %0, 64\n\t"
+					     "s_cbranch_scc1 Lhd_rethread_%=\n"
 					     "Lhd_rethread_done_%=:"
 					     : "+s"(xq), "+s"(fresh), "=&s"(hop)
 					     : "s"(starts), "v"(jump8)
