@@ -231,6 +231,16 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	constexpr uint32_t STG = 256;            // staging ring, dwords
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 	constexpr uint32_t TOKQ = 128;           // token queue: < 64 waiting + <= 64 of one step
+	// K16: every lane whose first eight bytes agree learns bytes 8..15 in the vector domain too (four more ring
+	// dwords per lane, issued ahead of the scan and used behind it), so the scalar extension loop below runs only
+	// for matches of 16 bytes and more.  On text 98 % of the "long" matches are 9..15 bytes long, and the parse
+	// kernels of the dynamic levels wait on that loop's LDS round trip; the level-1 kernel is bound by its vector
+	// instruction count instead and keeps the loop (HD_K16_LEVEL1 to try)
+#ifdef HD_K16_LEVEL1
+	constexpr bool K16 = true;
+#else
+	constexpr bool K16 = TOK;
+#endif
 
 	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
 	// unaligned 8-byte read never wrap
@@ -542,6 +552,18 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
 		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
 		const uint32_t lit = cv0 & 0xff;
+		// K16: length over 16 bytes (valid on the capped lanes; the reads go out here, the scan runs meanwhile)
+		uint32_t len16 = 8;
+		if (K16) {
+			const uint32_t *wp = &ring32[(p >> 2) & W4M], *wc = &ring32[(cp >> 2) & W4M];    // + 16 mirrored bytes: [0,5) never wraps
+			const uint32_t p2 = wp[2], p3 = wp[3], p4 = wp[4], c2 = qc.c2, c3 = wc[3], c4 = wc[4];
+			const uint32_t xa = __builtin_amdgcn_alignbyte(p3, p2, p & 3) ^ __builtin_amdgcn_alignbyte(c3, c2, cp & 3);   // bytes 8..11
+			const uint32_t xb = __builtin_amdgcn_alignbyte(p4, p3, p & 3) ^ __builtin_amdgcn_alignbyte(c4, c3, cp & 3);   // bytes 12..15
+			const uint32_t ka = xa ? (uint32_t)__builtin_ctz(xa) >> 3 : 4u, kb = xb ? (uint32_t)__builtin_ctz(xb) >> 3 : 4u;
+			len16 = 8 + (xa ? ka : 4 + kb);
+			if (!INNER)
+				len16 = len16 < room ? len16 : room;
+		}
 		uint64_t starts;
 		{
 			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on covered lanes
@@ -564,8 +586,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const uint32_t pm = S + m;
 			const uint32_t dm = pm + 1 - readlane(c, m);
 			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
-			uint32_t len = 8;
-			{
+			uint32_t len = K16 ? readlane(len16, m) : 8u;
+			if (!K16 || len == 16) {
 				// 64 bytes per pass, every index masked into the ring (lanes past maxlen may read too: the length
 				// is cut to maxlen behind the loop).  Written out: left to the compiler the two exits become 11
 				// scalar instructions of cselect per pass; here 3 (mismatch found) or 4 (another pass).
