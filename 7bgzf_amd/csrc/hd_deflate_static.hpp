@@ -236,11 +236,18 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// for matches of 16 bytes and more.  On text 98 % of the "long" matches are 9..15 bytes long, and the parse
 	// kernels of the dynamic levels wait on that loop's LDS round trip; the level-1 kernel is bound by its vector
 	// instruction count instead and keeps the loop (HD_K16_LEVEL1 to try)
-#ifdef HD_K16_LEVEL1
+#if defined(HD_K16_ALL)
 	constexpr bool K16 = true;
+#elif defined(HD_K16_OFF)
+	constexpr bool K16 = false;
+#elif defined(HD_K16_NOT_L2)
+	constexpr bool K16 = TOK && WIN_BITS > 12;
 #else
 	constexpr bool K16 = TOK;
 #endif
+	// the ring dwords for it are read a step ahead, in probe(), where five more registers do not cost a wave
+	// (every geometry but the level-2 one, which LDS lets run 18 waves per CU: <= 96 VGPRs)
+	constexpr bool K16_EARLY = K16 && WIN_BITS > 12;
 
 	// + 16 bytes that mirror the start of the ring, so that the 3 dwords under an
 	// unaligned 8-byte read never wrap
@@ -408,13 +415,25 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	};
 	struct Probed {
 		uint32_t c0, c1, c2;
+		uint32_t c3, c4, p2, p3, p4;     // K16: the candidate's and the lane's own bytes up to 16 (+ alignment)
 	};
-	auto probe = [&](uint32_t c) -> Probed {
+	auto probe = [&](uint32_t c, uint32_t p) -> Probed {
 		Probed q;
 		const uint32_t *w = &ring32[((c - 1) >> 2) & W4M];
 		q.c0 = w[0];
 		q.c1 = w[1];
 		q.c2 = w[2];
+		if (K16_EARLY) {
+			// (+ 16 mirrored bytes behind the ring: dwords [0,5) of an index never wrap)
+			const uint32_t *wp = &ring32[(p >> 2) & W4M];
+			q.c3 = w[3];
+			q.c4 = w[4];
+			q.p2 = wp[2];
+			q.p3 = wp[3];
+			q.p4 = wp[4];
+		} else {
+			q.c3 = q.c4 = q.p2 = q.p3 = q.p4 = 0;
+		}
 		return q;
 	};
 
@@ -476,11 +495,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		put(lane == 0 ? (flush ? 2u : 3u) : 0u, lane == 0 ? 3u : 0u, 3u, 3u);
 
 	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
-	Probed q0 = { 0, 0, 0 };
+	Probed q0 = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (use_static && n) {
 		fill_piece();
 		f0 = fetch(std::false_type{}, 0);
-		q0 = probe(f0.c);
+		q0 = probe(f0.c, lane);
 		f1 = fetch(std::false_type{}, 64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
@@ -498,7 +517,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const Fetched fc = f0;
 		const Probed qc = q0;
 		f0 = f1;
-		q0 = probe(f1.c);                  // harmless beyond n: every index is masked into the ring
+		q0 = probe(f1.c, S + 64 + lane);   // harmless beyond n: every index is masked into the ring
 		f1 = fetch(inner_tag, S + 128);
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
@@ -552,11 +571,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
 		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
 		const uint32_t lit = cv0 & 0xff;
-		// K16: length over 16 bytes (valid on the capped lanes; the reads go out here, the scan runs meanwhile)
+		// K16: length over 16 bytes (valid on the capped lanes)
 		uint32_t len16 = 8;
 		if (K16) {
-			const uint32_t *wp = &ring32[(p >> 2) & W4M], *wc = &ring32[(cp >> 2) & W4M];    // + 16 mirrored bytes: [0,5) never wraps
-			const uint32_t p2 = wp[2], p3 = wp[3], p4 = wp[4], c2 = qc.c2, c3 = wc[3], c4 = wc[4];
+			const uint32_t *wp = &ring32[(p >> 2) & W4M], *wc = &ring32[(cp >> 2) & W4M];
+			const uint32_t c2 = qc.c2;
+			const uint32_t p2 = K16_EARLY ? qc.p2 : wp[2], p3 = K16_EARLY ? qc.p3 : wp[3], p4 = K16_EARLY ? qc.p4 : wp[4];
+			const uint32_t c3 = K16_EARLY ? qc.c3 : wc[3], c4 = K16_EARLY ? qc.c4 : wc[4];
 			const uint32_t xa = __builtin_amdgcn_alignbyte(p3, p2, p & 3) ^ __builtin_amdgcn_alignbyte(c3, c2, cp & 3);   // bytes 8..11
 			const uint32_t xb = __builtin_amdgcn_alignbyte(p4, p3, p & 3) ^ __builtin_amdgcn_alignbyte(c4, c3, cp & 3);   // bytes 12..15
 			const uint32_t ka = xa ? (uint32_t)__builtin_ctz(xa) >> 3 : 4u, kb = xb ? (uint32_t)__builtin_ctz(xb) >> 3 : 4u;
@@ -564,11 +585,40 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			if (!INNER)
 				len16 = len16 < room ? len16 : room;
 		}
+		// K16, continuation lanes.  A capped match of 9..15 bytes at lane m is taken apart for the automaton: m
+		// jumps 8, and lane m + 8 -- its "continuation lane" -- jumps the k = len - 8 bytes that are left, whatever
+		// candidate that lane has itself.  A parse that takes m arrives at m + 8 with state 0, walks on k lanes and
+		// is where the match of 8 + k bytes would have put it: no scalar work at all.  The continuation lane is a
+		// token start for the scan only (`v` below: not queued; the token of m carries the whole length).  What
+		// is left for the scalar loop: matches of 16 bytes and more (k8m), and continuation lanes the parse reached
+		// WITHOUT taking their parent (the parent lies under an earlier token): there the lane's own candidate
+		// counts, and the chain is re-threaded from it.  On text that is one event in 12 steps instead of 2.5 per step.
+		//   A     parents: capped, 9..15 bytes, not themselves the continuation lane of a parent (stride-8 chains
+		//         alternate: A[l] = capk[l] & ~A[l - 8])
+		//   contm continuation lanes (A << 8; a parent in lanes 56..63 has none: its token simply ends in the next step)
+		//   jumpA what the automaton sees, jumpW the true length of a token that starts at the lane (16+: 8 for now)
+		uint64_t k8m = 0, par = 0, contm = 0;
+		uint32_t jumpA = jump8, jumpW = jump8;
+		if (K16) {
+			k8m = capmask & __ballot(len16 == 16);
+			const uint64_t capk = capmask & ~k8m & __ballot(len16 != 8);
+			par = capk;
+			if (capk & (capk << 8)) {
+#pragma unroll
+				for (int i = 0; i < 7; i++)
+					par = capk & ~(par << 8);
+			}
+			contm = (par << 8) & lanem;
+			const uint32_t kc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane - 8) << 2), (int)(len16 - 8));
+			jumpW = sel(capk, len16, jump8);
+			jumpA = sel(contm, kc, jump8);
+			lenv = jumpW;
+		}
 		uint64_t starts;
 		{
-			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump8 - 1, the identity on covered lanes
+			// fn8_make: {a, 0, 1, 2 | 3, 4, 5, 6} with a = jump - 1, the identity on covered lanes
 			Fn8 f;
-			f.lo = sel(livem, jump8 + 0x0200ffffu, 0x03020100u);
+			f.lo = sel(livem, jumpA + 0x0200ffffu, 0x03020100u);
 			f.hi = sel(livem, 0x06050403u, 0x07060504u);
 			const Fn8 w = fn8_scan(f, fid);
 			// state entering lane l = (f_{l-1} o ... o f_0)(0): byte 0 of lane l-1 (0 enters lane 0)
@@ -580,19 +630,24 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// behind it.  Two parses that start a token on the same lane coincide
 		// from there on, so the walk stops at the first old start it lands on
 		// (a few hops) instead of re-scanning the wave.
-		uint64_t cm = starts & capmask;
-		while (cm) {
-			const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
-			const uint32_t pm = S + m;
-			const uint32_t dm = pm + 1 - readlane(c, m);
-			const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
-			uint32_t len = K16 ? readlane(len16, m) : 8u;
-			if (!K16 || len == 16) {
-				// 64 bytes per pass, every index masked into the ring (lanes past maxlen may read too: the length
-				// is cut to maxlen behind the loop).  Written out: left to the compiler the two exits become 11
-				// scalar instructions of cselect per pass; here 3 (mismatch found) or 4 (another pass).
-				uint32_t t0, t1, k;
-				asm volatile("Lhd_ext_%=:\n\t"
+		uint64_t v = 0;                      // K16: continuation lanes whose parent the parse took
+		if (K16) {
+			uint64_t pend = ~0ull;           // lanes behind the last event
+			for (;;) {
+				v = starts & contm & ((starts & par) << 8);
+				const uint64_t ev = starts & (k8m | contm) & ~v & pend;
+				if (!ev)
+					break;
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)ev) - 1;
+				uint32_t len;
+				if ((k8m >> m) & 1) {
+					// 16 bytes and more: extended as below, from byte 16 on
+					const uint32_t pm = S + m;
+					const uint32_t dm = pm + 1 - readlane(c, m);
+					const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+					uint32_t t0, t1, k;
+					len = 16;
+					asm volatile("Lhd_ext_%=:\n\t"
 					     "v_add_u32 %[t0], %[len], %[vb]\n\t"
 					     "v_add_u32 %[t1], %[ndm], %[t0]\n\t"
 					     "v_and_or_b32 %[t0], %[t0], %[msk], %[rb]\n\t"
@@ -613,17 +668,16 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					     : [len] "+s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&s"(k)
 					     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "v"(ring_lds), [maxlen] "s"(maxlen)
 					     : "vcc", "scc", "memory");
-			}
-			len = len < maxlen ? len : maxlen;
-			if (len > 8) {
-				lenv = lane == m ? len : lenv;
-				const uint32_t q = m + len;                   // first lane behind the match
-				// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 2
-				// branches + one v_readlane.  The lane selects of v_readlane / s_bitcmp1 / s_bitset1 take the low
-				// 6 bits and xq < 64 is tested first; an SGPR written by the SALU needs no wait states before
-				// v_readlane uses it as lane select)
+					len = len < maxlen ? len : maxlen;
+					lenv = lane == m ? len : lenv;
+				} else {
+					len = readlane(jumpW, m);            // a continuation lane on its own: its own candidate (or a literal)
+				}
+				// re-thread behind the token of m.  The old chain is good again from its first start that is not a
+				// continuation lane (those behave differently when they are reached from elsewhere)
 				uint64_t fresh = 0;
-				uint32_t xq = q, hop;
+				// (the merge of an asm result and a v_readlane counts as divergent for the compiler: pinned)
+				uint32_t xq = m + (uint32_t)__builtin_amdgcn_readfirstlane((int)len), hop;
 				asm volatile("s_cmp_gt_u32 %0, 63\n\t"
 					     "s_cbranch_scc1 Lhd_rethread_done_%=\n"
 					     "Lhd_rethread_%=:\n\t"
@@ -636,22 +690,89 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					     "s_cbranch_scc1 Lhd_rethread_%=\n"
 					     "Lhd_rethread_done_%=:"
 					     : "+s"(xq), "+s"(fresh), "=&s"(hop)
-					     : "s"(starts), "v"(jump8)
+					     : "s"(starts & ~contm), "v"(jumpW)
 					     : "scc");
-				// the old parse holds from lane xq on: its starts in (m, xq) go (one s_bfm_b64: xq - m - 1 >= 8 ones
-				// from bit m + 1; xq >= 64 makes the run end at lane 63, m == 63 makes it empty)
 				const uint32_t xe = xq < 64 ? xq : 64;
-				uint64_t gone;
+				uint64_t gone;                           // lanes (m, xe): xe - m - 1 may be 0 here (a literal at m)
 				asm("s_bfm_b64 %0, %1, %2" : "=s"(gone) : "s"(xe - m - 1), "s"(m + 1));
 				starts = (starts & ~gone) | fresh;
+				pend = ~1ull << m;
 			}
-			cm = starts & capmask & (~1ull << m);             // lanes > m
+		} else {
+			uint64_t cm = starts & capmask;
+			while (cm) {
+				const uint32_t m = (uint32_t)__ffsll((unsigned long long)cm) - 1;
+				const uint32_t pm = S + m;
+				const uint32_t dm = pm + 1 - readlane(c, m);
+				const uint32_t maxlen = n - pm < HD_MAX_MATCH ? n - pm : HD_MAX_MATCH;
+				uint32_t len = 8;
+				{
+					// 64 bytes per pass, every index masked into the ring (lanes past maxlen may read too: the length
+					// is cut to maxlen behind the loop).  Written out: left to the compiler the two exits become 11
+					// scalar instructions of cselect per pass; here 3 (mismatch found) or 4 (another pass).
+					uint32_t t0, t1, k;
+					asm volatile("Lhd_ext_%=:\n\t"
+						     "v_add_u32 %[t0], %[len], %[vb]\n\t"
+						     "v_add_u32 %[t1], %[ndm], %[t0]\n\t"
+						     "v_and_or_b32 %[t0], %[t0], %[msk], %[rb]\n\t"
+						     "v_and_or_b32 %[t1], %[t1], %[msk], %[rb]\n\t"
+						     "ds_read_u8 %[t0], %[t0]\n\t"
+						     "ds_read_u8 %[t1], %[t1]\n\t"
+						     "s_waitcnt lgkmcnt(0)\n\t"
+						     "v_cmp_ne_u16 vcc, %[t0], %[t1]\n\t"
+						     "s_cbranch_vccnz Lhd_ext_hit_%=\n\t"
+						     "s_add_u32 %[len], %[len], 64\n\t"
+						     "s_cmp_lt_u32 %[len], %[maxlen]\n\t"
+						     "s_cbranch_scc1 Lhd_ext_%=\n\t"
+						     "s_branch Lhd_ext_done_%=\n"
+						     "Lhd_ext_hit_%=:\n\t"
+						     "s_ff1_i32_b64 %[k], vcc\n\t"
+						     "s_add_u32 %[len], %[len], %[k]\n"
+						     "Lhd_ext_done_%=:"
+						     : [len] "+s"(len), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&s"(k)
+						     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "v"(ring_lds), [maxlen] "s"(maxlen)
+						     : "vcc", "scc", "memory");
+				}
+				len = len < maxlen ? len : maxlen;
+				if (len > 8) {
+					lenv = lane == m ? len : lenv;
+					const uint32_t q = m + len;                   // first lane behind the match
+					// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 2
+					// branches + one v_readlane.  The lane selects of v_readlane / s_bitcmp1 / s_bitset1 take the low
+					// 6 bits and xq < 64 is tested first; an SGPR written by the SALU needs no wait states before
+					// v_readlane uses it as lane select)
+					uint64_t fresh = 0;
+					uint32_t xq = q, hop;
+					asm volatile("s_cmp_gt_u32 %0, 63\n\t"
+						     "s_cbranch_scc1 Lhd_rethread_done_%=\n"
+						     "Lhd_rethread_%=:\n\t"
+						     "s_bitcmp1_b64 %3, %0\n\t"
+						     "s_cbranch_scc1 Lhd_rethread_done_%=\n\t"
+						     "s_bitset1_b64 %1, %0\n\t"
+						     "v_readlane_b32 %2, %4, %0\n\t"
+						     "s_add_u32 %0, %0, %2\n\t"
+						     "s_cmp_lt_u32 %0, 64\n\t"
+						     "s_cbranch_scc1 Lhd_rethread_%=\n"
+						     "Lhd_rethread_done_%=:"
+						     : "+s"(xq), "+s"(fresh), "=&s"(hop)
+						     : "s"(starts), "v"(jump8)
+						     : "scc");
+					// the old parse holds from lane xq on: its starts in (m, xq) go (one s_bfm_b64: xq - m - 1 >= 8 ones
+					// from bit m + 1; xq >= 64 makes the run end at lane 63, m == 63 makes it empty)
+					const uint32_t xe = xq < 64 ? xq : 64;
+					uint64_t gone;
+					asm("s_bfm_b64 %0, %1, %2" : "=s"(gone) : "s"(xe - m - 1), "s"(m + 1));
+					starts = (starts & ~gone) | fresh;
+				}
+				cm = starts & capmask & (~1ull << m);             // lanes > m
+			}
 		}
 		// coverage behind the last token of the step
-		const uint32_t last = 63 - (uint32_t)__clzll((long long)starts);      // starts != 0: carry < lanes
+		// (the last REAL start: a continuation lane behind it belongs to its token)
+		const uint32_t last = 63 - (uint32_t)__clzll((long long)(starts & ~v));      // != 0: carry < lanes, and the first start is real
 		const uint32_t E = last + readlane(lenv, last);
-		const uint64_t mm = starts & okm;                  // matches
-		const uint64_t tm = starts & lanem;                // tokens: matches + literals inside the block
+		const uint64_t tm = starts & lanem & ~v;           // tokens: matches + literals inside the block
+		const uint64_t mm = tm & okm;                      // matches
 		// max(E, 64) - 64 in scalar registers (written in C the compiler makes a v_sub ... clamp + v_readfirstlane of
 		// it); tail step: matches are clipped to n
 		if (INNER || lanes == 64)
