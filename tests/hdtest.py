@@ -187,6 +187,33 @@ def _fib_literals():
     return v.tobytes()
 
 
+def corpus_phrases(seed, count):
+    """Blocks made of a small dictionary of 5..40-byte phrases (most of them 9..15 bytes long) with 0..3 random
+    bytes between them: matches of 9..15 bytes at every spacing, eight lanes apart included -- the continuation
+    lanes of the parse kernels (hd_deflate_static.hpp, K16), parents that are continuation lanes themselves,
+    continuation lanes reached without their parent, 16-byte-and-longer matches in between."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        alpha = [np.arange(256, dtype=np.uint8), np.frombuffer(b"ACGT", dtype=np.uint8),
+                 np.frombuffer(b"etaoin shrdlu", dtype=np.uint8)][k % 3]
+        lens = rng.choice([5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 24, 40], int(rng.integers(3, 40)))
+        words = [rng.choice(alpha, int(n)) for n in lens]
+        n = int(rng.choice([200, 1000, 4096, 9000, 20000, 65280, 70000]))
+        parts, have = [], 0
+        gap = int(rng.integers(0, 4))
+        while have < n:
+            w = words[int(rng.integers(0, len(words)))]
+            if rng.integers(0, 8) == 0:
+                w = w[:int(rng.integers(1, len(w) + 1))]                 # a phrase cut short
+            parts.append(w)
+            g = rng.integers(0, 256, int(rng.integers(0, gap + 1)), dtype=np.uint8)
+            parts.append(g)
+            have += len(w) + len(g)
+        out.append(np.concatenate(parts).tobytes()[:n])
+    return out
+
+
 def corpus_fuzz(seed, count):
     """Seeded structured-random blocks that lean on the corners of the parse: runs and periodic
     data (8-byte-capped matches, extension across steps, lengths around 258), copies at distances

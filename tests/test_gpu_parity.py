@@ -230,6 +230,27 @@ def test_encode_fuzz_blocks_match_twin(pkg, level):
         assert int(crc[i]) == hdtest.oracle_crc32(d), i
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 5, 6, 9])
+def test_encode_phrase_blocks_match_twin(pkg, level):
+    """Blocks of dictionary phrases (hdtest.corpus_phrases: matches of 9..15 bytes at every spacing -- the
+    continuation lanes of the parse kernels, their conflicts and the stride-8 parent chains): kernel == twin."""
+    blocks = hdtest.corpus_phrases(2000 + level, 90)
+    blob, offs, lens = bytearray(), [], []
+    for d in blocks:
+        blob += bytes(-len(blob) % 16)
+        offs.append(len(blob))
+        lens.append(len(d))
+        blob += d
+    for frame, twin_fn in ((pkg.FRAME_RAW, hdtest.oracle_twin), (pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin)):
+        slot = int(pkg.lib().hipdeflate_bound(max(lens), level))
+        members, crc, st = pkg.batch_deflate(bytes(blob), offs, lens, level, frame, slot=slot)
+        for i, d in enumerate(blocks):
+            assert st[i] == 0, i
+            r, twin = twin_fn(d, level, cap=slot)
+            assert r == 0 and members[i] == twin, (i, len(d), level, frame, len(members[i]), len(twin))
+            assert zlib.decompress(members[i], -15) == d, i
+
+
 @pytest.mark.parametrize("level", [2, 6])
 def test_encode_many_small_blocks_across_sub_batches(pkg, level):
     """70000 blocks of 1000 bytes: more than one parse + emit launch pair of the split path (at most

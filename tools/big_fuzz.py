@@ -1,5 +1,5 @@
 """One-off wide differential run on the GPU box (not part of the test suite: minutes, not seconds):
-for many seeds of tests/hdtest.corpus_fuzz and every level class, kernel bytes == twin bytes, zlib
+for many seeds of tests/hdtest.corpus_fuzz (+ corpus_phrases) and every level class, kernel bytes == twin bytes, zlib
 inflates them, and the kernel's own inflate returns the input; long blocks (flushed segments) too.
 usage: python tools/big_fuzz.py [blocks_per_seed] [seeds...]"""
 import importlib
@@ -20,7 +20,7 @@ seeds = [int(a) for a in sys.argv[2:]] or [11, 12, 13, 14]
 t0 = time.time()
 total = bad = 0
 for seed in seeds:
-    blocks = hdtest.corpus_fuzz(seed, count)
+    blocks = hdtest.corpus_fuzz(seed, count) + hdtest.corpus_phrases(seed, count // 8)
     rng = np.random.default_rng(seed)
     # a few long blocks: random length 330..900 KB made of fuzz blocks back to back
     for _ in range(3):

@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 export TMPDIR=/tmp
 OUT=$1; shift
 mkdir -p $OUT
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc -- python3 bench.py --steps 1 --warmup 0 --gib 2 --tile-mib 16 --no-cpu --no-extra "$@" > $OUT/bench_pmc.log 2>&1
+rocprofv3 --pmc ${HD_PMC:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA} --output-format csv -d $OUT/pmc -- python3 bench.py --steps 1 --warmup 0 --gib 2 --tile-mib 16 --no-cpu --no-extra "$@" > $OUT/bench_pmc.log 2>&1
 python3 - $OUT <<'PY'
 import csv,glob,collections,sys,json
 out=sys.argv[1]
