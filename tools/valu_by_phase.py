@@ -109,6 +109,11 @@ def main():
             tot[k] += v / steps
             if f:
                 wtot[k] += v / steps * f
+    out["long_match_path"] = ("its blocks (the extension loop and the re-threading walk, both inline asm since round 2) are laid out "
+                              "behind the loop's back edge and are not in the counts above; measured instead: PMC per step minus the "
+                              "weighted sum = ~41 SALU + ~12 branches + ~19 VALU per step at 1.27 long matches per step on the "
+                              "FASTQ-like set (twin count), i.e. ~32 scalar + ~10 branch + ~15 vector instructions per long match")
+    out["measured_pmc_per_step"] = "profiles/r02_encode_l1_pmc_summary.json (tools/pmc_quick.sh): VALU 97.6, SALU 73.2, branch 16.0"
     out["sum_static_all_paths_per_step"] = {k: round(v, 1) for k, v in sorted(tot.items())}
     out["sum_weighted_by_frequency_per_step"] = {k: round(v, 1) for k, v in sorted(wtot.items())}
     json.dump(out, sys.stdout, indent=1)
