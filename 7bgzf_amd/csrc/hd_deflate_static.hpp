@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint8_t *const rec = TOK ? split_block(a.scratch, a.split_max, blockIdx.x) : nullptr;
 	uint32_t *const slab = (uint32_t *)rec;
 	uint32_t ntok_slab = 0, db_start = 0, ndb = 0;       // tokens stored; first token / index of the open DEFLATE block
+	int32_t db_room = HD_DYN_BLOCK_TOKENS;               // tokens until the open DEFLATE block may close (stored + queued ones counted)
 
 	Fn8Ident fid;
 	fid.init(lane);
@@ -580,8 +581,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			const uint32_t c3 = K16_EARLY ? qc.c3 : wc[3], c4 = K16_EARLY ? qc.c4 : wc[4];
 			const uint32_t xa = __builtin_amdgcn_alignbyte(p3, p2, p & 3) ^ __builtin_amdgcn_alignbyte(c3, c2, cp & 3);   // bytes 8..11
 			const uint32_t xb = __builtin_amdgcn_alignbyte(p4, p3, p & 3) ^ __builtin_amdgcn_alignbyte(c4, c3, cp & 3);   // bytes 12..15
-			const uint32_t ka = xa ? (uint32_t)__builtin_ctz(xa) >> 3 : 4u, kb = xb ? (uint32_t)__builtin_ctz(xb) >> 3 : 4u;
-			len16 = 8 + (xa ? ka : 4 + kb);
+			// (v_ffbl_b32 of 0 is -1: >> 3 and min 4 turn it into "all four agree"; ka >> 2 is 1 exactly then)
+			uint32_t fa, fb;
+			asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
+			asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
+			const uint32_t ka = (fa >> 3) < 4 ? (fa >> 3) : 4u, kb = (fb >> 3) < 4 ? (fb >> 3) : 4u;
+			len16 = 8 + ka + (ka >> 2) * kb;
 			if (!INNER)
 				len16 = len16 < room ? len16 : room;
 		}
@@ -796,6 +801,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 				tokbuf[sel(tm, qslot, TOKQ + (lane & 31))] = tw;
 			}
 			qtail += (uint32_t)__popcll(tm);
+			if (TOK)
+				db_room -= (int32_t)__popcll(tm);
 		}
 		// (a failed pass -- the stream would pass `limit`, or the slab is full -- clears use_static and the
 		// passes after it do nothing: the steps of a group need no exits between them)
@@ -819,11 +826,14 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		if (lane == 0)
 			((uint32_t *)(rec + lay.off_ntok))[ndb] = ntok_slab - db_start;
 		db_start = ntok_slab;
+		db_room = HD_DYN_BLOCK_TOKENS;
 		ndb++;
 	};
 	// a DEFLATE block closes at the first step boundary with >= 32768 tokens (as the fused kernel)
-	auto step_boundary = [&](uint32_t S) -> bool {
-		if (TOK && use_static && ntok_slab + (qtail - qhead) - db_start >= HD_DYN_BLOCK_TOKENS && S + 64 < n) {
+	// (db_room == HD_DYN_BLOCK_TOKENS - (ntok_slab + queued - db_start); an INNER step is never the last one)
+	auto step_boundary = [&](auto inner_tag, uint32_t S) -> bool {
+		constexpr bool INNER = decltype(inner_tag)::value;
+		if (TOK && db_room <= 0 && use_static && (INNER || S + 64 < n)) {
 			if (qtail != qhead && !emit_tokens(qtail - qhead))
 				return false;
 			close_deflate_block();
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 #pragma unroll
 				for (uint32_t u = 0; u < 4; u++) {
 					step(std::true_type{}, std::true_type{}, S);
-					step_boundary(S);
+					step_boundary(std::true_type{}, S);
 					S += 64;
 				}
 			}
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		}
 		const bool ok_step = (small && S + 192 + 8 <= n) ? step(std::true_type{}, std::false_type{}, S)
 								  : step(std::false_type{}, std::false_type{}, S);
-		if (!ok_step || !step_boundary(S))
+		if (!ok_step || !step_boundary(std::false_type{}, S))
 			break;
 		S += 64;
 	}
