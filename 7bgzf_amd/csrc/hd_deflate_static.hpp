@@ -267,7 +267,6 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// tokens waiting for the emit pass; [TOKQ, TOKQ + 32) = dump slots of lanes without one (two lanes share
 	// a slot: what lands there is never read)
 	__shared__ uint32_t tokbuf[TOK ? TOKQ : TOKQ + 32];
-	const uint8_t *ring8 = (const uint8_t *)ring32;
 	const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ring32;   // LDS byte address of the ring
 
 	const uint32_t lane = threadIdx.x;
@@ -674,7 +673,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 					     : [vb] "v"(pm + lane), [ndm] "s"(0u - dm), [msk] "s"(W - 1), [rb] "v"(ring_lds), [maxlen] "s"(maxlen)
 					     : "vcc", "scc", "memory");
 					len = len < maxlen ? len : maxlen;
-					lenv = lane == m ? len : lenv;
+					// (v_writelane_b32 with the lane select in M0: the one form that may name two scalar operands on
+					// gfx9.  Nothing else in this kernel uses M0 -- LDS instructions do not need it here)
+					asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(lenv) : "s"(len), "s"(m));
 				} else {
 					len = readlane(jumpW, m);            // a continuation lane on its own: its own candidate (or a literal)
 				}
@@ -740,7 +741,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 				}
 				len = len < maxlen ? len : maxlen;
 				if (len > 8) {
-					lenv = lane == m ? len : lenv;
+					// (v_writelane_b32 with the lane select in M0: the one form that may name two scalar operands on
+					// gfx9.  Nothing else in this kernel uses M0 -- LDS instructions do not need it here)
+					asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(lenv) : "s"(len), "s"(m));
 					const uint32_t q = m + len;                   // first lane behind the match
 					// the walk, written out (the compiler spends ~11 scalar instructions per hop on it; here 4 + 2
 					// branches + one v_readlane.  The lane selects of v_readlane / s_bitcmp1 / s_bitset1 take the low
