@@ -498,7 +498,7 @@ def main():
     default_run = (args.mode == "encode" and level == 1 and args.data == "fastq" and not args.block_kib
                    and world == 1 and not args.no_extra and not args.slot and args.gib == 16.0)
     if default_run:
-        xs, xw = min(args.steps, 5), 1
+        xs, xw = min(args.steps, 5), 2
         configs = {}
         res.pop("enc", None), res.pop("packed", None)
         res = None
