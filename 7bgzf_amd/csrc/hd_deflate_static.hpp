@@ -571,9 +571,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// DPP stages)  match: HD_TOKEN_MATCH_TAG | (len - 3) << 16 | (dist - 1), dist - 1 = p - c
 		const uint32_t mw_base = (p + (HD_TOKEN_MATCH_TAG - (3u << 16))) - c;
 		const uint32_t lit = cv0 & 0xff;
-		// K16: length over 16 bytes (valid on the capped lanes)
+		// K16: length over 16 bytes (valid on the capped lanes).  (The level-2 geometry reads the dwords here and is
+		// bound by its instruction count: it skips all of this in a step without a capped lane -- a quarter of the
+		// steps on FASTQ-like data)
 		uint32_t len16 = 8;
-		if (K16) {
+		const bool k16_step = K16 && (K16_EARLY || capmask != 0);
+		if (k16_step) {
 			const uint32_t *wp = &ring32[(p >> 2) & W4M], *wc = &ring32[(cp >> 2) & W4M];
 			const uint32_t c2 = qc.c2;
 			const uint32_t p2 = K16_EARLY ? qc.p2 : wp[2], p3 = K16_EARLY ? qc.p3 : wp[3], p4 = K16_EARLY ? qc.p4 : wp[4];
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		//   jumpA what the automaton sees, jumpW the true length of a token that starts at the lane (16+: 8 for now)
 		uint64_t k8m = 0, par = 0, contm = 0;
 		uint32_t jumpA = jump8, jumpW = jump8;
-		if (K16) {
+		if (k16_step) {
 			k8m = capmask & __ballot(len16 == 16);
 			const uint64_t capk = capmask & ~k8m & __ballot(len16 != 8);
 			par = capk;
