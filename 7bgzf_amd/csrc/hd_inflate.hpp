@@ -121,21 +121,11 @@ struct InfLds {
 		};
 		struct {
 			uint8_t dump[64];                 // a dump slot per lane, right behind the ring
-#ifdef HD_INFLATE_SS
-			uint32_t comp[512];               // 8 pieces of the compressed stream for the batch decoder
-			uint32_t list_tok[1024];          // the batch's tokens in stream order
-			uint16_t list_bit[1024];          // ... and the bit each starts at, from the batch's first bit
-#else
 			uint32_t comp[128];               // 2 pieces of the compressed stream for the window decoder
-#endif
 		};
 	};
 };
-#ifdef HD_INFLATE_SS
-static_assert(sizeof(InfLds) <= 14080, "InfLds must stay within eleven LDS allocation units");
-#else
 static_assert(sizeof(InfLds) == 6400, "InfLds must stay within five LDS allocation units");
-#endif
 constexpr uint32_t INF_T_SCRATCH = 320;      // byte offset in cl of { u32 cnt[16]; u16 first[16]; u16 offs[16]; }
 
 // Build one decode table from code lengths (all 64 lanes).  Returns false for
@@ -365,396 +355,6 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	};
 
 
-#ifdef HD_INFLATE_SS
-	// ---- batch decode: self-synchronising subsequences ---------------------------------------
-	// A window of the other build speculates one decode per input BIT and keeps one in fourteen.  Here every
-	// lane decodes TOKENS, one after the other, in its own G-bit region of the stream:
-	//   pass 1  from the region's first bit (not a token boundary, as a rule) until it leaves the region: Huffman
-	//           streams re-synchronise, so after a few tokens the lane is on the real chain and its exit point is
-	//           the real chain's;
-	//   pass 2  from the exit point of the lane before it (a real boundary if that lane had synchronised) until it
-	//           lands on a boundary its own first pass found -- from there the first pass's tokens are real;
-	//           repeated for the lanes whose start moved (a lane that had NOT synchronised hands on another exit);
-	//   the tokens of the lanes whose starts stand go to an LDS list in stream order (prefix sum of the counts) and
-	//   are placed 128 at a time by the same code that places a window's tokens.
-	// A decode per token instead of per bit: ~3 passes x 50 VALU for the ~5 tokens of every lane.  G follows the
-	// stream (shorter regions where tokens are short) so that a region holds about SS_T * 0.6 tokens.
-	constexpr uint32_t WIN_OUT_BUDGET = 704;
-	constexpr uint32_t SS_T = 16, SS_M = 6, SS_LIST = 1024, SS_RIPPLE = 4, SS_GMAX = 128;
-	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
-	uint32_t lds_p0 = 0xfffffff0u;                // pieces [lds_p0, lds_p0 + 8) are in L.comp
-#ifdef SS_FIXG
-	uint32_t ssG = SS_FIXG;
-#else
-	uint32_t ssG = 96;
-#endif
-	struct Tok {
-		uint32_t w, nb;
-		bool stop;
-	};
-	// the token that starts at absolute bit x: word = literal byte | MATCH(31) | length << 22 | (offset - 1)
-	auto dec1 = [&](uint32_t x) -> Tok {
-		Tok r;
-		const uint32_t di = x >> 5, sh = x & 31;
-		const uint32_t lo = L.comp[di & 511], mid = L.comp[(di + 1) & 511], hi = L.comp[(di + 2) & 511];
-		const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, sh);
-		const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, sh);
-		const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
-		const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
-		const uint32_t length = (e >> 16) + ((a >> len1) & ((1u << eb) - 1));
-		const uint32_t t1 = len1 + eb;                 // <= 9 + 5
-		const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
-		const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
-		const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
-		const uint32_t offset = (dd >> 16) + ((rest >> dlen) & ((1u << deb) - 1));
-		const bool is_len = kind == K_LEN;
-		r.nb = is_len ? t1 + dlen + deb : len1;
-		// long codewords, end of block (and a zero-bit token, which a well-formed table cannot give): not for a batch
-		r.stop = kind == K_SLOW || kind == K_EOB || (is_len && ((dd >> 8) & 3) == K_SLOW) || r.nb == 0;
-		r.w = is_len ? (0x80000000u | (length << 22) | (offset - 1)) : (e >> 16);
-		return r;
-	};
-	auto run_windows = [&](int32_t &st_out) -> uint32_t {
-		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
-		uint32_t result = 0;
-		for (;;) {
-			if (pos - flushed >= HD_PIECE)
-				flush_pieces();
-			if (cap == pos)
-				break;                             // no room left: the scalar loop says so
-			// lanes whose region, the longest token behind it and the three dwords under a decode are whole
-			const uint32_t safe_bits = dw_safe << 5;
-			if (B + 96 + ssG > safe_bits)
-				break;                             // not one whole region: the scalar loop takes the rest
-			uint32_t NL = (uint32_t)((float)(safe_bits - B - 96) / (float)ssG);
-			NL = uniform(NL);
-			while (NL * ssG + B + 96 > safe_bits)
-				NL--;
-			NL = NL < 64 ? NL : 64;
-			const uint32_t G = ssG;
-			{
-				// the stream bits come from an LDS copy of the four pieces around B
-				const uint32_t p0 = B >> 11;
-				const uint32_t from = (p0 >= lds_p0 && p0 < lds_p0 + 8) ? lds_p0 + 8 : p0;
-				for (uint32_t pc = from; pc < p0 + 8; pc++)
-					L.comp[((pc & 7) << 6) + lane] = load_piece(pc);
-				lds_p0 = p0;
-			}
-			// ---- pass 1: from the region's first bit
-			const bool act = lane < NL;
-			const uint32_t s = B + lane * G, endl = s + G;
-			uint32_t tok[SS_T];
-			uint32_t PB[SS_T / 4];                         // bit offsets (from s) of the tokens found, a byte each; ff = none
-#pragma unroll
-			for (uint32_t k = 0; k < SS_T / 4; k++)
-				PB[k] = 0xffffffffu;
-			uint32_t x = s, nt = 0;
-			bool stopf = false;                            // the region's chain ends in front of a token no batch takes
-#pragma unroll
-			for (uint32_t k = 0; k < SS_T; k++) {
-				const bool run = act && x < endl && !stopf;
-				tok[k] = 0;
-				if (!__ballot(run))
-					continue;
-				const Tok tk = dec1(x);
-				if (run) {
-					if (tk.stop) {
-						stopf = true;
-					} else {
-						tok[k] = tk.w;
-						const uint32_t ob = (x - s) << (8 * (k & 3));
-						const uint32_t km = ~(0xffu << (8 * (k & 3)));
-						PB[k >> 2] = (PB[k >> 2] & km) | ob;
-						x += tk.nb;
-						nt = k + 1;
-					}
-				}
-			}
-			const uint32_t e1 = x;                         // where the first pass stopped
-			const bool ovf1 = act && x < endl && !stopf;     // more than SS_T tokens in the region
-			// is bit position y (y - s < 128) one of the boundaries of pass 1?  -> slot index, or 8
-			auto find = [&](uint32_t y) -> uint32_t {
-				const uint32_t off = y - s;
-				const uint32_t bc4 = __builtin_amdgcn_perm(off, off, 0u);        // the low byte four times
-				uint32_t idx = SS_T;
-#pragma unroll
-				for (int g = SS_T / 4 - 1; g >= 0; g--) {
-					const uint32_t t0 = PB[g] ^ bc4;
-					const uint32_t z0 = (t0 - 0x01010101u) & ~t0 & 0x80808080u;
-					idx = z0 ? 4 * g + ((uint32_t)__builtin_ctz(z0) >> 3) : idx;
-				}
-				return off < 128 ? idx : SS_T;
-			};
-			// ---- pass 2: from the exit of the lane before, until the two chains meet
-			uint32_t q[SS_M];
-			uint32_t qn0 = 0, qn1 = 0;                     // bits of the prefix tokens, a byte each
-			uint32_t ex = e1, tprev = 0xffffffffu, m = 0, j = SS_T;
-			bool lstop = stopf;
-#pragma unroll
-			for (uint32_t i = 0; i < SS_M; i++)
-				q[i] = 0;
-			for (uint32_t it = 0; it < SS_RIPPLE; it++) {
-				const uint32_t exl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ex, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-				const uint32_t t = lane == 0 ? B : exl;
-				const bool need = act && t != tprev;
-				if (!__ballot(need))
-					break;
-				uint32_t y = t, mm = 0, jj = SS_T, n0 = 0, n1 = 0;
-				bool done = !need, st2 = false;
-#pragma unroll
-				for (uint32_t i = 0; i <= SS_M; i++) {
-					if (!done) {
-						const uint32_t f = find(y);
-						if (f < nt) {
-							jj = f;
-							done = true;
-						}
-					}
-					if (i == SS_M)
-						break;
-					const bool run = !done && y < endl;
-					if (!__ballot(run))
-						break;
-					const Tok tk = dec1(y);
-					if (run) {
-						if (tk.stop) {
-							st2 = true;
-							done = true;
-						} else {
-							q[i] = tk.w;
-							if (i < 4)
-								n0 |= tk.nb << (8 * (i & 3));
-							else
-								n1 |= tk.nb << (8 * (i & 3));
-							y += tk.nb;
-							mm = i + 1;
-						}
-					}
-				}
-#ifdef HD_INFLATE_STATS
-				if (it == 0) {
-					const uint32_t c_need = (uint32_t)__popcll(__ballot(need)), c_met = (uint32_t)__popcll(__ballot(need && jj < SS_T));
-					const uint32_t c_met0 = (uint32_t)__popcll(__ballot(need && jj < SS_T && mm <= 2));
-					INF_STAT(2, c_need);                   // lanes that ran pass 2
-					INF_STAT(5, c_met);                    // ... and met their own first pass within SS_M tokens
-					INF_STAT(4, c_met0);                   // ... within 2 tokens
-				}
-#endif
-				if (need) {
-					m = mm;
-					j = jj;
-					qn0 = n0;
-					qn1 = n1;
-					ex = jj < SS_T ? e1 : y;
-					lstop = jj < SS_T ? stopf : st2;
-					tprev = t;
-				}
-			}
-			// the lanes whose starts stand: lane 0, and every lane that started where the lane before it ended
-			const uint32_t exl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ex, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-			const uint64_t bad = __ballot(!act || tprev != (lane == 0 ? B : exl));
-			uint32_t V = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1 : 64;     // >= 1: lane 0 starts at B
-			bool bstop = false;
-			{
-				const uint64_t stm = __ballot(lstop) & (V >= 64 ? ~0ull : (1ull << V) - 1);
-				if (stm) {
-					V = (uint32_t)__ffsll((unsigned long long)stm);             // that lane is the last one
-					bstop = true;
-				}
-			}
-			uint32_t c = lane < V ? m + (j < SS_T ? nt - j : 0u) : 0u;
-			uint32_t incl = wave_incl_scan(c);
-			if (readlane(incl, 63) > SS_LIST) {
-				// more tokens than the list holds: the batch ends with the last lane that fits
-				const uint64_t fit = __ballot(incl <= SS_LIST);
-				V = (uint32_t)__popcll(fit);                 // lanes 0 .. V-1 fit (incl is monotonic; a lane holds <= 14)
-				bstop = false;
-				c = lane < V ? c : 0u;
-				incl = wave_incl_scan(c);
-			}
-			const uint32_t N = readlane(incl, 63);
-			const uint32_t Bend = readlane(ex, V - 1) - B;       // bits of the whole batch
-			INF_STAT(0, 1);                    // batches
-			INF_STAT(1, N);                    // tokens listed
-			INF_STAT(6, V);                    // lanes whose starts stood
-			INF_STAT(7, NL);                   // lanes that ran
-			INF_STAT(3, G);                    // region bits
-			// ---- the tokens, in stream order
-			{
-				const uint32_t base = incl - c;
-				uint32_t yq = tprev;
-#pragma unroll
-				for (uint32_t i = 0; i < SS_M; i++) {
-					if (lane < V && i < m) {
-						L.list_tok[(base + i) & (SS_LIST - 1)] = q[i];
-						L.list_bit[(base + i) & (SS_LIST - 1)] = (uint16_t)(yq - B);
-					}
-					yq += ((i < 4 ? qn0 : qn1) >> (8 * (i & 3))) & 0xff;
-				}
-#pragma unroll
-				for (uint32_t k = 0; k < SS_T; k++) {
-					if (lane < V && j < SS_T && k >= j && k < nt) {
-						const uint32_t idx = (base + m + k - j) & (SS_LIST - 1);
-						L.list_tok[idx] = tok[k];
-						L.list_bit[idx] = (uint16_t)(s + ((PB[k >> 2] >> (8 * (k & 3))) & 0xff) - B);
-					}
-				}
-			}
-			// the region size follows the stream: an overflow shortens it, half-empty regions lengthen it
-			{
-				const uint64_t valid = V >= 64 ? ~0ull : (1ull << V) - 1;
-				const uint64_t of = __ballot(ovf1 || (j >= SS_T && m == SS_M && !lstop)) & valid;
-#ifdef SS_FIXG
-				ssG = SS_FIXG;
-				(void)of;
-#else
-				if (of)
-					ssG = ssG > 16 ? ssG - 16 : 8;
-				else if (N < 10 * V && ssG < SS_GMAX)
-					ssG += 8;                  // aim: ten tokens to a region
-#endif
-			}
-			// ---- placement, up to 128 tokens at a time (the window build's code on list entries)
-			uint32_t i0 = 0;
-			bool room = true;
-			while (i0 < N) {
-				if (pos - flushed >= HD_PIECE)
-					flush_pieces();
-				const uint32_t budget = cap - pos < WIN_OUT_BUDGET ? cap - pos : WIN_OUT_BUDGET;
-				const uint32_t left = N - i0;
-				uint64_t real0 = left >= 64 ? ~0ull : (1ull << left) - 1;
-				uint64_t real1 = left >= 128 ? ~0ull : left > 64 ? (1ull << (left - 64)) - 1 : 0ull;
-				const uint32_t w0 = L.list_tok[(i0 + lane) & (SS_LIST - 1)], w1 = L.list_tok[(i0 + 64 + lane) & (SS_LIST - 1)];
-				const uint64_t isl0 = __ballot((int32_t)w0 < 0), isl1 = __ballot((int32_t)w1 < 0);
-				const uint32_t len0 = (w0 >> 22) & 0x1ff, len1 = (w1 >> 22) & 0x1ff;
-				const uint32_t off0 = (w0 & 0x7fff) + 1, off1 = (w1 & 0x7fff) + 1;
-				const uint32_t ol0 = sel(isl0, len0, 1u), ol1 = sel(isl1, len1, 1u);
-				const uint32_t incl0 = wave_incl_scan(sel(real0, ol0, 0u));
-				const uint32_t incl1 = wave_incl_scan(sel(real1, ol1, 0u)) + readlane(incl0, 63);
-				const uint64_t over0 = __ballot(incl0 > budget) & real0;
-				const uint64_t over1 = __ballot(incl1 > budget) & real1;
-				if (over0) {
-					real0 &= (1ull << ((uint32_t)__ffsll((unsigned long long)over0) - 1)) - 1;
-					real1 = 0;
-				} else if (over1) {
-					real1 &= (1ull << ((uint32_t)__ffsll((unsigned long long)over1) - 1)) - 1;
-				}
-				if (real0 == 0) {
-					room = false;                  // not even the first token fits: the scalar loop's checks
-					break;
-				}
-				const uint32_t cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
-							   : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
-				const uint32_t rel0 = incl0 - ol0, rel1 = incl1 - ol1;
-				const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
-				const uint64_t lit0 = real0 & ~isl0, lit1 = real1 & ~isl1;
-				L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)w0;
-				L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)w1;
-				const uint32_t wend = pos + cum;
-				const uint64_t match0 = real0 & isl0, match1 = real1 & isl1;
-				const uint32_t srcl0 = opos0 - off0, srcl1 = opos1 - off1;
-				if ((__ballot(off0 > opos0) & match0) | (__ballot(off1 > opos1) & match1)) {   // decompress_template.h:724
-					st_out = HD_BAD_DATA;
-					result = 2;
-					break;
-				}
-				const uint64_t simple0 = match0 & __ballot(wend - srcl0 <= INF_RING - 64) & __ballot(off0 >= rel0 + len0) &
-							 __ballot(len0 <= 64);
-				const uint64_t simple1 = match1 & __ballot(wend - srcl1 <= INF_RING - 64) & __ballot(off1 >= rel1 + len1) &
-							 __ballot(len1 <= 64);
-				const uint64_t tiny0 = simple0 & __ballot(len0 <= 8), tiny1 = simple1 & __ballot(len1 <= 8);
-				if (tiny0 | tiny1) {
-					const uint32_t nt0 = (uint32_t)__popcll(tiny0), ntiny = nt0 + (uint32_t)__popcll(tiny1);
-					const uint32_t slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny0, 0));
-					const uint32_t slot1 = nt0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny1, 0));
-					const uint32_t pk0 = (opos0 & (INF_RING - 1)) | ((srcl0 & (INF_RING - 1)) << 11) | (len0 << 22);
-					const uint32_t pk1 = (opos1 & (INF_RING - 1)) | ((srcl1 & (INF_RING - 1)) << 11) | (len1 << 22);
-					const uint32_t sub = lane & 7, lead = (lane & ~7u) << 2;
-					for (uint32_t base = 0; base < ntiny; base += 8) {
-						const uint32_t d0 = sel(tiny0, slot0 - base, 8u), d1 = sel(tiny1, slot1 - base, 8u);
-						const uint32_t a0 = d0 < 8 ? d0 << 5 : ((lane | 1u) << 2), a1 = d1 < 8 ? d1 << 5 : ((lane | 1u) << 2);
-						const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < 8 ? pk0 : 0u));
-						const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < 8 ? pk1 : 0u));
-						const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)(g0 | g1));
-						const uint32_t tl = w >> 22;                               // 0: no match in this group
-						const uint8_t v = L.ring[(((w >> 11) & (INF_RING - 1)) + sub) & (INF_RING - 1)];
-						L.ring[sub < tl ? (((w & (INF_RING - 1)) + sub) & (INF_RING - 1)) : INF_RING + lane] = v;
-					}
-				}
-				for (uint64_t sm = simple0 & ~tiny0; sm;) {
-					const uint32_t mi = (uint32_t)__ffsll((unsigned long long)sm) - 1;
-					sm &= sm - 1;
-					const uint32_t mlen = readlane(len0, mi), P = readlane(opos0, mi), srcp = readlane(srcl0, mi);
-					const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
-					L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
-				}
-				for (uint64_t sm = simple1 & ~tiny1; sm;) {
-					const uint32_t mi = (uint32_t)__ffsll((unsigned long long)sm) - 1;
-					sm &= sm - 1;
-					const uint32_t mlen = readlane(len1, mi), P = readlane(opos1, mi), srcp = readlane(srcl1, mi);
-					const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
-					L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
-				}
-				auto copy_general = [&](uint32_t mlen, uint32_t P, uint32_t srcp) {
-					const uint32_t moff = P - srcp;
-					if (wend - srcp <= INF_RING - 64) {
-						if (moff >= mlen) {
-							for (uint32_t i = lane; i < mlen; i += 64)
-								L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + i) & (INF_RING - 1)];
-						} else {
-							const float rcp = 1.0f / (float)moff;
-							for (uint32_t i = lane; i < mlen; i += 64) {
-								uint32_t qq = (uint32_t)((float)i * rcp);
-								uint32_t rr = i - qq * moff;
-								rr = (int32_t)rr < 0 ? rr + moff : rr;
-								rr = rr >= moff ? rr - moff : rr;
-								L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + rr) & (INF_RING - 1)];
-							}
-						}
-					} else {
-						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 1
-						for (uint32_t i = lane; i < mlen; i += 64)
-							L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
-					}
-				};
-				for (uint64_t mq = match0 & ~simple0; mq;) {
-					const uint32_t mi = (uint32_t)__ffsll((unsigned long long)mq) - 1;
-					mq &= mq - 1;
-					copy_general(readlane(len0, mi), readlane(opos0, mi), readlane(srcl0, mi));
-				}
-				for (uint64_t mq = match1 & ~simple1; mq;) {
-					const uint32_t mi = (uint32_t)__ffsll((unsigned long long)mq) - 1;
-					mq &= mq - 1;
-					copy_general(readlane(len1, mi), readlane(opos1, mi), readlane(srcl1, mi));
-				}
-				pos = wend;
-				i0 += (uint32_t)__popcll(real0) + (uint32_t)__popcll(real1);
-			}
-			// the batch's bits that were taken
-			B += i0 == N ? Bend : (uint32_t)uniform(L.list_bit[i0 & (SS_LIST - 1)]);
-			if (result || !room || bstop || i0 < N)
-				break;
-		}
-		// hand the position back to the scalar reader
-		dw = B >> 5;
-		if ((dw >> 6) != cur_piece) {
-			const uint32_t piece = dw >> 6;
-			if (piece == cur_piece + 1)
-				cw = cw_next;
-			else
-				cw = load_piece(piece);
-			cur_piece = piece;
-			cw_next = load_piece(piece + 1);
-		}
-		bb = 0;
-		bc = 0;
-		refill();
-		bb >>= (B & 31);
-		bc -= (B & 31);
-		return result;
-	};
-#else
 	// ---- window decode: 64 speculative tokens per pass -----------------------
 	// The scalar token loop costs ~80 SALU per token on the CU's single scalar ALU.
 	// Here every lane decodes the token that WOULD start at bit B + lane (two LDS
@@ -1007,8 +607,6 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		bc -= (B & 31);
 		return result;
 	};
-
-#endif
 
 	int32_t st = HD_OK;
 	bool static_loaded = false;
