@@ -384,11 +384,15 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				break;
 			// the stream bits come from an LDS copy of the pieces around d0 (every lane
 			// reads its own dwords: no scalar gather)
+			// (piece p0 always sits in comp[0,64) and p0 + 1 in comp[64,128): the five dwords under a lane's two
+			// decodes are consecutive and never wrap -- one address, three LDS reads for both)
 			const uint32_t p0 = d0 >> 6;
 			if (p0 != lds_p0) {
-				if (p0 != lds_p0 + 1)
-					L.comp[((p0 & 1) << 6) + lane] = load_piece(p0);
-				L.comp[(((p0 + 1) & 1) << 6) + lane] = load_piece(p0 + 1);
+				if (p0 == lds_p0 + 1)
+					L.comp[lane] = L.comp[64 + lane];
+				else
+					L.comp[lane] = load_piece(p0);
+				L.comp[64 + lane] = load_piece(p0 + 1);
 				lds_p0 = p0;
 			}
 			// A window is 128 bits: every lane decodes the token that would start at bit
@@ -398,10 +402,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				uint32_t e, length, offset, outlen, walk;
 				bool is_len, is_lit;
 			};
-			auto spec = [&](uint32_t bl) -> Spec {                // bl = bit offset from dword d0
+			// dwords w[0..4] under bit (B & 31) + lane: the "lo" decode reads w[0..2], the "hi" one (64 bits on) w[2..4]
+			const uint32_t bl0 = (B & 31) + lane;
+			const uint32_t *wsp = &L.comp[(d0 & 63) + (bl0 >> 5)];
+			const uint32_t ws0 = wsp[0], ws1 = wsp[1], ws2 = wsp[2], ws3 = wsp[3], ws4 = wsp[4];
+			auto spec = [&](uint32_t bl, uint32_t lo, uint32_t mid, uint32_t hi) -> Spec {   // bl = bit offset from dword d0
 				Spec r;
-				const uint32_t di = d0 + (bl >> 5);
-				const uint32_t lo = L.comp[di & 127], mid = L.comp[(di + 1) & 127], hi = L.comp[(di + 2) & 127];
 				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
 				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
 				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				r.walk = tokbits | ((slow || kind == K_EOB || tokbits == 0) ? 64u : 0u);
 				return r;
 			};
-			const Spec s0 = spec((B & 31) + lane), s1 = spec((B & 31) + lane + 64);
+			const Spec s0 = spec(bl0, ws0, ws1, ws2), s1 = spec(bl0 + 64, ws2, ws3, ws4);
 
 			// The real chain from bit 0 of the window.  This walk is the hottest scalar
 			// code of the kernel (the CU has one scalar ALU) and the compiler spends ~20
