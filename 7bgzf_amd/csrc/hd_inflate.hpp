@@ -413,12 +413,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
 				const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
 				r.e = e;
-				r.length = (e >> 16) + ((a >> len1) & ((1u << eb) - 1));
+				r.length = (e >> 16) + __builtin_amdgcn_ubfe(a, len1, eb);         // (one v_bfe_u32; width 0 gives 0)
 				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
 				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
 				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
 				const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
-				r.offset = (dd >> 16) + ((rest >> dlen) & ((1u << deb) - 1));
+				r.offset = (dd >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
 				r.is_len = kind == K_LEN;
 				r.is_lit = kind == K_LIT;
 				const bool slow = kind == K_SLOW || (r.is_len && ((dd >> 8) & 3) == K_SLOW);
