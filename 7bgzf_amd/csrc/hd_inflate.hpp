@@ -411,22 +411,26 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
 				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
 				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
-				const uint32_t len1 = e & 15, kind = (e >> 8) & 3, eb = (e >> 4) & 15;
+				const uint32_t len1 = e & 15, eb = (e >> 4) & 15;
 				r.e = e;
 				r.length = (e >> 16) + __builtin_amdgcn_ubfe(a, len1, eb);         // (one v_bfe_u32; width 0 gives 0)
 				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
 				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
 				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
-				const uint32_t dlen = dd & 15, deb = (dd >> 4) & 15;
-				r.offset = (dd >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
-				r.is_len = kind == K_LEN;
-				r.is_lit = kind == K_LIT;
-				const bool slow = kind == K_SLOW || (r.is_len && ((dd >> 8) & 3) == K_SLOW);
-				const uint32_t tokbits = r.is_len ? t1 + dlen + deb : len1;
+				r.is_len = (e & 0x300) == (K_LEN << 8);
+				r.is_lit = (e & 0x300) == (K_LIT << 8);
+				// (the offset entry counts for a length only: masked here, its fields are zero elsewhere -- and so is
+				// eb in a literal's or an end-of-block's entry, so the token's bits are one sum)
+				const uint32_t ddm = r.is_len ? dd : 0u;
+				const uint32_t dlen = ddm & 15, deb = (ddm >> 4) & 15;
+				r.offset = (ddm >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
+				const uint32_t tokbits = t1 + dlen + deb;
 				r.outlen = r.is_lit ? 1u : r.is_len ? r.length : 0u;
-				// bit 6 = the walk stops in front of this token (long codeword, end of block; a
-				// zero-bit token cannot come out of a well-formed table, but it would not advance)
-				r.walk = tokbits | ((slow || kind == K_EOB || tokbits == 0) ? 64u : 0u);
+				// bit 6 = the walk stops in front of this token: bit 9 of either entry (K_EOB and K_SLOW have it)
+				// moved down.  (A zero-bit token cannot come out of a well-formed table; the max keeps the walk
+				// moving whatever the table holds.)
+				const uint32_t tb1 = tokbits ? tokbits : 1u;
+				r.walk = tb1 | ((e >> 3) & 64u) | ((ddm >> 3) & 64u);
 				return r;
 			};
 			const Spec s0 = spec(bl0, ws0, ws1, ws2), s1 = spec(bl0 + 64, ws2, ws3, ws4);
@@ -467,9 +471,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// output positions; cut in front of the first token that would overrun the budget.  (Conditions are
 			// 64-bit lane masks: the ballot of ONE compare each, combined in scalar code, back to the lanes
 			// through sel() -- hd_device.hpp "lane masks".)
-			const uint32_t o0 = sel(real0, s0.outlen, 0u);
-			const uint32_t incl0 = wave_incl_scan(o0);
-			const uint32_t incl1 = wave_incl_scan(sel(real1, s1.outlen, 0u)) + readlane(incl0, 63);
+			// (both halves' output lengths in one prefix sum, 16 bits each: 64 x 258 < 2^16)
+			const uint32_t scn = wave_incl_scan(sel(real0, s0.outlen, 0u) | (sel(real1, s1.outlen, 0u) << 16));
+			const uint32_t incl0 = scn & 0xffff;
+			const uint32_t incl1 = (scn >> 16) + readlane(incl0, 63);
 			const uint64_t over0 = __ballot(incl0 > budget) & real0;
 			const uint64_t over1 = __ballot(incl1 > budget) & real1;
 			if (over0 | over1) {
