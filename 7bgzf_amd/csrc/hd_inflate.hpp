@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// window halve the scalar glue per token, which is what bounds this kernel.
 			struct Spec {
 				uint32_t e, length, offset, outlen, walk;
-				bool is_len, is_lit;
+				uint64_t is_len, is_lit;             // lane masks (one v_cmp each, used through sel())
 			};
 			// dwords w[0..4] under bit (B & 31) + lane: the "lo" decode reads w[0..2], the "hi" one (64 bits on) w[2..4]
 			const uint32_t bl0 = (B & 31) + lane;
@@ -417,15 +417,16 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
 				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
 				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
-				r.is_len = (e & 0x300) == (K_LEN << 8);
-				r.is_lit = (e & 0x300) == (K_LIT << 8);
+				const uint32_t kind2 = e & 0x300;
+				r.is_len = __ballot(kind2 == (K_LEN << 8));
+				r.is_lit = __ballot(kind2 == (K_LIT << 8));
 				// (the offset entry counts for a length only: masked here, its fields are zero elsewhere -- and so is
 				// eb in a literal's or an end-of-block's entry, so the token's bits are one sum)
-				const uint32_t ddm = r.is_len ? dd : 0u;
+				const uint32_t ddm = sel(r.is_len, dd, 0u);
 				const uint32_t dlen = ddm & 15, deb = (ddm >> 4) & 15;
 				r.offset = (ddm >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
 				const uint32_t tokbits = t1 + dlen + deb;
-				r.outlen = r.is_lit ? 1u : r.is_len ? r.length : 0u;
+				r.outlen = sel(r.is_lit, 1u, sel(r.is_len, r.length, 0u));
 				// bit 6 = the walk stops in front of this token: bit 9 of either entry (K_EOB and K_SLOW have it)
 				// moved down.  (A zero-bit token cannot come out of a well-formed table; the max keeps the walk
 				// moving whatever the table holds.)
@@ -499,14 +500,19 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid on the real tokens
 			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
 			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
-			const uint64_t lit0 = real0 & __ballot(s0.is_lit), lit1 = real1 & __ballot(s1.is_lit);
+			const uint64_t lit0 = real0 & s0.is_lit, lit1 = real1 & s1.is_lit;
 			L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s0.e >> 16);
 			L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s1.e >> 16);
 			const uint32_t wend = pos + cum;
 			// per-lane verdicts for the matches, so that the scalar loops below only dispatch
-			const uint64_t match0 = real0 & __ballot(s0.is_len), match1 = real1 & __ballot(s1.is_len);
+			const uint64_t match0 = real0 & s0.is_len, match1 = real1 & s1.is_len;
 			const uint32_t srcl0 = opos0 - s0.offset, srcl1 = opos1 - s1.offset;   // wrap when offset > opos
-			if ((__ballot(s0.offset > opos0) & match0) | (__ballot(s1.offset > opos1) & match1)) {   // decompress_template.h:724
+			// (one v_cmp each: written out, or the compiler takes the carry of the subtraction above and turns it
+			// back into a mask with two more instructions)
+			uint64_t far0, far1;
+			asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far0) : "v"(opos0), "v"(s0.offset));
+			asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far1) : "v"(opos1), "v"(s1.offset));
+			if ((far0 & match0) | (far1 & match1)) {   // offset > bytes out so far: decompress_template.h:724
 				st_out = HD_BAD_DATA;
 				result = 2;
 				break;
