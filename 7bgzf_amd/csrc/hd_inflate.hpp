@@ -552,14 +552,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// (copying the longer ones two at a time, both reads ahead of both writes, measured 2 % slower)
 			for (uint64_t sm = simple0 & ~tiny0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
-				sm &= sm - 1;
+				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
 			for (uint64_t sm = simple1 & ~tiny1; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
-				sm &= sm - 1;
+				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
@@ -591,12 +591,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			};
 			for (uint64_t mm = match0 & ~simple0; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
-				mm &= mm - 1;
+				asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(m));
 				copy_general(readlane(s0.outlen, m), readlane(opos0, m), readlane(srcl0, m));
 			}
 			for (uint64_t mm = match1 & ~simple1; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
-				mm &= mm - 1;
+				asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(m));
 				copy_general(readlane(s1.outlen, m), readlane(opos1, m), readlane(srcl1, m));
 			}
 			pos = wend;
