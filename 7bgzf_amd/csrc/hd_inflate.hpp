@@ -474,11 +474,15 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// through sel() -- hd_device.hpp "lane masks".)
 			// (both halves' output lengths in one prefix sum, 16 bits each: 64 x 258 < 2^16)
 			const uint32_t scn = wave_incl_scan(sel(real0, s0.outlen, 0u) | (sel(real1, s1.outlen, 0u) << 16));
+			const uint32_t tot = readlane(scn, 63);                   // the totals of both halves
 			const uint32_t incl0 = scn & 0xffff;
-			const uint32_t incl1 = (scn >> 16) + readlane(incl0, 63);
-			const uint64_t over0 = __ballot(incl0 > budget) & real0;
-			const uint64_t over1 = __ballot(incl1 > budget) & real1;
-			if (over0 | over1) {
+			const uint32_t incl1 = (scn >> 16) + (tot & 0xffff);
+			// (the usual window fits its budget whole: one scalar compare, and the total is its output)
+			uint32_t cum = (tot & 0xffff) + (tot >> 16);
+			const bool over = cum > budget;
+			if (over) {
+				const uint64_t over0 = __ballot(incl0 > budget) & real0;
+				const uint64_t over1 = __ballot(incl1 > budget) & real1;
 				if (over0) {
 					b = (uint32_t)__ffsll((unsigned long long)over0) - 1;
 					real0 &= (1ull << b) - 1;
@@ -488,6 +492,9 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					real1 &= (1ull << f) - 1;
 					b = 64 + f;
 				}
+				if (real0)
+					cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
+						    : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
 			}
 			INF_STAT(0, 1);
 			if (real0 == 0) {
@@ -495,8 +502,6 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				break;                                     // the token at B is not for a window: scalar loop
 			}
 			INF_STAT(1, __popcll(real0) + __popcll(real1));
-			const uint32_t cum = real1 ? readlane(incl1, 63 - (uint32_t)__clzll((long long)real1))
-						   : readlane(incl0, 63 - (uint32_t)__clzll((long long)real0));
 			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid on the real tokens
 			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
 			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			B += b;
 			// the walk stopped in front of a token no window takes (long codeword, end of block): a new
 			// window there would come back empty (6 % of all windows did) -- the scalar loop is next
-			if ((wm & 64) && !(over0 | over1))
+			if ((wm & 64) && !over)
 				break;
 		}
 		// hand the position back to the scalar reader
