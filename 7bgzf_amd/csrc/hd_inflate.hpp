@@ -525,10 +525,53 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// "simple": source wholly in the ring and wholly in front of this window's output,
 			// at most 64 bytes.  Nothing in the window feeds them, so they go first and in any order;
 			// whatever else there is follows in stream order.
-			const uint64_t simple0 = match0 & __ballot(wend - srcl0 <= INF_RING - 64) & __ballot(s0.offset >= rel0 + s0.length) &
-						 __ballot(s0.length <= 64);
-			const uint64_t simple1 = match1 & __ballot(wend - srcl1 <= INF_RING - 64) & __ballot(s1.offset >= rel1 + s1.length) &
-						 __ballot(s1.length <= 64);
+			const uint64_t inr0 = __ballot(wend - srcl0 <= INF_RING - 64), inr1 = __ballot(wend - srcl1 <= INF_RING - 64);
+			const uint64_t le0 = __ballot(s0.length <= 64), le1 = __ballot(s1.length <= 64);
+			const uint64_t simple0 = match0 & inr0 & __ballot(s0.offset >= rel0 + s0.length) & le0;
+			const uint64_t simple1 = match1 & inr1 & __ballot(s1.offset >= rel1 + s1.length) & le1;
+			// "far": the source left the ring long ago (it ends >= 1217 bytes in front of this window and is flushed:
+			// pending < 1024, budget <= 704) -- nothing in the window feeds it either, but a load from HBM takes ~700 ns.
+			// A libdeflate-6 stream of FASTQ-like data has several per window (5 vector loads per 64 output bytes,
+			// 54 % of a wave's cycles parked on s_waitcnt): their loads all go out HERE, up to four at a time, and
+			// the bytes are put into the ring behind the ring-to-ring copies below instead of one round trip each.
+			const uint64_t hbm0 = match0 & ~inr0 & le0, hbm1 = match1 & ~inr1 & le1;
+			uint64_t fa = hbm0, fb = hbm1;
+			// (FARK in flight; every one holds a register, and at 81 the kernel would lose a wave per SIMD -- the offset
+			// table's copy in registers made room: the scalar loop reads it from LDS now)
+			constexpr int FARK = 2;
+			uint32_t fml[FARK], fP[FARK], fv[FARK];
+			auto far_issue = [&]() {
+#pragma unroll
+				for (int k = 0; k < FARK; k++) {
+					uint32_t sp = 0;
+					fml[k] = 0;
+					fP[k] = 0;
+					if (fa) {
+						const uint32_t m = (uint32_t)__ffsll((unsigned long long)fa) - 1;
+						asm("s_bitset0_b64 %0, %1" : "+s"(fa) : "s"(m));
+						fml[k] = readlane(s0.outlen, m);
+						fP[k] = readlane(opos0, m);
+						sp = readlane(srcl0, m);
+					} else if (fb) {
+						const uint32_t m = (uint32_t)__ffsll((unsigned long long)fb) - 1;
+						asm("s_bitset0_b64 %0, %1" : "+s"(fb) : "s"(m));
+						fml[k] = readlane(s1.outlen, m);
+						fP[k] = readlane(opos1, m);
+						sp = readlane(srcl1, m);
+					}
+					fv[k] = lane < fml[k] ? (uint32_t)dst[sp + lane] : 0u;
+				}
+			};
+			auto far_store = [&]() {
+#pragma unroll
+				for (int k = 0; k < FARK; k++)
+					L.ring[lane < fml[k] ? ((fP[k] + lane) & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)fv[k];
+			};
+			const bool anyfar = (hbm0 | hbm1) != 0;
+			if (anyfar) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // our own stores first
+				far_issue();
+			}
 			// The short ones among them (<= 8 bytes: most matches of a DEFLATE stream) are copied EIGHT AT A TIME, a
 			// group of eight lanes per match: every owner pushes {destination, source, length} to the first lane
 			// of its group (ds_permute), the group fetches it (ds_bpermute), one byte per lane moves.  No scalar
@@ -594,12 +637,19 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
 				}
 			};
-			for (uint64_t mm = match0 & ~simple0; mm;) {
+			if (anyfar) {
+				far_store();
+				while (fa | fb) {
+					far_issue();
+					far_store();
+				}
+			}
+			for (uint64_t mm = match0 & ~simple0 & ~hbm0; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(m));
 				copy_general(readlane(s0.outlen, m), readlane(opos0, m), readlane(srcl0, m));
 			}
-			for (uint64_t mm = match1 & ~simple1; mm;) {
+			for (uint64_t mm = match1 & ~simple1 & ~hbm1; mm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)mm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(mm) : "s"(m));
 				copy_general(readlane(s1.outlen, m), readlane(opos1, m), readlane(srcl1, m));
@@ -636,16 +686,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	// entry i lives in lane i & 63 of register i >> 6, a lookup is one relative
 	// v_mov (s_set_gpr_idx) + v_readlane -- no LDS round trip per symbol.
 	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 	u32x8 LT;
-	u32x4 DT;
 	auto load_tables = [&]() {
 #pragma unroll
 		for (int r = 0; r < (1 << INF_LT_BITS) / 64; r++)
 			LT[r] = L.lit[r * 64 + lane];
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-			DT[r] = L.off[r * 64 + lane];
 	};
 
 	INF_T0(t_kernel);
@@ -807,7 +852,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				if (length > cap - pos) { st = HD_INSUFFICIENT_SPACE; break; }
 				refill();
 				const uint32_t di = (uint32_t)bb & ((1u << INF_DT_BITS) - 1);
-				uint32_t d = readlane(DT[di >> 6], di & 63);
+				uint32_t d = uniform(L.off[di]);                 // (LDS: one token in 130 comes this way, its copy in four registers cost a wave)
 				if (((d >> 8) & 3) == K_SLOW) {
 					INF_STAT(4, 1);
 					const uint32_t sl = uniform(slow_decode(bb, L.off_count, L.off_sorted, lane));
