@@ -122,14 +122,25 @@ void build_crc_tables(CrcTables *t)
 	for (int k = 1; k < 4; k++)
 		for (uint32_t i = 0; i < 256; i++)
 			t->T[k][i] = (t->T[k - 1][i] >> 8) ^ t->T[0][t->T[k - 1][i] & 0xff];
-	// B[k][v]: state (v << 8k) after 1008 zero bytes
+	// B[k][v]: state (v << 8k) after 1024 zero bytes; B16: after 16; BL: after 1008
 	for (int k = 0; k < 4; k++)
 		for (uint32_t i = 0; i < 256; i++) {
 			uint32_t s = i << (8 * k);
-			for (int z = 0; z < 1008; z++)
+			for (int z = 0; z < 1024; z++) {
+				if (z == 16)
+					t->B16[k][i] = s;
+				if (z == 1008)
+					t->BL[k][i] = s;
 				s = t->T[0][s & 0xff] ^ (s >> 8);
+			}
 			t->B[k][i] = s;
 		}
+	// T16[j][b]: byte b followed by j zero bytes (slicing-by-16)
+	for (uint32_t i = 0; i < 256; i++)
+		t->T16[0][i] = t->T[0][i];
+	for (int j = 1; j < 16; j++)
+		for (uint32_t i = 0; i < 256; i++)
+			t->T16[j][i] = (t->T16[j - 1][i] >> 8) ^ t->T[0][t->T16[j - 1][i] & 0xff];
 	// SL: static litlen codes (RFC 1951 3.2.6), bit-reversed, length extra bits appended, bit count << 16
 	{
 		auto rev = [](uint32_t c, int bits) {

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			((uint4 *)ring32)[ro / 16 + lane] = v;
 			if (ro == 0 && lane == 0)
 				((uint4 *)ring32)[W / 16] = v;
-			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+			crc.template fold<true>(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 		};
 		struct Fetched {
 			uint32_t v, vh, c;
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			filled += HD_PIECE;
 			if (filled < n)
 				pre = load_slot(src, n, piece + 1, lane, aligned);
-			crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
+			crc.template fold<true>(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
 		}
 		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 		} else {

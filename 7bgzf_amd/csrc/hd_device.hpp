@@ -12,7 +12,7 @@ namespace hd {
 // CRC-32 folding tables, built once on the host (hd_api.hip) and kept in HBM;
 // 8.25 KiB, L1/L2 resident on every CU.
 //   T[k][v] : slicing-by-4 tables of the reflected IEEE polynomial
-//   B[k][v] : "append 1008 zero bytes" to the state byte v << 8k
+//   B[k][v] : "append 1024 zero bytes" to the state byte v << 8k (B16: 16 zero bytes)
 //   K[q]    : x^(128 q) mod P, q = 0..63, for the final per-lane alignment
 //   SL[i]   : the static litlen code of RFC 1951 3.2.6, ready to OR into an LSB-first stream:
 //             bits 0..15 the codeword (bit-reversed) and, for lengths, its extra bits behind it, bits 16..20
@@ -23,7 +23,10 @@ namespace hd {
 //             hd_segment.hpp folds the CRC-32 of a member from its segments' with one lookup per segment.
 struct CrcTables {
 	uint32_t T[4][256];
-	uint32_t B[4][256];
+	uint32_t B[4][256];           // "append 1024 zero bytes" (a piece), byte-sliced like P2 / SM
+	uint32_t B16[4][256];         // "append 16 zero bytes" (a lane's slot)
+	uint32_t BL[4][256];          // "append 1008 zero bytes" (the CHAIN form of CrcLanes::fold)
+	uint32_t T16[16][256];        // slicing-by-16: T16[j][b] = byte b followed by j zero bytes
 	uint32_t K[64];
 	uint32_t SL[512];
 	uint32_t P2[24][4][256];
@@ -204,11 +207,6 @@ __device__ __forceinline__ uint32_t crc_step4(const CrcTables *ct, uint32_t s, u
 	return ct->T[3][s & 0xff] ^ ct->T[2][(s >> 8) & 0xff] ^ ct->T[1][(s >> 16) & 0xff] ^ ct->T[0][s >> 24];
 }
 
-__device__ __forceinline__ uint32_t crc_skip1008(const CrcTables *ct, uint32_t s)
-{
-	return ct->B[0][s & 0xff] ^ ct->B[1][(s >> 8) & 0xff] ^ ct->B[2][(s >> 16) & 0xff] ^ ct->B[3][s >> 24];
-}
-
 // one of the byte-sliced "append zero bytes" operators (P2[j], SM[s][m]) applied to a CRC state
 __device__ __forceinline__ uint32_t crc_shift(const uint32_t (*Z)[256], uint32_t s)
 {
@@ -241,14 +239,36 @@ struct CrcLanes {
 	{
 		s = (lane == 0 && n >= 16) ? 0xffffffffu : 0u;
 	}
+	// CHAIN: the same value with four loads in flight instead of twenty (the fused dynamic kernel sits at its
+	// register budget): skip 1008 zero bytes, then four dependent slicing-by-4 steps
+	template <bool CHAIN = false>
 	__device__ __forceinline__ void fold(const CrcTables *ct, uint32_t piece, bool full, uint4 v)
 	{
+		if (CHAIN) {
+			if (full) {
+				uint32_t t = s;
+				if (piece)
+					t = ct->BL[0][s & 0xff] ^ ct->BL[1][(s >> 8) & 0xff] ^ ct->BL[2][(s >> 16) & 0xff] ^ ct->BL[3][s >> 24];
+				t = crc_step4(ct, t, v.x);
+				t = crc_step4(ct, t, v.y);
+				t = crc_step4(ct, t, v.z);
+				s = crc_step4(ct, t, v.w);
+			}
+			return;
+		}
 		if (full) {
-			uint32_t t = piece ? crc_skip1008(ct, s) : s;
-			t = crc_step4(ct, t, v.x);
-			t = crc_step4(ct, t, v.y);
-			t = crc_step4(ct, t, v.z);
-			s = crc_step4(ct, t, v.w);
+			// CRC is linear: the state moved on by a piece (or, in the first piece, by the slot's 16 bytes) XOR the
+			// slot's own 16 bytes by slicing-by-16 -- twenty table loads that do not wait for one another.  (The
+			// chain it replaces, skip 1008 bytes then four slicing-by-4 steps, was five dependent rounds of loads
+			// from global memory, ~3000 cycles per piece per wave.)
+			const uint32_t (*Z)[256] = piece ? ct->B : ct->B16;
+			uint32_t t = Z[0][s & 0xff] ^ Z[1][(s >> 8) & 0xff] ^ Z[2][(s >> 16) & 0xff] ^ Z[3][s >> 24];
+			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				t ^= ct->T16[15 - 4 * k][w[k] & 0xff] ^ ct->T16[14 - 4 * k][(w[k] >> 8) & 0xff] ^
+				     ct->T16[13 - 4 * k][(w[k] >> 16) & 0xff] ^ ct->T16[12 - 4 * k][w[k] >> 24];
+			s = t;
 		}
 	}
 	// tail = the < 16 bytes after the last full slot
