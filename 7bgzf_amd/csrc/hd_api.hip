@@ -1365,6 +1365,18 @@ int hipdeflate_test_emit_stats(uint64_t *out8)
 }
 #endif
 
+#ifdef HD_CLOCK_STAMPS
+// diagnostic build: per kernel { shader cycles, 100 MHz ticks, waves, - } summed over the waves since the last call
+int hipdeflate_test_clock(uint64_t *out16)
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hd::g_clk), 128));
+	static const uint64_t zero[16] = { 0 };
+	HD_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hd::g_clk), zero, 128));
+	return 0;
+}
+#endif
+
 #ifdef HD_INFLATE_STATS
 int hipdeflate_test_inflate_stats(uint64_t *out8)
 {

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	__shared__ uint32_t tokq[EMIT ? 1 : TOKQ];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 	const uint32_t lane = threadIdx.x;
+	const ClockStamp clk(HD_CLK_DYNAMIC);
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
 

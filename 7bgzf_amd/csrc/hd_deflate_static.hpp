@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const uint32_t b = a.first + blockIdx.x;
 	if (b >= a.nblocks)
 		return;
+	const ClockStamp clk(TOK ? HD_CLK_PARSE : HD_CLK_STATIC);
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
 	if (TOK && n > a.split_max) {

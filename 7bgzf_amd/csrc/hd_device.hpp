@@ -33,6 +33,38 @@ struct CrcTables {
 	uint32_t SM[3][16][4][256];
 };
 
+// ---- in-kernel clock (diagnostic build only: EXTRA=-DHD_CLOCK_STAMPS) -----------------------------------------
+// MI355X_MICROARCH.md "DVFS give-back" item 6: the clock a kernel really runs at is delta s_memtime (shader cycles)
+// over delta s_memrealtime (100 MHz), stamped once around the whole wave.  The sums go to a buffer of their own that
+// nothing in the kernels reads (hipdeflate_test_clock() copies and clears it); in the product build ClockStamp is
+// empty and no stamp executes.
+#ifdef HD_CLOCK_STAMPS
+__device__ unsigned long long g_clk[4][4];      // [kernel]{ sum of cycles, sum of 100 MHz ticks, waves, - }
+struct ClockStamp {
+	unsigned long long t0, r0;
+	int k;
+	__device__ __forceinline__ ClockStamp(int kernel) : k(kernel)
+	{
+		asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
+	}
+	__device__ __forceinline__ ~ClockStamp()
+	{
+		unsigned long long t1, r1;
+		asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+		if (threadIdx.x == 0) {
+			atomicAdd(&g_clk[k][0], t1 - t0);
+			atomicAdd(&g_clk[k][1], r1 - r0);
+			atomicAdd(&g_clk[k][2], 1ull);
+		}
+	}
+};
+#else
+struct ClockStamp {
+	__device__ __forceinline__ ClockStamp(int) {}
+};
+#endif
+enum { HD_CLK_STATIC = 0, HD_CLK_DYNAMIC = 1, HD_CLK_INFLATE = 2, HD_CLK_PARSE = 3 };
+
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v)
 {

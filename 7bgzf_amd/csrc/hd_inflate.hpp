@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	const uint32_t b = blockIdx.x;
 	if (b >= a.nblocks)
 		return;
+	const ClockStamp clk(HD_CLK_INFLATE);
 	const uint8_t *src = a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
 	if (n >= HD_INFLATE_MAX_IN) {
