@@ -110,6 +110,24 @@ struct Ctx {
 Ctx g;
 std::mutex g_init_mu;
 
+} // namespace
+int hd_probe_lds_order(void);        // hd_selftest.hip
+namespace {
+// the per-block codecs' pool of latency contexts (deflate_one below), closed by hipdeflate_shutdown()
+constexpr int CODEC_LEVELS = 13;                          // levels 0..12 (the kernels clamp above 9)
+constexpr size_t CODEC_POOL_MAX = 64;                     // idle contexts kept per level (~200 KiB pinned each)
+std::mutex g_codec_mu;
+std::vector<hipdeflate_lat *> g_codec_free[CODEC_LEVELS];
+void codec_pool_drain()
+{
+	std::lock_guard<std::mutex> lk(g_codec_mu);
+	for (std::vector<hipdeflate_lat *> &f : g_codec_free) {
+		for (hipdeflate_lat *c : f)
+			hipdeflate_lat_close(c);
+		f.clear();
+	}
+}
+
 void build_crc_tables(CrcTables *t)
 {
 	const uint32_t poly = 0xEDB88320u;
@@ -248,6 +266,19 @@ int ctx_init(int device)
 	HD_CHECK(hipMalloc((void **)&g.d_ct, sizeof(CrcTables)));
 	HD_CHECK(hipMemcpy(g.d_ct, h, sizeof(CrcTables), hipMemcpyHostToDevice));
 	free(h);
+	// Several lanes' ds_write_b16 to one table entry in one instruction: the highest lane's data must stay (the parse
+	// kernels and their CPU twin lean on it, hd_deflate_static.hpp fetch()).  Probed once per process: on a device
+	// that arbitrates differently the streams would still be valid DEFLATE but not the twin's bytes, and ranks of one
+	// job could disagree -- refused rather than run.
+	if (const int bad = hd_probe_lds_order()) {
+		fprintf(stderr, "hipdeflate: device %d failed the LDS store-order probe (%d); this build's encoders are not "
+			"reproducible on it and refuse to run\n", device, bad);
+		(void)hipFree(g.d_ct);
+		g.d_ct = nullptr;
+		(void)hipStreamDestroy(g.stream);
+		g.stream = nullptr;
+		return g.failed = HD_E_NODEVICE;
+	}
 	g.device = device;
 	snprintf(g.desc, sizeof(g.desc), "hipdeflate 0.1 on device %d: %s (%s), %d CUs, %.0f GiB", device, prop.name,
 		 prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
@@ -315,6 +346,7 @@ void hipdeflate_shutdown(void)
 		return;
 	(void)hipSetDevice(g.device);
 	(void)hipDeviceSynchronize();                        // launches on callers' streams may still use our scratch
+	codec_pool_drain();                                  // the per-block codecs' latency contexts
 	for (Buf *b : { &g.d_in, &g.d_meta, &g.d_slots, &g.d_packed, &g.d_scratch, &g.d_scan, &g.h_in, &g.h_meta,
 			&g.h_out, &g.d_tok, &g.d_tiles })
 		b->release();
@@ -709,6 +741,7 @@ int hipdeflate_batch_inflate_flush(const uint8_t *in, const uint64_t *in_off, co
 
 struct PipeSlot {
 	Buf h_in{ nullptr, 0, true }, h_out{ nullptr, 0, true }, h_meta{ nullptr, 0, true };
+	std::vector<uint64_t> doff;      // member offsets of the held result, 8-byte aligned (pipe_members)
 	Buf d_in, d_meta, d_slots, d_packed;
 	hipStream_t st = nullptr;
 	size_t nbytes = 0;
@@ -860,6 +893,9 @@ int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nby
 		uint64_t t64;
 		memcpy(&t64, (const uint8_t *)s.h_meta.p + (size_t)20 * s.nb, 8);
 		total = (size_t)t64;
+		// (doff[] sits 12 nb bytes into the pinned table: only 4-byte aligned for an odd nb)
+		s.doff.resize(s.nb);
+		memcpy(s.doff.data(), (const uint8_t *)s.h_meta.p + (size_t)12 * s.nb, (size_t)8 * s.nb);
 		for (uint32_t i = 0; i < s.nb; i++)
 			bad |= h_st[i] != 0;
 		HD_CHECK(hipMemcpyAsync(s.h_out.p, s.d_packed.p, total, hipMemcpyDeviceToHost, s.st));
@@ -886,12 +922,13 @@ int hipdeflate_pipe_members(hipdeflate_pipe *p, const uint32_t **out_len, const 
 	const PipeSlot &s = p->slots[p->held];
 	// the layout pipe_submit() copied back: olen[nb], crc[nb], status[nb], doff[nb] (u64), total (u64)
 	const uint32_t *h_olen = (const uint32_t *)s.h_meta.p;
+	const bool none = s.nb == 0;             // an empty batch: the pinned table holds an earlier batch's figures
 	if (out_len)
-		*out_len = h_olen;
+		*out_len = none ? nullptr : h_olen;
 	if (crc32)
-		*crc32 = h_olen + s.nb;
+		*crc32 = none ? nullptr : h_olen + s.nb;
 	if (dst_off)
-		*dst_off = (const uint64_t *)((const uint8_t *)s.h_meta.p + (size_t)12 * s.nb);
+		*dst_off = none ? nullptr : s.doff.data();
 	return 0;
 }
 
@@ -1168,8 +1205,9 @@ static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int
 		return HD_E_ARG;
 	if (!n)
 		return 0;
-	int r = bind_device();
-	if (r)
+	// (a context may outlive hipdeflate_shutdown(), which frees the shared tables: ensure() brings them back)
+	int r = ensure();
+	if (r || (r = bind_device()))
 		return r;
 	const uint32_t mb = c->max_blocks;
 	const uint32_t seg_limit = latency ? c->seg_limit : 0;           // (a context's slots are far below HD_SEG_LIMIT)
@@ -1263,15 +1301,40 @@ void hipdeflate_lat_close(hipdeflate_lat *c)
 /* ---- per-block codecs (zlibutil_code_enc / zlibutil_code_dec) --------------- */
 
 // One block per call from each of the caller's threads (zlibutil_buffer_code as a pthread start routine,
-// applet/7bgzf.c:211): every thread keeps a latency context of its own for blocks up to 64 KiB -- no global lock, no
-// staging copies, ~90 us per 0xff00-byte block and thread, all threads at once.
-struct CodecCtx {
-	hipdeflate_lat *lat = nullptr;
-	int level = 0;
-	~CodecCtx() { hipdeflate_lat_close(lat); }
-};
-static thread_local CodecCtx t_codec;
+// applet/7bgzf.c:211 -- which creates a THREAD PER BLOCK): a call borrows a latency context (blocks up to 64 KiB) from a
+// small pool keyed by level and gives it back, so a short-lived thread reuses the pinned buffers, scratch and stream of
+// the one before it -- no hipHostMalloc / hipFree per block, no HIP call from a thread-exit destructor, no global
+// lock around the coding itself: ~90 us per 0xff00-byte block and thread, all threads at once.  hipdeflate_shutdown()
+// closes the pooled contexts.
 constexpr uint32_t CODEC_BLOCK = 0x10000;
+
+static hipdeflate_lat *codec_acquire(int level)
+{
+	const int k = level < 0 ? 0 : level >= CODEC_LEVELS ? CODEC_LEVELS - 1 : level;
+	{
+		std::lock_guard<std::mutex> lk(g_codec_mu);
+		std::vector<hipdeflate_lat *> &f = g_codec_free[k];
+		if (!f.empty()) {
+			hipdeflate_lat *c = f.back();
+			f.pop_back();
+			return c;
+		}
+	}
+	return hipdeflate_lat_open(level, HD_FRAME_RAW | HD_FRAME_LATENCY, 1, CODEC_BLOCK);
+}
+
+static void codec_release(hipdeflate_lat *c, int level)
+{
+	const int k = level < 0 ? 0 : level >= CODEC_LEVELS ? CODEC_LEVELS - 1 : level;
+	{
+		std::lock_guard<std::mutex> lk(g_codec_mu);
+		if (g_codec_free[k].size() < CODEC_POOL_MAX) {
+			g_codec_free[k].push_back(c);
+			return;
+		}
+	}
+	hipdeflate_lat_close(c);
+}
 
 static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level,
 		       int frame)
@@ -1279,34 +1342,30 @@ static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xffffffffu - 65536u)
 		return HD_E_ARG;
 	if (sourceLen <= CODEC_BLOCK && ensure() == 0) {
-		CodecCtx &t = t_codec;
-		if (t.lat && t.level != level) {
-			hipdeflate_lat_close(t.lat);
-			t.lat = nullptr;
-		}
-		if (!t.lat) {
-			t.lat = hipdeflate_lat_open(level, HD_FRAME_RAW | HD_FRAME_LATENCY, 1, CODEC_BLOCK);
-			t.level = level;
-		}
-		if (t.lat) {
-			const size_t cap = *destLen > t.lat->slot ? t.lat->slot : *destLen;
+		if (hipdeflate_lat *c = codec_acquire(level)) {
+			const size_t cap = *destLen > c->slot ? c->slot : *destLen;
 			const uint32_t lat = HD_LAT_SEG_BYTES(level);
+			// latency form only when the room covers its worst case AND the context has a slot for every segment
 			const bool latency = level >= 1 && sourceLen > lat &&
-					     cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH);
+					     cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH) &&
+					     HD_SEGN_COUNT((uint32_t)sourceLen, lat) <= c->S;
 			if (sourceLen)
-				memcpy(hipdeflate_lat_input(t.lat, 0), source, sourceLen);
+				memcpy(hipdeflate_lat_input(c, 0), source, sourceLen);
 			const uint32_t len = (uint32_t)sourceLen;
-			int r = lat_run_ex(t.lat, &len, 1, frame, latency, (uint32_t)cap);
-			if (r)
-				return r;
+			int r = lat_run_ex(c, &len, 1, frame, latency, (uint32_t)cap);
 			uint32_t olen = 0;
 			int32_t st = 0;
-			const uint8_t *m = hipdeflate_lat_output(t.lat, 0, &olen, nullptr, &st);
-			if (st || olen > *destLen)
-				return 1; /* !Z_OK, as libdeflate_deflate (lib/zlibutil.c:189) */
-			memcpy(dest, m, olen);
-			*destLen = olen;
-			return 0;
+			if (!r) {
+				const uint8_t *m = hipdeflate_lat_output(c, 0, &olen, nullptr, &st);
+				if (st || olen > *destLen)
+					r = 1; /* !Z_OK, as libdeflate_deflate (lib/zlibutil.c:189) */
+				else
+					memcpy(dest, m, olen);
+			}
+			codec_release(c, level);
+			if (!r)
+				*destLen = olen;
+			return r;
 		}
 	}
 	uint64_t off = 0;

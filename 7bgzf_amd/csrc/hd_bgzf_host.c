@@ -404,9 +404,12 @@ static int do_compress_files(int level, int nthreads)
 				ret = 1;
 				break;
 			}
-			for (uint32_t i = 0; i < nb; i++)
-				if (total_blocks + (int)i > 0)
-					index_add((uint64_t)written + doff[i], (uint64_t)(total_blocks + (int)i) * g_block);
+			for (uint32_t i = 0; i < nb && !ret; i++)
+				if (total_blocks + (int)i > 0 &&
+				    index_add((uint64_t)written + doff[i], (uint64_t)(total_blocks + (int)i) * g_block))
+					ret = 1;
+			if (ret)
+				break;
 		}
 		t0 = now_s();
 		if (nbytes && io_parallel(g_fd_out, 1, (unsigned char *)(uintptr_t)data, nbytes, written)) {

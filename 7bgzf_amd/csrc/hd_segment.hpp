@@ -34,8 +34,9 @@ struct SegArgs {
 inline uint32_t seg_slots_per_block(uint32_t cap, uint32_t seg)
 {
 	const uint32_t full = HD_STORED_SIZE(seg) + 5u;
-	// (a raw frame has no header: the count may be one high for the others, never low)
-	return cap / full + (cap % full >= 13u ? 1u : 0u);
+	// (a raw frame has no header, a flush frame no 03 00 tail -- its shortest last segment, one byte, takes
+	// 1 + 5 + 5 = 11 bytes: the count may be one high for the other frames, never low)
+	return cap / full + (cap % full >= 11u ? 1u : 0u);
 }
 
 inline uint32_t seg_round_blocks(uint32_t nblocks, uint32_t S)

@@ -65,6 +65,50 @@ __global__ __launch_bounds__(64) void k_selftest_build(const uint32_t *freq, uin
 
 } // namespace
 
+// ---- LDS write arbitration: of the lanes that store to one entry in one instruction, the highest stays ----
+// Kernel == CPU twin (and with it golden hashes and multi-rank determinism) leans on this property of the gfx950 LDS,
+// which no document promises: ctx_init() runs this probe once per process and refuses the device if it fails.
+// Returns the number of entries that did not hold the highest writer; < 0 on an allocation error.
+int hd_probe_lds_order(void)
+{
+	const uint32_t nb = 16, rounds = 32, n = nb * rounds * 64;
+	uint16_t *hx = (uint16_t *)malloc(n * 2), *ho = (uint16_t *)malloc(n * 2), *dx = nullptr, *dout = nullptr;
+	uint32_t seed = 777;
+	for (uint32_t i = 0; i < n; i++) {
+		seed = seed * 1664525u + 1013904223u;
+		const uint32_t pat = (i / 64) % 8, l = i % 64;
+		// 0: one entry; 1: pairs; 2: two entries alternating; 3: 8 distinct, same bank; 4..7: random over 2^k
+		hx[i] = pat == 0 ? 5 : pat == 1 ? (uint16_t)(l / 2) : pat == 2 ? (uint16_t)(l & 1)
+			: pat == 3 ? (uint16_t)((l & 7) * 64) : (uint16_t)((seed >> 16) % (pat == 4 ? 4u : pat == 5 ? 16u : pat == 6 ? 64u : 1536u));
+	}
+	if (hipMalloc((void **)&dx, n * 2) != hipSuccess || hipMalloc((void **)&dout, n * 2) != hipSuccess) {
+		free(hx);
+		free(ho);
+		(void)hipFree(dx);
+		return -1;
+	}
+	(void)hipMemcpy(dx, hx, n * 2, hipMemcpyHostToDevice);
+	hipLaunchKernelGGL(k_selftest_lds_order, dim3(nb), dim3(64), 0, 0, dx, rounds, dout);
+	int bad = hipMemcpy(ho, dout, n * 2, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+	for (uint32_t g = 0; g < n && !(bad && g == 0); g += 64)
+		for (uint32_t l = 0; l < 64; l++) {
+			uint32_t top = l;
+			for (uint32_t k = l + 1; k < 64; k++)
+				if (hx[g + k] == hx[g + l])
+					top = k;
+			if (ho[g + l] != top + 1) {
+				if (bad++ < 5)
+					fprintf(stderr, "hipdeflate: LDS store arbitration: group %u lane %u entry %u holds lane %u, "
+						"highest writer is %u\n", g / 64, l, hx[g + l], ho[g + l] - 1, top);
+			}
+		}
+	free(hx);
+	free(ho);
+	(void)hipFree(dx);
+	(void)hipFree(dout);
+	return bad;
+}
+
 /* test entry: code lengths the DEVICE Huffman construction gives `nvec` frequency vectors of `nsyms` symbols
  * each (tests/test_gpu_parity.py compares them with the oracle's on adversarial distributions) */
 extern "C" int hipdeflate_test_build_lengths(const uint32_t *freq, uint32_t nvec, uint32_t nsyms, uint32_t maxbits,
@@ -130,41 +174,12 @@ extern "C" int hipdeflate_selftest(void)
 		(void)hipFree(dx);
 		(void)hipFree(di);
 	}
-	// ---- LDS write arbitration: of the lanes that store to one entry in one instruction, the highest stays ----
+	// ---- LDS write arbitration (also run by ctx_init) ----------------------------
 	{
-		const uint32_t nb = 16, rounds = 32, n = nb * rounds * 64;
-		uint16_t *hx = (uint16_t *)malloc(n * 2), *ho = (uint16_t *)malloc(n * 2), *dx, *dout;
-		uint32_t seed = 777;
-		for (uint32_t i = 0; i < n; i++) {
-			seed = seed * 1664525u + 1013904223u;
-			const uint32_t pat = (i / 64) % 8, l = i % 64;
-			// 0: one entry; 1: pairs; 2: two entries alternating; 3: 8 distinct, same bank; 4..7: random over 2^k
-			hx[i] = pat == 0 ? 5 : pat == 1 ? (uint16_t)(l / 2) : pat == 2 ? (uint16_t)(l & 1)
-				: pat == 3 ? (uint16_t)((l & 7) * 64) : (uint16_t)((seed >> 16) % (pat == 4 ? 4u : pat == 5 ? 16u : pat == 6 ? 64u : 1536u));
-		}
-		if (hipMalloc((void **)&dx, n * 2) != hipSuccess || hipMalloc((void **)&dout, n * 2) != hipSuccess)
+		const int bad = hd_probe_lds_order();
+		if (bad < 0)
 			return HD_E_NOMEM;
-		(void)hipMemcpy(dx, hx, n * 2, hipMemcpyHostToDevice);
-		hipLaunchKernelGGL(k_selftest_lds_order, dim3(nb), dim3(64), 0, 0, dx, rounds, dout);
-		(void)hipMemcpy(ho, dout, n * 2, hipMemcpyDeviceToHost);
-		int bad = 0;
-		for (uint32_t g = 0; g < n; g += 64)
-			for (uint32_t l = 0; l < 64; l++) {
-				uint32_t top = l;
-				for (uint32_t k = l + 1; k < 64; k++)
-					if (hx[g + k] == hx[g + l])
-						top = k;
-				if (ho[g + l] != top + 1) {
-					if (bad++ < 5)
-						fprintf(stderr, "hipdeflate selftest: LDS store arbitration: group %u lane %u entry %u holds lane %u, "
-							"highest writer is %u\n", g / 64, l, hx[g + l], ho[g + l] - 1, top);
-				}
-			}
 		fails += bad;
-		free(hx);
-		free(ho);
-		(void)hipFree(dx);
-		(void)hipFree(dout);
 	}
 	// ---- slot arithmetic vs RFC 1951 3.2.5 tables ---------------------------
 	{

@@ -11,9 +11,12 @@ contiguous BGZF stream.  value = input bytes of ALL ranks / time.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode encode|decode]
                   [--level L] [--gib G] [--no-cpu] [--no-extra]
 
-N > 1 is launched by the driver with torch.distributed.run, one rank per GPU
-(weak scaling: every rank holds its own G GiB shard = a contiguous block range of
-a G*N GiB stream).  The step then contains the ONE exchange of the path (SURVEY.md
+N > 1: one rank per GPU.  The driver launches the ranks itself (torch.distributed.run, WORLD_SIZE
+in the environment); called plainly as `python bench.py --gpus N`, bench.py starts that launcher
+as a CHILD process before anything here touches torch or HIP, passes its one JSON line through
+and exits with its code.  WORLD_SIZE != --gpus is an error, never a silent one-GPU run.  Weak
+scaling: every rank holds its own G GiB shard = a contiguous block range of a G*N GiB stream;
+G defaults to 16 at N = 1 (BASELINE config 2) and to 32 at N > 1 (config 4: 256 GiB over 8 GPUs).  The step then contains the ONE exchange of the path (SURVEY.md
 8(e)): all_gather of the per-rank compressed totals (7bgzf_amd/shard.py, RCCL) ->
 this rank's base -> member offsets in the whole stream (scan with that base) ->
 gather into the rank's span (what the rank would pwrite() at `base`).
@@ -56,7 +59,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"])
     ap.add_argument("--level", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=16.0, help="input GiB per GPU")
+    ap.add_argument("--gib", type=float, default=None,
+                    help="input GiB per GPU (default: 16 at N = 1 = config 2; 32 at N > 1 = config 4's 256 GiB over 8 GPUs)")
     ap.add_argument("--tile-mib", type=int, default=64, help="host-generated tile replicated on the device")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the headline config (profiling runs)")
@@ -66,7 +70,45 @@ def parse():
     ap.add_argument("--block-kib", type=int, default=0, help="0 = BGZF 0xff00-byte blocks; else MiGz blocks of N KiB")
     ap.add_argument("--stream", default="own", choices=["own", "libdeflate6", "zlib6", "libdeflate1"],
                     help="decode mode: who compressed the stream (reference encoders need oracle/_ref/libref.so)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.gib_default = args.gib is None
+    if args.gib is None:
+        args.gib = 16.0 if args.gpus <= 1 else 32.0
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks as a CHILD process
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1) before this process has imported torch
+    or made any HIP call, hand its JSON line through, return its exit code.  Never an exec."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("HD_BENCH_LAUNCH", None)
+    if args.gpus == 1:
+        env["HD_BENCH_FORCE_DIST"] = "1"         # the launcher path at N = 1 runs the N > 1 code
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in p.stdout:
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: expected ONE JSON line from rank 0, got %d\n" % len(lines))
+        rc = 1
+    for ln in lines:
+        sys.stdout.write(ln)
+    sys.stdout.flush()
+    return rc
 
 
 # ---- CPU baseline: the reference's own per-block function on host cores ------------
@@ -171,16 +213,12 @@ def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
         return one, allc, wall, n_all
 
     out = {}
-    one, allc, wall, n_all = measure(adapter_work(enc), 0.45 if mode == "encode" else 1.0)
-    out.update({"value": round(allc, 4), "unit": "GB/s", "cores": threads, "kind": kind,
-                "one_core": round(one, 4),
-                "sample": "%s; %d blocks (%.2f GB) of the same workload over %d threads, %.1f s CPU work"
-                          % (what, threads * n_all, threads * n_all * block / 1e9, threads, wall * threads)})
-    # The same reference function on real pthreads (tools/hook_bench.c linked against oracle/_ref/libref.so): Python
-    # threads hand the GIL around between the ctypes calls and sell the reference short.  Where the harness exists
-    # its all-core figure is the reported value; the reference's LD_PRELOAD hook (bgzf_compress.c: codec + CRC-32 +
-    # framing per call) is timed the same way.
+    # The reference function on real pthreads (tools/hook_bench.c linked against oracle/_ref/libref.so) is the reported
+    # figure where the harness exists: Python threads hand the GIL around between the ctypes calls and sell the reference
+    # short (round 2: by 2x), so they are only the fallback.  The reference's LD_PRELOAD hook (bgzf_compress.c: codec +
+    # CRC-32 + framing per call) is timed the same way.
     harness = os.path.join(ROOT, "oracle", "_ref", "hook_bench_ref")
+    done = False
     if have_ref and mode == "encode" and os.path.exists(harness):
         import subprocess
         import tempfile
@@ -198,23 +236,30 @@ def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
                 c_all = run(threads, "libdeflate_deflate:%d" % level)
                 c_one = run(1, "libdeflate_deflate:%d" % level)
                 hook = run(threads, None, "libdeflate%d" % level) if block <= 0xff00 else None
-                out["python_threads"] = {"all_cores": out["value"], "one_core": out["one_core"]}
                 if c_all:
-                    out["value"], out["one_core"] = round(c_all, 4), round(c_one or 0, 4)
-                    out["sample"] = ("libdeflate 1.23 via libdeflate_deflate (lib/zlibutil.c:179), one call per %d-byte block of "
-                                     "the same workload from %d pthreads for 2 s (tools/hook_bench.c against oracle/_ref/libref.so)"
-                                     % (block, threads))
+                    out.update({"value": round(c_all, 4), "unit": "GB/s", "cores": threads, "kind": kind,
+                                "one_core": round(c_one or 0, 4),
+                                "sample": "libdeflate 1.23 via libdeflate_deflate (lib/zlibutil.c:179), one call per %d-byte "
+                                          "block of the same workload from %d pthreads for 2 s = %d core-seconds "
+                                          "(tools/hook_bench.c against oracle/_ref/libref.so)" % (block, threads, 2 * threads)})
+                    done = True
                 if hook:
                     out["reference_hook"] = {"all_cores": round(hook, 4), "what": "bgzf_compress (bgzf_compress.c:39) with "
                                              "BGZF_METHOD=libdeflate%d from %d pthreads: codec + CRC-32 + framing per call" % (level, threads)}
             except Exception as ex:
                 out["c_harness_error"] = "%s: %s" % (type(ex).__name__, ex)
+    if not done:
+        one, allc, wall, n_all = measure(adapter_work(enc), 0.45 if mode == "encode" else 1.0)
+        out.update({"value": round(allc, 4), "unit": "GB/s", "cores": threads, "kind": kind,
+                    "one_core": round(one, 4),
+                    "sample": "%s; %d blocks (%.2f GB) of the same workload over %d python threads, %.1f s CPU work"
+                              % (what, threads * n_all, threads * n_all * block / 1e9, threads, wall * threads)})
     if mode == "encode":
         if have_ref:
-            one, allc, _, _ = measure(reused_work, 0.3)
+            one, allc, _, _ = measure(reused_work, 0.15)
             out["reused_compressor"] = {"one_core": round(one, 4), "all_cores": round(allc, 4),
                                         "what": "libdeflate_deflate_compress level %d, one compressor per thread" % level}
-        one, allc, _, _ = measure(adapter_work(o.hdo_deflate_twin), 0.25)
+        one, allc, _, _ = measure(adapter_work(o.hdo_deflate_twin), 0.15)
         out["twin"] = {"one_core": round(one, 4), "all_cores": round(allc, 4),
                        "what": "oracle/hd_deflate_twin.c level %d: the serial restatement of the HIP encoder "
                                "(same bytes as the kernel)" % level}
@@ -231,15 +276,25 @@ class Bench:
         self.torch, self.dist, self.args = torch, dist, args
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != max(args.gpus, 1):
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or call bench.py "
+                             "without a launcher and let it start the ranks)" % (args.gpus, self.world))
+        # HD_BENCH_DEVICE: every rank on that one card (the two-rank rehearsal on a one-GPU box, with
+        # HD_BENCH_DIST_BACKEND=gloo: RCCL wants one device per rank)
+        local = int(os.environ.get("HD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(local)
         force = self.world == 1 and os.environ.get("HD_BENCH_FORCE_DIST") == "1"
         self.use_dist = self.world > 1 or force
+        self.backend = os.environ.get("HD_BENCH_DIST_BACKEND", "nccl")
+        self.coll_dev = "cuda" if self.backend == "nccl" else "cpu"
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", local))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.pkg = importlib.import_module("7bgzf_amd")
         self.dev = importlib.import_module("7bgzf_amd.device")
         self.synth = importlib.import_module("7bgzf_amd.synth")
@@ -287,12 +342,21 @@ class Bench:
         drain()
         self.fence()
         elapsed = time.perf_counter() - t0
+        self.rank_elapsed = [elapsed]
         if self.use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            # every rank's own time (the line carries them, so a reader sees how many ranks the collective saw);
+            # the job's time is the slowest rank's
+            self.rank_elapsed = self.gather_f64(elapsed)
+            elapsed = max(self.rank_elapsed)
         kms = [a.elapsed_time(b) for a, b in evs]
         return elapsed, sum(kms) / len(kms) / 1e3
+
+    def gather_f64(self, x):
+        torch = self.torch
+        mine = torch.tensor([float(x)], dtype=torch.float64, device=self.coll_dev)
+        allt = torch.zeros(self.world, dtype=torch.float64, device=self.coll_dev)
+        self.dist.all_gather_into_tensor(allt, mine)
+        return [float(v) for v in allt.cpu()]
 
     def encode(self, data, block, level, migz, steps, warmup, slot_arg=0, incompressible=False):
         """-> dict(elapsed, k_avg_s, total, comp_total, nb, ...) for `steps` passes of the encode path"""
@@ -322,7 +386,7 @@ class Bench:
                 base = 0
                 if self.use_dist:
                     # the ONE exchange of the path: per-rank compressed totals -> base offsets
-                    totals = self.shard.exchange_totals(int(enc.total.item()), device="cuda")
+                    totals = self.shard.exchange_totals(int(enc.total.item()), device=self.coll_dev)
                     bases, grand = self.shard.bases_from_totals(totals)
                     base = bases[self.rank]
                     enc.scan(base=base)                          # member offsets in the whole stream
@@ -364,6 +428,10 @@ class Bench:
         if self.use_dist:
             assert state["totals"][self.rank] == comp_total
             assert state["grand"] == state["bases"][-1] + state["totals"][-1] == sum(state["totals"])
+            assert len(state["totals"]) == self.world
+            # what every rank found at the head of its span: its first member's offset in the WHOLE stream
+            state["first_member_offset"] = [int(v) for v in self.gather_f64(int(enc.dst_off[0].item()))]
+            state["rank_elapsed"] = list(self.rank_elapsed)
         # the span starts with a member header and the last member ends where the span ends
         head = bytes(packed[:4].cpu().numpy())
         assert head == b"\x1f\x8b\x08\x04", head
@@ -451,7 +519,19 @@ def summary(res, steps, world=1, mode="encode"):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("HD_BENCH_LAUNCH") == "1"):
+        sys.exit(launch_ranks(args))             # before torch / HIP are touched in this process
     block = args.block_kib * 1024 if args.block_kib else BGZF_BLOCK
+    cpu = None
+    if not args.no_cpu and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # The CPU legs come FIRST (a synthetic tile of the same generator, host only): the GPU phase then runs
+        # in one piece at the end of the process instead of being followed by ~10 s of host-only work
+        synth = importlib.import_module("7bgzf_amd.synth")
+        tb = min(args.tile_mib, 64) << 20
+        ctile = (synth.fastq_like(tb, seed=1234, first_record=1) if args.data == "fastq" else
+                 synth.text_like(tb, seed=4321) if args.data == "text" else synth.random_bytes(tb, seed=99))
+        cpu = cpu_baseline(ctile, max(args.level, 1), args.mode, block)
+        del ctile
     B = Bench(args)
     torch = B.torch
     world, rank = B.world, B.rank
@@ -479,21 +559,27 @@ def main():
         res = B.decode(data, packed, in_off, in_len, want_crc, block, args.steps, args.warmup)
     s = summary(res, args.steps, world, args.mode)
 
-    traffic = None
+    # HBM bytes per launch from the PMC counters: NOT measured in this run (counters need rocprofv3 around the
+    # process); the tracked file holds the figure of the same command under `rocprofv3 --pmc` (tools/prof_round.sh)
+    traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "traffic_%s_l%d.json" % (args.mode, level))
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
             if tj.get("input_bytes") == total:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE passes over this "
+                                  "command in an earlier run; not measured by this process" % os.path.basename(tp))
         except Exception:
             traffic = None
 
     line = None
     if rank == 0:
         shard_txt = "HBM-resident" if world == 1 else \
-            "HBM-resident; each rank = its own %.2f GiB shard (a contiguous block range) of a %.0f GiB stream" % (
-                total / 2 ** 30, total * world / 2 ** 30)
+            "HBM-resident; each rank = its own %.2f GiB shard (a contiguous block range) of a %.0f GiB stream%s" % (
+                total / 2 ** 30, total * world / 2 ** 30,
+                " (BASELINE config 4: 256 GiB over 8 GPUs = 32 GiB per rank, kept per rank at every N > 1)"
+                if args.gib_default else "")
         line = {
             "metric": ("GB/s input compressed, %s blocks" if args.mode == "encode"
                        else "GB/s output produced, %s blocks (inflate)") % (
@@ -521,17 +607,22 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_deflate_static" if args.mode == "encode" and level <= 1
                          else ("k_deflate_static<TOK> (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" else "k_inflate"),
                          "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": s["frac"], "traffic": traffic,
+                         "frac": s["frac"], "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],
                          "kernel_ms_avg": s["kernel_ms_avg"]},
         }
+        line["ranks_seen"] = len(B.rank_elapsed)
+        line["value_per_rank"] = [round(total * args.steps / e / 1e9, 3) for e in B.rank_elapsed]
         if B.use_dist and args.mode == "encode":
             d = res["dist"]
-            line["config"]["stream_offsets"] = {"totals": d["totals"], "bases": d["bases"], "stream_bytes": d["grand"]}
+            line["ranks_seen"] = len(d["totals"])        # length of the all-gathered totals: what the collective saw
+            line["config"]["stream_offsets"] = {"totals": d["totals"], "bases": d["bases"], "stream_bytes": d["grand"],
+                                                "first_member_offset": d["first_member_offset"]}
+            line["config"]["collective"] = "all_gather of one int64 per rank, backend %s" % B.backend
 
     # ---- the other GPU configs of BASELINE.json, same run (default invocation, one GPU) ----------
     default_run = (args.mode == "encode" and level == 1 and args.data == "fastq" and not args.block_kib
-                   and world == 1 and not args.no_extra and not args.slot and args.gib == 16.0)
+                   and world == 1 and not B.use_dist and not args.no_extra and not args.slot and args.gib == 16.0)
     if default_run:
         xs, xw = min(args.steps, 5), 2
         configs = {}
@@ -554,21 +645,25 @@ def main():
             return out
         note("encode_l2", encode_l2)
 
-        def decode_ld6():
-            so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
-            if not os.path.exists(so):
-                return {"error": "oracle/_ref/libref.so not built"}
-            tb = (args.tile_mib << 20) // block * block
-            nt = total // tb
-            tnp = tile_np[:tb]
-            d2 = torch.from_numpy(tnp).cuda().repeat(nt)
-            packed, in_off, in_len, want_crc, _ = B.reference_stream(tnp, nt, block, "libdeflate6")
-            r = B.decode(d2, packed, in_off, in_len, want_crc, block, xs, xw)
-            out = summary(r, xs, mode="decode")
-            out["workload"] = ("BGZF decode (inflate), 0xff00-byte blocks, %.2f GiB out, stream from the reference's "
-                               "libdeflate 1.23 level 6; output and per-block CRC-32 checked" % (d2.numel() / 2 ** 30))
-            return out
-        note("decode_libdeflate6", decode_ld6)
+        def decode_ref(which, who):
+            def run():
+                so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+                if not os.path.exists(so):
+                    return {"error": "oracle/_ref/libref.so not built"}
+                tb = (args.tile_mib << 20) // block * block
+                nt = total // tb
+                tnp = tile_np[:tb]
+                d2 = torch.from_numpy(tnp).cuda().repeat(nt)
+                packed, in_off, in_len, want_crc, _ = B.reference_stream(tnp, nt, block, which)
+                r = B.decode(d2, packed, in_off, in_len, want_crc, block, xs, xw)
+                out = summary(r, xs, mode="decode")
+                out["workload"] = ("BGZF decode (inflate), 0xff00-byte blocks, %.2f GiB out, stream from the reference's "
+                                   "%s; output and per-block CRC-32 checked" % (d2.numel() / 2 ** 30, who))
+                return out
+            return run
+        # BASELINE config 3 names both reference encoders
+        note("decode_libdeflate6", decode_ref("libdeflate6", "libdeflate 1.23 level 6"))
+        note("decode_zlib6", decode_ref("zlib6", "zlib 1.3.1 level 6"))
         del data
         B.free()
 
@@ -584,10 +679,8 @@ def main():
         line["configs"] = configs
 
     if rank == 0:
-        if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tile_np, max(level, 1), args.mode, block)
-        elif not args.no_cpu:
-            line["cpu_baseline"] = None
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu           # N = 1 only (None on a multi-rank run)
         print(json.dumps(line), flush=True)
     if B.use_dist:
         B.dist.destroy_process_group()

@@ -22,6 +22,8 @@ The outputs are DATA (inputs, reference outputs, verdicts), not source:
   next to the raw stream the same encoder gives for the same input: pins the
   full-flush form (zlibutil_buffer_full_flush, applet/7dictzip.c:93-126) that
   HD_FRAME_RAW_FLUSH produces on the GPU.
+* ratio_ref.json -- compressed sizes of the reference's encoders (libdeflate 1/2/6/9, zlib 6, slz) on seeded
+  FASTQ-like / text block sets: the ratio envelope of the encoder levels.
 * boundary.json -- known answers at the drop-in boundary: bgzf_compress
   (bgzf_compress.c:39) return codes/sizes/header bytes, the EOF member,
   zlibutil_buffer_code's RFC1950/1952 wrappers (lib/zlibutil.c:374-405),
@@ -352,9 +354,43 @@ def gen_full_flush(ref):
           "with the extra zero byte")
 
 
+RATIO_SETS = [("fastq", 201, 0xff00, 64), ("text", 202, 0xff00, 64), ("text", 203, 1 << 20, 4)]
+RATIO_ENCODERS = [("libdeflate", 1), ("libdeflate", 2), ("libdeflate", 6), ("libdeflate", 9), ("zlib", 6), ("slz", 1)]
+
+
+def ratio_input(kind, seed, block, nblocks):
+    """the inputs of ratio_ref.json: `nblocks` blocks of `block` bytes cut from one seeded stream (regenerated by the
+    tests from (kind, seed), not stored)"""
+    s = hdtest.synth()
+    n = block * nblocks
+    return bytes(s.fastq_like(n, seed=seed) if kind == "fastq" else s.text_like(n, seed=seed))
+
+
+def gen_ratio_ref(ref):
+    """encoder parity = round trip + RATIO ENVELOPE (libdeflate's bytes are no golden,
+    lib/libdeflate/libdeflate.h:75-83).  The compressed sizes the reference's encoders reach on seeded block sets:
+    what tests/test_gpu_parity.py::test_ratio_envelope holds the kernels' sizes against."""
+    out = []
+    for kind, seed, block, nblocks in RATIO_SETS:
+        data = ratio_input(kind, seed, block, nblocks)
+        sizes = {}
+        for name, level in RATIO_ENCODERS:
+            tot = 0
+            for b in range(nblocks):
+                tot += len(ref_encode(ref, name, level, data[b * block:(b + 1) * block]))
+            sizes["%s%d" % (name, level)] = tot
+        out.append({"kind": kind, "seed": seed, "block": block, "nblocks": nblocks, "in_bytes": len(data),
+                    "in_sha256": hdtest.sha(data), "ref_bytes": sizes})
+        print("ratio_ref:", kind, block, {k: round(v / len(data), 4) for k, v in sizes.items()})
+    json.dump(out, open(os.path.join(HERE, "ratio_ref.json"), "w"), indent=1)
+
+
 def main():
     ref = hdtest.ref()
     assert ref is not None, "build the reference first: make -C oracle ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "ratio":
+        return gen_ratio_ref(ref)
+    gen_ratio_ref(ref)
     gen_std_vects(ref)
     gen_ref_streams(ref)
     gen_ref_streams_full(ref)

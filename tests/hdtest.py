@@ -250,3 +250,26 @@ def corpus_fuzz(seed, count):
             have += len(seg)
         out.append(np.concatenate(parts).tobytes()[:n] if parts else b"")
     return out
+
+
+# ---- ratio envelope (encoder parity = round trip + ratio envelope) ---------------------------------
+# tests/golden/ratio_ref.json holds what the REFERENCE's encoders make of three seeded block sets (make_golden.py
+# gen_ratio_ref).  An encoder level here must stay within a stated factor of the reference level it stands for; the
+# bounds are today's measured truth plus a hair, so that a geometry change cannot cost ratio silently -- tighten them
+# when the encoder improves, never loosen them without saying so in DESIGN.md.
+#   (our level, reference key): {set name: bound on our bytes / reference bytes}
+RATIO_BOUNDS = {
+    (1, "slz1"):        {"fastq/65280": 1.03, "text/65280": 1.16, "text/1048576": 1.19},    # static Huffman both
+    (2, "libdeflate1"): {"fastq/65280": 1.055, "text/65280": 1.11, "text/1048576": 1.14},
+    (6, "libdeflate6"): {"fastq/65280": 1.11, "text/65280": 1.13, "text/1048576": 1.16},
+    (9, "libdeflate9"): {"fastq/65280": 1.14, "text/65280": 1.10, "text/1048576": 1.14},
+}
+
+
+def ratio_sets():
+    import json
+    for e in json.load(open(os.path.join(GOLDEN, "ratio_ref.json"))):
+        n = e["block"] * e["nblocks"]
+        data = bytes(synth().fastq_like(n, seed=e["seed"]) if e["kind"] == "fastq" else synth().text_like(n, seed=e["seed"]))
+        assert sha(data) == e["in_sha256"], "the seeded generator changed: regenerate tests/golden/ratio_ref.json"
+        yield "%s/%d" % (e["kind"], e["block"]), e, data

@@ -315,6 +315,23 @@ def test_encode_migz_1mib_blocks_match_twin(pkg, level):
         assert st2[i] == 0 and outs[i] == data[offs[i]:offs[i] + lens[i]] and int(crc2[i]) == int(crc[i])
 
 
+@pytest.mark.parametrize("level,refkey", sorted(hdtest.RATIO_BOUNDS))
+def test_ratio_envelope(pkg, level, refkey):
+    """encoder parity = round trip + RATIO ENVELOPE.  The kernel's total bytes on the seeded block sets
+    of tests/golden/ratio_ref.json over the reference encoder's (libdeflate 1.23 levels 1/6/9, slz) stay under the bounds
+    of hdtest.RATIO_BOUNDS; every member inflates back (zlib) to its block."""
+    for name, e, data in hdtest.ratio_sets():
+        nb, blk = e["nblocks"], e["block"]
+        offs = [i * blk for i in range(nb)]
+        slot = (blk + blk // 8 + 4096 + 15) & ~15
+        members, crc, st = pkg.batch_deflate(data, offs, [blk] * nb, level, pkg.FRAME_RAW, slot=slot)
+        assert not any(st)
+        for i in (0, nb // 2, nb - 1):
+            assert zlib.decompress(members[i], -15) == data[offs[i]:offs[i] + blk]
+        got = sum(len(m) for m in members) / e["ref_bytes"][refkey]
+        assert got <= hdtest.RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))
+
+
 @pytest.mark.parametrize("level", [1, 2, 6])
 def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, level):
     """Blocks longer than HD_SEG_LIMIT are coded as flushed 0xff00-byte segments and stitched on the device

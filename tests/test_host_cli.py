@@ -13,6 +13,14 @@ EXE = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7bgzf")
 REF = os.path.join(hdtest.ROOT, "oracle", "_ref", "cielbox_ref")
 
 
+def have_ref_cli():
+    """the reference CLI built from /root/reference; on a GPU box its absence is an error (tests/conftest.py), here it
+    is asserted again so that no test loses its interop half quietly"""
+    ok = os.path.exists(REF)
+    assert ok or not os.path.exists("/dev/kfd") or os.environ.get("HD_ALLOW_NO_REF") == "1", "oracle/_ref/cielbox_ref missing"
+    return ok
+
+
 def run(args, data):
     p = subprocess.run([EXE] + args, input=data, capture_output=True, timeout=300)
     return p.returncode, p.stdout, p.stderr.decode()
@@ -30,7 +38,7 @@ def test_filter_matches_library_and_reference_format(level):
     assert gzip.decompress(blob) == data
     rc, back, err = run(["-d"], blob)
     assert rc == 0 and back == data, err
-    if os.path.exists(REF):
+    if have_ref_cli():
         # the REAL reference CLI decodes our file, and we decode the reference's
         p = subprocess.run([REF, "7bgzf", "-d"], input=blob, capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
@@ -51,7 +59,7 @@ def test_migz_framing_roundtrip(level):
     assert gzip.decompress(blob) == data
     rc, back, err = run(["-d"], blob)
     assert rc == 0 and back == data, err
-    if os.path.exists(REF):
+    if have_ref_cli():
         p = subprocess.run([REF, "7migz", "-d"], input=blob, capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
 
@@ -95,7 +103,7 @@ def test_dictzip_writer_and_reader_against_the_reference(tmp_path, level, extrem
     open(fo, "wb").write(bytes(bad))
     p = subprocess.run([DZ, "-d", fo], capture_output=True, timeout=300)
     assert p.returncode != 0 and "mismatch" in p.stderr.decode()
-    if os.path.exists(REF):
+    if have_ref_cli():
         open(fo, "wb").write(d)
         p = subprocess.run([REF, "7dictzip", "-cd", fo], capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
@@ -150,7 +158,7 @@ def test_razf_writer_and_reader_against_the_reference(tmp_path, level, nbytes):
     open(fo, "wb").write(bytes(bad))
     p = subprocess.run([RZ, "-d", fo], capture_output=True, timeout=300)
     assert p.returncode != 0 and "mismatch" in p.stderr.decode()
-    if os.path.exists(REF):
+    if have_ref_cli():
         open(fo, "wb").write(d)
         p = subprocess.run([REF, "7razf", "-cd", fo], capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
@@ -199,7 +207,7 @@ def test_gzinga_writer_and_reader_against_the_reference(tmp_path, level, nbytes)
         open(fo, "wb").write(bytes(bad))
         p = subprocess.run([GZA, "-d", fo], capture_output=True, timeout=300)
         assert p.returncode != 0 and "mismatch" in p.stderr.decode()
-    if os.path.exists(REF) and nbytes:
+    if have_ref_cli() and nbytes:
         open(fo, "wb").write(d)
         p = subprocess.run([REF, "7gzinga", "-cd", fo], capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
@@ -248,7 +256,7 @@ def test_ciso_writer_and_reader_against_the_reference(tmp_path, level, threshold
     assert 0 < plain < nblk
     p = subprocess.run([CS, "-d"], input=d, capture_output=True, timeout=300)
     assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
-    if os.path.exists(REF):
+    if have_ref_cli():
         p = subprocess.run([REF, "7ciso", "-cd"], input=d, capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
         fr = str(tmp_path / "ref.cso")
@@ -293,7 +301,7 @@ def test_daxcr_writer_and_reader_against_the_reference(tmp_path, level):
     assert pos == len(d)
     p = subprocess.run([DX, "-d"], input=d, capture_output=True, timeout=300)
     assert p.returncode == 0 and p.stdout == data, p.stderr.decode()
-    if os.path.exists(REF):
+    if have_ref_cli():
         p = subprocess.run([REF, "7daxcr", "-cd"], input=d, capture_output=True, timeout=300)
         assert p.returncode == 0 and p.stdout == data
         fr = str(tmp_path / "ref.dax")

@@ -360,3 +360,21 @@ def test_twin_code_lengths_are_complete_and_limited():
                   np.array([fib[i % 30] for i in range(k)], dtype=np.uint32), rng.integers(1, 30000, k)][t % 4]
         ls = lens(f, maxbits)
         assert max(ls) <= maxbits and kraft(ls, maxbits) == 1 << maxbits, t
+
+
+@pytest.mark.parametrize("level,refkey", sorted(hdtest.RATIO_BOUNDS))
+def test_twin_ratio_envelope(level, refkey):
+    """The twin's bytes ARE the kernel's bytes (tests/test_gpu_parity.py), so the ratio envelope can be held on the CPU:
+    our level's total compressed size on each seeded block set / the reference encoder's (tests/golden/ratio_ref.json,
+    libdeflate 1.23 / slz built from the reference tree) stays under the bound written in hdtest.RATIO_BOUNDS."""
+    for name, e, data in hdtest.ratio_sets():
+        if e["block"] > 0xff00 and level == 9:
+            continue                                  # (the 1 MiB set at level 9 is 40 s of serial twin: GPU test only)
+        total = 0
+        for b in range(e["nblocks"]):
+            chunk = data[b * e["block"]:(b + 1) * e["block"]]
+            r, z = hdtest.oracle_twin(chunk, level, cap=len(chunk) + len(chunk) // 8 + 4096)
+            assert r == 0
+            total += len(z)
+        got = total / e["ref_bytes"][refkey]
+        assert got <= hdtest.RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))

@@ -23,6 +23,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hwid, xcc; };
 
 #define REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
@@ -50,6 +51,9 @@ struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hwid, xcc; };
         unsigned long long m = ((unsigned long long)sink[8] << 32) | sink[9] | 0x5555aaaa0f0ff0f0ull;            \
         unsigned long long mm0 = m, mm1 = m * 3, mm2 = m * 5, mm3 = m * 7;                                       \
         unsigned addr = (lane * 4) & 1023;                                                                       \
+        unsigned long long y = lane;                                                                             \
+        v4u z = {lane, lane, lane, lane};                                                            \
+        const unsigned* gp = sink + 64;                                                                          \
         for (unsigned i = lane; i < 512; i += 64) lds[i] = (i * 0x01000193u) & 0x3fc;                            \
         __syncthreads();                                                                                         \
         unsigned long long t0, t1, r0, r1;                                                                       \
@@ -62,14 +66,16 @@ struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hwid, xcc; };
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7),       \
                            [s0] "+s"(s0), [s1] "+s"(s1), [s2] "+s"(s2), [s3] "+s"(s3), [s4] "+s"(s4),            \
                            [s5] "+s"(s5), [s6] "+s"(s6), [s7] "+s"(s7), [m0] "+s"(mm0), [m1] "+s"(mm1),          \
-                           [m2] "+s"(mm2), [m3] "+s"(mm3)                                                        \
-                         : [a] "v"(a), [b] "v"(b), [c] "v"(c), [m] "s"(m), [addr] "v"(addr), [k] "s"(k)          \
+                           [m2] "+s"(mm2), [m3] "+s"(mm3), [y] "+v"(y), [z] "+v"(z)                              \
+                         : [a] "v"(a), [b] "v"(b), [c] "v"(c), [m] "s"(m), [addr] "v"(addr), [k] "s"(k),         \
+                           [gp] "s"(gp), [addr16] "v"((lane * 16) & 1023)                                        \
                          : "vcc", "scc", "memory");                                                              \
         }                                                                                                        \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" \
                      : "=s"(t1), "=s"(r1)::"memory");                                                            \
         unsigned acc = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7 ^          \
-                       (unsigned)(mm0 ^ mm1 ^ mm2 ^ mm3) ^ (unsigned)((mm0 ^ mm1 ^ mm2 ^ mm3) >> 32);            \
+                       (unsigned)(mm0 ^ mm1 ^ mm2 ^ mm3) ^ (unsigned)((mm0 ^ mm1 ^ mm2 ^ mm3) >> 32) ^           \
+                       (unsigned)y ^ z.x ^ z.w;                                                                  \
         if (acc == 0x12345678u && iters < 0) sink[16 + lane] = acc;                                              \
         if (lane == 0) st[blockIdx.x] = Stamp{t0, t1, r0, r1, hwid, xcc};                                        \
     }
@@ -117,6 +123,40 @@ struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hwid, xcc; };
 #define M_readfirstlane(J) "v_readfirstlane_b32 " XS(J) ", " X(J) "\n\t"
 #define M_writelane(J) "v_writelane_b32 " X(J) ", %[k], 5\n\t"
 #define M_swap(J) "v_swap_b32 " X(J) ", %[a]\n\t"
+#define M_and(J) "v_and_b32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_or(J) "v_or_b32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_sub(J) "v_sub_u32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_subrev(J) "v_subrev_u32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_lshr(J) "v_lshrrev_b32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_lshl_const(J) "v_lshlrev_b32 " X(J) ", 3, " X(J) "\n\t"
+#define M_min(J) "v_min_u32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_max(J) "v_max_u32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_not(J) "v_not_b32 " X(J) ", %[a]\n\t"
+#define M_or3(J) "v_or3_b32 " X(J) ", %[a], %[b], " X(J) "\n\t"
+#define M_xad(J) "v_xad_u32 " X(J) ", %[a], %[b], " X(J) "\n\t"
+#define M_and_sgpr(J) "v_and_b32 " X(J) ", %[k], " X(J) "\n\t"
+#define M_add_sgpr(J) "v_add_u32 " X(J) ", %[k], " X(J) "\n\t"
+#define M_add_lit(J) "v_add_u32 " X(J) ", 0x12345, " X(J) "\n\t"
+#define M_add_inline(J) "v_add_u32 " X(J) ", 7, " X(J) "\n\t"
+#define M_add_e64(J) "v_add_u32_e64 " X(J) ", %[a], " X(J) "\n\t"
+#define M_add_co(J) "v_add_co_u32 " X(J) ", vcc, %[a], " X(J) "\n\t"
+#define M_addc_co(J) "v_addc_co_u32 " X(J) ", vcc, %[a], " X(J) ", vcc\n\t"
+#define M_cndmask_e64_vcc(J) "v_cndmask_b32_e64 " X(J) ", " X(J) ", %[a], vcc\n\t"
+#define M_cmp_cnd_vcc(J) "v_cmp_lt_u32_e32 vcc, %[a], " X(J) "\n\tv_cndmask_b32_e32 " X(J) ", " X(J) ", %[b], vcc\n\t"
+#define M_cmp_cnd_sgpr(J) "v_cmp_lt_u32_e64 %[m0], %[a], " X(J) "\n\tv_cndmask_b32_e64 " X(J) ", " X(J) ", %[b], %[m0]\n\t"
+#define M_pk_add_u16(J) "v_pk_add_u16 " X(J) ", %[a], " X(J) "\n\t"
+#define M_add_u16(J) "v_add_u16 " X(J) ", %[a], " X(J) "\n\t"
+#define M_and_sdwa(J) "v_and_b32_sdwa " X(J) ", %[a], " X(J) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+#define M_mov_sdwa(J) "v_mov_b32_sdwa " X(J) ", %[a] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n\t"
+#define M_fma_dep2(J) "v_fma_f32 " X(J) ", %[a], %[b], " X(J) "\n\t"
+#define M_mul_f32(J) "v_mul_f32 " X(J) ", %[a], " X(J) "\n\t"
+#define M_pk_fma(J) "v_pk_fma_f32 %[m" #J "], %[m" #J "], %[m" #J "], %[m" #J "]\n\t"
+#define M_ds_read_b64(J) "ds_read_b64 %[y], %[addr16] offset:" #J "*64\n\t"
+#define M_ds_read_b128(J) "ds_read_b128 %[z], %[addr16] offset:" #J "*64\n\t"
+#define M_ds_write_b64(J) "ds_write_b64 %[addr16], %[y] offset:" #J "*64\n\t"
+#define M_global_load(J) "global_load_dword " X(J) ", %[addr], %[gp] offset:" #J "*256\n\t"
+#define M_branch_not_taken(J) "s_cbranch_scc0 Lend_%=\n\t"
+#define M_branch_taken(J) "s_cbranch_scc1 Lt" #J "_%=\n\tLt" #J "_%=:\n\t"
 #define REP8M4(M) M(0) M(1) M(2) M(3) M(0) M(1) M(2) M(3)
 #define REP64M4(M) REP8M4(M) REP8M4(M) REP8M4(M) REP8M4(M) REP8M4(M) REP8M4(M) REP8M4(M) REP8M4(M)
 
@@ -181,6 +221,15 @@ T_V(and_or) T_V(lshl_or) T_V(lshl_add) T_V(add3) T_V(bfi) T_V(mul24_sdwa) T_V(ad
 T_V(mul_hi) T_V(bfe) T_V(ffbl) T_V(ffbh) T_V(bfrev) T_V(bcnt) T_V(mbcnt) T_V(sad_u8) T_V(dot4) T_V(cmp_vcc) T_V(readlane)
 T_V(readlane_sidx) T_V(readfirstlane) T_V(writelane) T_V(swap)
 T_M4(cmp_sgpr)
+T_V(and) T_V(or) T_V(sub) T_V(subrev) T_V(lshr) T_V(lshl_const) T_V(min) T_V(max) T_V(not) T_V(or3) T_V(xad) T_V(and_sgpr)
+T_V(add_sgpr) T_V(add_lit) T_V(add_inline) T_V(add_e64) T_V(add_co) T_V(addc_co) T_V(cndmask_e64_vcc) T_V(pk_add_u16)
+T_V(add_u16) T_V(and_sdwa) T_V(mov_sdwa) T_V(mul_f32)
+KERNEL(cmp_cnd_vcc, REP32(M_cmp_cnd_vcc))
+KERNEL(cmp_cnd_sgpr, REP32(M_cmp_cnd_sgpr))
+T_L(ds_read_b64) T_L(ds_read_b128) T_L(ds_write_b64)
+KERNEL(branch_not_taken, "s_cmp_eq_u32 %[k], %[k]\n\t" M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) M_branch_not_taken(0) "Lend_%=:\n\t")
+KERNEL(branch_taken, "s_cmp_eq_u32 %[k], %[k]\n\t" M_branch_taken(0) M_branch_taken(1) M_branch_taken(2) M_branch_taken(3) M_branch_taken(4) M_branch_taken(5) M_branch_taken(6) M_branch_taken(7) M_branch_taken(8) M_branch_taken(9) M_branch_taken(10) M_branch_taken(11) M_branch_taken(12) M_branch_taken(13) M_branch_taken(14) M_branch_taken(15))
+KERNEL(global_load, REP64(M_global_load) "s_waitcnt vmcnt(0)\n\t")
 T_L(ds_read_u8) T_L(ds_read_u16) T_L(ds_read_b32) T_L(ds_write_b8) T_L(ds_write_b16) T_L(ds_write_b32) T_L(ds_or_b32)
 T_L(ds_add_u32) T_L(ds_bpermute) T_L(ds_permute) T_L(ds_swizzle)
 T_V(s_add) T_V(s_mov) T_V(s_nop) T_V(s_cselect) T_V(s_mul) T_V(s_bcnt64) T_V(s_ff1_64)
@@ -211,6 +260,20 @@ static Test tests[] = {
     E(mul_lo, "v_mul_lo_u32"), E(mul_hi, "v_mul_hi_u32"), E(bfe, "v_bfe_u32"), E(ffbl, "v_ffbl_b32"), E(ffbh, "v_ffbh_u32"),
     E(bfrev, "v_bfrev_b32"), E(bcnt, "v_bcnt_u32_b32"), E(mbcnt, "v_mbcnt_lo_u32_b32"), E(sad_u8, "v_sad_u8"),
     E(dot4, "v_dot4_u32_u8"), E(add_sdwa, "v_add_u32_sdwa src0_sel:BYTE_1"),
+    E(and, "v_and_b32"), E(or, "v_or_b32"), E(sub, "v_sub_u32"), E(subrev, "v_subrev_u32"), E(lshr, "v_lshrrev_b32"),
+    E(lshl_const, "v_lshlrev_b32 by an inline constant"), E(min, "v_min_u32"), E(max, "v_max_u32"), E(not, "v_not_b32"),
+    E(or3, "v_or3_b32"), E(xad, "v_xad_u32"), E(and_sgpr, "v_and_b32 with an SGPR source"),
+    E(add_sgpr, "v_add_u32 with an SGPR source"), E(add_lit, "v_add_u32 with a 32-bit literal"),
+    E(add_inline, "v_add_u32 with an inline constant"), E(add_e64, "v_add_u32 in VOP3 encoding"),
+    E(add_co, "v_add_co_u32 (writes vcc)"), E(addc_co, "v_addc_co_u32 (reads and writes vcc)"),
+    E(cndmask_e64_vcc, "v_cndmask_b32_e64 with vcc named as the selector"), E(pk_add_u16, "v_pk_add_u16"),
+    E(add_u16, "v_add_u16"), E(and_sdwa, "v_and_b32_sdwa"), E(mov_sdwa, "v_mov_b32_sdwa"), E(mul_f32, "v_mul_f32"),
+    E(cmp_cnd_vcc, "32 x (v_cmp_lt_u32_e32 vcc ; v_cndmask_b32_e32 vcc): the compiler's select"),
+    E(cmp_cnd_sgpr, "32 x (v_cmp_lt_u32_e64 sgpr ; v_cndmask_b32_e64 sgpr)"),
+    E(ds_read_b64, "ds_read_b64"), E(ds_read_b128, "ds_read_b128"), E(ds_write_b64, "ds_write_b64"),
+    E(global_load, "global_load_dword, 64 in flight, L2-resident 16 KiB"),
+    {"branch_not_taken", k_branch_not_taken, 17, "s_cmp + 16 x s_cbranch_scc0 that falls through"},
+    {"branch_taken", k_branch_taken, 17, "s_cmp + 16 x s_cbranch_scc1 taken (to the next instruction)"},
     E(cmp_sgpr, "v_cmp_lt_u32_e64 -> SGPR pair"), E(cmp_vcc, "v_cmp_lt_u32_e32 -> vcc"),
     E(readlane, "v_readlane_b32 constant lane"), E(readlane_sidx, "v_readlane_b32 SGPR lane"),
     E(readfirstlane, "v_readfirstlane_b32"), E(writelane, "v_writelane_b32"), E(swap, "v_swap_b32"),
