@@ -23,6 +23,7 @@
 //     lane stores; a match copy is 64 bytes per step across the lanes, from the
 //     ring when the source is near, from HBM (already flushed) when it is far.
 #pragma once
+#include <type_traits>
 #include "hd_device.hpp"
 
 namespace hd {
@@ -536,10 +537,20 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// 54 % of a wave's cycles parked on s_waitcnt): their loads all go out HERE, up to four at a time, and
 			// the bytes are put into the ring behind the ring-to-ring copies below instead of one round trip each.
 			const uint64_t hbm0 = match0 & ~inr0 & le0, hbm1 = match1 & ~inr1 & le1;
-			uint64_t fa = hbm0, fb = hbm1;
+			// LANE GROUPS.  Most matches of a DEFLATE stream are short (libdeflate-6 on FASTQ-like data: 70 % <= 8 bytes,
+			// 90 % <= 16), and both kinds above -- "simple" and "far" -- depend on nothing in this window.  They are copied
+			// several at a time, a group of 8 (16) lanes per match, with no scalar work per match: every owner pushes
+			// one dword {offset in the window's output, length, distance} to the first lane of its group (ds_permute),
+			// the group fetches it (ds_bpermute), each lane moves one byte -- from the ring, or, for a source that has
+			// left the ring, straight from the flushed output in HBM (one vector load for up to eight matches, where
+			// the scalar path below needs a load, three v_readlane and a dozen scalar instructions per match).
+			const uint64_t l8_0 = __ballot(s0.length <= 8), l8_1 = __ballot(s1.length <= 8);
+			const uint64_t l16_0 = __ballot(s0.length <= 16), l16_1 = __ballot(s1.length <= 16);
+			const uint64_t vec0 = (simple0 | hbm0) & l16_0, vec1 = (simple1 | hbm1) & l16_1;
+			uint64_t fa = hbm0 & ~vec0, fb = hbm1 & ~vec1;            // far and 17..64 bytes long: the scalar path
 			// (FARK in flight; every one holds a register, and at 81 the kernel would lose a wave per SIMD -- the offset
 			// table's copy in registers made room: the scalar loop reads it from LDS now)
-			constexpr int FARK = 2;
+			constexpr int FARK = 1;
 			uint32_t fml[FARK], fP[FARK], fv[FARK];
 			auto far_issue = [&]() {
 #pragma unroll
@@ -569,44 +580,55 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					L.ring[lane < fml[k] ? ((fP[k] + lane) & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)fv[k];
 			};
 			const bool anyfar = (hbm0 | hbm1) != 0;
-			if (anyfar) {
+			if (anyfar)
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // our own stores first
+			const bool scalar_far = (fa | fb) != 0;
+			if (scalar_far)
 				far_issue();
+			if (vec0 | vec1) {
+				// rel < 1024 (the window's budget), length <= 16, distance <= 32768: 10 + 5 + 16 bits
+				const uint32_t pk0 = rel0 | (s0.length << 10) | (s0.offset << 15);
+				const uint32_t pk1 = rel1 | (s1.length << 10) | (s1.offset << 15);
+				auto group_pass = [&](auto gtag, uint64_t own0, uint64_t own1) {
+					constexpr uint32_t G = decltype(gtag)::value, NG = 64 / G;
+					const uint32_t n0 = (uint32_t)__popcll(own0), nt = n0 + (uint32_t)__popcll(own1);
+					const uint32_t slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(own0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own0, 0));
+					const uint32_t slot1 = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(own1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own1, 0));
+					const uint32_t sub = lane & (G - 1), lead = (lane & ~(G - 1)) << 2;
+					for (uint32_t base = 0; base < nt; base += NG) {
+						// an owner whose slot falls into this pass targets the first lane of group (slot - base); everybody
+						// else an odd lane (never a group's first): what arrives there is not looked at
+						const uint32_t d0 = sel(own0, slot0 - base, NG), d1 = sel(own1, slot1 - base, NG);
+						const uint32_t a0 = d0 < NG ? d0 * (4 * G) : ((lane | 1u) << 2), a1 = d1 < NG ? d1 * (4 * G) : ((lane | 1u) << 2);
+						const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < NG ? pk0 : 0u));
+						const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < NG ? pk1 : 0u));
+						const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)(g0 | g1));
+						const uint32_t ml = (w >> 10) & 31;                        // 0: no match in this group
+						const uint32_t dp = pos + (w & 1023) + sub, sp = dp - (w >> 15);
+						const bool act = sub < ml;
+						// (the whole source in the ring or the whole source flushed: the same test as inr above)
+						const bool ringsrc = wend - (sp - sub) <= INF_RING - 64;
+						uint32_t v = L.ring[sp & (INF_RING - 1)];
+						if (act && !ringsrc)
+							v = dst[sp];
+						L.ring[act ? (dp & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)v;
+					}
+				};
+				const uint64_t g8_0 = vec0 & l8_0, g8_1 = vec1 & l8_1;
+				if (g8_0 | g8_1)
+					group_pass(std::integral_constant<uint32_t, 8>{}, g8_0, g8_1);
+				if ((vec0 & ~l8_0) | (vec1 & ~l8_1))
+					group_pass(std::integral_constant<uint32_t, 16>{}, vec0 & ~l8_0, vec1 & ~l8_1);
 			}
-			// The short ones among them (<= 8 bytes: most matches of a DEFLATE stream) are copied EIGHT AT A TIME, a
-			// group of eight lanes per match: every owner pushes {destination, source, length} to the first lane
-			// of its group (ds_permute), the group fetches it (ds_bpermute), one byte per lane moves.  No scalar
-			// loop per match -- the scalar unit is what bounds this kernel.
-			const uint64_t tiny0 = simple0 & __ballot(s0.length <= 8), tiny1 = simple1 & __ballot(s1.length <= 8);
-			if (tiny0 | tiny1) {
-				const uint32_t nt0 = (uint32_t)__popcll(tiny0), ntiny = nt0 + (uint32_t)__popcll(tiny1);
-				const uint32_t slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny0, 0));
-				const uint32_t slot1 = nt0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(tiny1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tiny1, 0));
-				const uint32_t pk0 = (opos0 & (INF_RING - 1)) | ((srcl0 & (INF_RING - 1)) << 11) | (s0.length << 22);
-				const uint32_t pk1 = (opos1 & (INF_RING - 1)) | ((srcl1 & (INF_RING - 1)) << 11) | (s1.length << 22);
-				const uint32_t sub = lane & 7, lead = (lane & ~7u) << 2;
-				for (uint32_t base = 0; base < ntiny; base += 8) {
-					// an owner whose slot falls into this pass targets lane 8 (slot - base); everybody else an odd lane
-					// (never a group's first): what arrives there is not looked at
-					const uint32_t d0 = sel(tiny0, slot0 - base, 8u), d1 = sel(tiny1, slot1 - base, 8u);
-					const uint32_t a0 = d0 < 8 ? d0 << 5 : ((lane | 1u) << 2), a1 = d1 < 8 ? d1 << 5 : ((lane | 1u) << 2);
-					const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < 8 ? pk0 : 0u));
-					const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < 8 ? pk1 : 0u));
-					const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)(g0 | g1));
-					const uint32_t tl = w >> 22;                               // 0: no match in this group
-					const uint8_t v = L.ring[(((w >> 11) & (INF_RING - 1)) + sub) & (INF_RING - 1)];
-					L.ring[sub < tl ? (((w & (INF_RING - 1)) + sub) & (INF_RING - 1)) : INF_RING + lane] = v;
-				}
-			}
-			// (copying the longer ones two at a time, both reads ahead of both writes, measured 2 % slower)
-			for (uint64_t sm = simple0 & ~tiny0; sm;) {
+			// the longer simple ones, one at a time (two at a time, both reads ahead of both writes, measured 2 % slower)
+			for (uint64_t sm = simple0 & ~vec0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
-			for (uint64_t sm = simple1 & ~tiny1; sm;) {
+			for (uint64_t sm = simple1 & ~vec1; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
@@ -638,7 +660,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
 				}
 			};
-			if (anyfar) {
+			if (scalar_far) {
 				far_store();
 				while (fa | fb) {
 					far_issue();
