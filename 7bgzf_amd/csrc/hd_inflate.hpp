@@ -61,6 +61,17 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
 #define INF_T1(k, t) do { } while (0)
 #endif
 
+// experiment switches (tools/exp_inflate_ab.sh rebuilds with -D...): the shipped values are the defaults
+#ifndef HD_INF_POLICY
+#define HD_INF_POLICY 0      // 1: a 16-lane-group pass only when it pays; 0: always, for every 9..16-byte match
+#endif
+#ifndef HD_INF_DEFER
+#define HD_INF_DEFER 1       // 1: the first lane-group pass of a window stays open across the scalar copies
+#endif
+#ifndef HD_INF_PREFETCH
+#define HD_INF_PREFETCH 1    // 1: the stream piece after next is requested a refill ahead
+#endif
+
 constexpr uint32_t INF_LT_BITS = 9;      // litlen direct table (8 VGPRs once loaded)
 constexpr uint32_t INF_DT_BITS = 8;      // offset direct table
 constexpr uint32_t INF_RING    = 2048;   // LDS output ring: small on purpose, occupancy beats window
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	constexpr uint32_t WIN_OUT_BUDGET = 704;
 	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
 	uint32_t lds_p0 = 0xfffffff0u;                // pieces lds_p0, lds_p0 + 1 are in L.comp
+	uint32_t pre_piece = 0, pre_idx = 0xfffffff0u; // piece pre_idx of the stream, requested ahead of its use
 	auto run_windows = [&](int32_t &st_out) -> uint32_t {
 		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
 		uint32_t result = 0;
@@ -394,7 +406,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					L.comp[lane] = L.comp[64 + lane];
 				else
 					L.comp[lane] = load_piece(p0);
-				L.comp[64 + lane] = load_piece(p0 + 1);
+				// the piece behind was requested when the last one was put in: its load has had ~16 windows to arrive
+				if (HD_INF_PREFETCH) {
+					L.comp[64 + lane] = pre_idx == p0 + 1 ? pre_piece : load_piece(p0 + 1);
+					pre_piece = load_piece(p0 + 2);
+					pre_idx = p0 + 2;
+				} else {
+					L.comp[64 + lane] = load_piece(p0 + 1);
+				}
 				lds_p0 = p0;
 			}
 			// A window is 128 bits: every lane decodes the token that would start at bit
@@ -585,10 +604,17 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const bool scalar_far = (fa | fb) != 0;
 			if (scalar_far)
 				far_issue();
+			uint64_t done0 = 0, done1 = 0;                           // matches the lane groups took
+			bool pend = false;                                       // a lane-group pass is open: bytes pend_v for ring[pend_idx]
+			uint32_t pend_idx = 0, pend_v = 0;
 			if (vec0 | vec1) {
 				// rel < 1024 (the window's budget), length <= 16, distance <= 32768: 10 + 5 + 16 bits
 				const uint32_t pk0 = rel0 | (s0.length << 10) | (s0.offset << 15);
 				const uint32_t pk1 = rel1 | (s1.length << 10) | (s1.offset << 15);
+				// The FIRST pass of a window is left open: its reads -- ring bytes, and for far sources one vector load from
+				// the flushed output -- are issued here, the bytes go into the ring behind the scalar copies below, so
+				// the load's ~1 us is not waited for where it is issued.  (One open pass = two registers; the kernel sits
+				// three below the step that costs a wave per SIMD.)
 				auto group_pass = [&](auto gtag, uint64_t own0, uint64_t own1) {
 					constexpr uint32_t G = decltype(gtag)::value, NG = 64 / G;
 					const uint32_t n0 = (uint32_t)__popcll(own0), nt = n0 + (uint32_t)__popcll(own1);
@@ -611,30 +637,58 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						uint32_t v = L.ring[sp & (INF_RING - 1)];
 						if (act && !ringsrc)
 							v = dst[sp];
-						L.ring[act ? (dp & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)v;
+						const uint32_t di = act ? (dp & (INF_RING - 1)) : INF_RING + lane;
+						if (HD_INF_DEFER && !pend) {
+							pend = true;
+							pend_idx = di;
+							pend_v = v;
+						} else {
+							L.ring[di] = (uint8_t)v;
+						}
 					}
 				};
-				const uint64_t g8_0 = vec0 & l8_0, g8_1 = vec1 & l8_1;
-				if (g8_0 | g8_1)
-					group_pass(std::integral_constant<uint32_t, 8>{}, g8_0, g8_1);
-				if ((vec0 & ~l8_0) | (vec1 & ~l8_1))
-					group_pass(std::integral_constant<uint32_t, 16>{}, vec0 & ~l8_0, vec1 & ~l8_1);
+				// A pass costs the same for one match as for a full set of groups (three LDS permutes, ~35 vector
+				// instructions): eight-lane groups take the <= 8-byte matches; the 9..16-byte ones get a pass of
+				// sixteen-lane groups when it pays -- a far one among them (the scalar far path is a load and ~45
+				// instructions per match), three or more, or when everything fits one such pass (<= 4 matches);
+				// otherwise they are "simple" and go one at a time below.
+				uint64_t a0 = vec0 & l8_0, a1 = vec1 & l8_1, b0 = vec0 & ~l8_0, b1 = vec1 & ~l8_1;
+				if (HD_INF_POLICY) {
+					const uint32_t n8 = (uint32_t)__popcll(a0) + (uint32_t)__popcll(a1);
+					const uint32_t n16 = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+					const bool run16 = n16 && (((b0 & hbm0) | (b1 & hbm1)) != 0 || n16 >= 3 || n8 + n16 <= 4);
+					if (run16 && n8 + n16 <= 4) {
+						b0 |= a0;
+						b1 |= a1;
+						a0 = a1 = 0;
+					}
+					if (!run16)
+						b0 = b1 = 0;
+				}
+				if (a0 | a1)
+					group_pass(std::integral_constant<uint32_t, 8>{}, a0, a1);
+				if (b0 | b1)
+					group_pass(std::integral_constant<uint32_t, 16>{}, b0, b1);
+				done0 = a0 | b0;
+				done1 = a1 | b1;
 			}
-			// the longer simple ones, one at a time (two at a time, both reads ahead of both writes, measured 2 % slower)
-			for (uint64_t sm = simple0 & ~vec0; sm;) {
+			// the other simple ones, one at a time (two at a time, both reads ahead of both writes, measured 2 % slower)
+			for (uint64_t sm = simple0 & ~done0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
-			for (uint64_t sm = simple1 & ~vec1; sm;) {
+			for (uint64_t sm = simple1 & ~done1; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
 				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
 				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
 			}
+			if (pend)
+				L.ring[pend_idx] = (uint8_t)pend_v;
 			auto copy_general = [&](uint32_t mlen, uint32_t P, uint32_t srcp) {
 				const uint32_t moff = P - srcp;
 				if (wend - srcp <= INF_RING - 64) {
