@@ -1444,6 +1444,12 @@ int hipdeflate_test_inflate_stats(uint64_t *out8)
 	// slots 6, 7 are reused for nothing: the cycle counters follow behind when the caller left room for 16 words
 	return 0;
 }
+int hipdeflate_test_inflate_stats2(uint64_t *out8)
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_inf_stats2), 64));
+	return 0;
+}
 int hipdeflate_test_inflate_cycles(uint64_t *out8)
 {
 	HD_CHECK(hipDeviceSynchronize());

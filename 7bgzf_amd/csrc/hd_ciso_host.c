@@ -142,7 +142,10 @@ static int cs_decompress(FILE *in, FILE *out)
 		fprintf(stderr, "unexpected end of file\n");
 		return 1;
 	}
-	unsigned char *ibuf = NULL, *obuf = malloc((size_t)CS_BATCH * up16(block) + 16);
+	/* the sector size comes from the file: a batch holds at most 128 MiB of output whatever it claims (2048-byte
+	 * sectors: the whole CS_BATCH; a header that says 1 MiB: 128 of them -- not a 64 GiB allocation) */
+	const uint32_t batch = (uint32_t)((128u << 20) / up16(block)) < CS_BATCH ? (uint32_t)((128u << 20) / up16(block)) : CS_BATCH;
+	unsigned char *ibuf = NULL, *obuf = malloc((size_t)batch * up16(block) + 16);
 	size_t icap = 0;
 	uint64_t *ioff = malloc(sizeof(uint64_t) * CS_BATCH), *ooff = malloc(sizeof(uint64_t) * CS_BATCH);
 	uint32_t *ilen = malloc(sizeof(uint32_t) * CS_BATCH), *cap = malloc(sizeof(uint32_t) * CS_BATCH);
@@ -156,8 +159,8 @@ static int cs_decompress(FILE *in, FILE *out)
 	uint64_t produced = 0;
 	int ret = 0;
 #define CS_POS(k) ((uint64_t)(rd32(index + 4 * (size_t)(k)) & 0x7fffffffu) << align)
-	for (uint32_t c = 0; c < nblk && !ret; c += CS_BATCH) {
-		const uint32_t m = nblk - c < CS_BATCH ? nblk - c : CS_BATCH;
+	for (uint32_t c = 0; c < nblk && !ret; c += batch) {
+		const uint32_t m = nblk - c < batch ? nblk - c : batch;
 		const uint64_t first = CS_POS(c), end = CS_POS(c + m);
 		if (first < at || end < first || end - first > (uint64_t)m * (block + 64)) {
 			fprintf(stderr, "corrupted index\n");

@@ -30,9 +30,9 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
 	// one persistent wave per LDS slot of the level (levels 2-4: 14.5 KiB -> 10 resident per CU
-	// -- 11 do not fit, measured --; 5-6: 16 KiB -> 9; 7-8: 27 KiB -> 5; 9: 31 KiB -> 5); a grid
-	// larger than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 7 ? 5u : level >= 5 ? 9u : 10u;
+	// -- 11 do not fit, measured --; with the two-way tables of the lazy levels 5-6: 21 KiB -> 7; 7-8: 29 KiB -> 5;
+	// 9: 35 KiB -> 4); a grid larger than what is resident would run its tail serially
+	const uint32_t per_cu = level >= 9 ? 4u : level >= 7 ? 5u : level >= 5 ? 7u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -47,7 +47,7 @@ constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 6 ? 10u : level <= 8 ? 6u : 5u);
+	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 6 ? 8u : level <= 8 ? 5u : 4u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)
@@ -313,12 +313,14 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // EMIT = 1: emit-only mode, the second half of the level-2 split path: tokens, histograms and
 // CRC of blocks [a.first, a.first + a.count) are in the scratch (written by k_deflate_static<.., true>),
 // this kernel builds the codes and writes the members exactly as the fused mode would have.
-template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0>
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0>
 __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
-	constexpr uint32_t HS = HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
+	// DEEP (the lazy levels, hipdeflate_params.h "LAZY LEVELS"): dword buckets of two positions; HS counts 16-bit units
+	constexpr uint32_t NB = HD_BUCKETS(WIN_BITS, HASH_BITS);
+	constexpr uint32_t HS = DEEP ? 2 * NB : HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
 	// staging ring (dwords) and flush granule: the token loop adds up to 64 x 48 bits = 96 dwords to
 	// fewer than FLUSH_DW pending ones before it flushes one granule, so 128 + 96 <= 256 is what it takes
 	// (a 128-dword ring would do for typical data and overflow on 48-bit tokens)
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			crc.template fold<true>(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
 		};
 		struct Fetched {
-			uint32_t v, vh, c;
+			uint32_t v, vh, c, c2;
 		};
 		auto fetch = [&](uint32_t S_) -> Fetched {
 			Fetched f;
@@ -447,13 +449,26 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
 			f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 			f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
-			const bool can = p + HD_MIN_MATCH <= n;
-			const uint32_t h = can ? HD_HASH_SLOT(f.v, HS) : HS;
-			const uint16_t mine = (uint16_t)(p + 1);
-			const uint32_t e = table[h];
-			table[h] = mine;
+			const bool can = p + (DEEP ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH) <= n;
+			uint32_t e, e2 = 0;
+			if (DEEP) {
+				// (a lane past the end reads and writes the spare bucket behind the table)
+				uint32_t *const bk = (uint32_t *)table;
+				const uint32_t h = can ? HD_HASH_SLOT6(f.v, f.vh, NB) : NB;
+				const uint32_t eb = bk[h];
+				bk[h] = (eb << 16) | ((p + 1) & 0xffffu);
+				e = eb & 0xffffu;
+				e2 = eb >> 16;
+			} else {
+				const uint32_t h = can ? HD_HASH_SLOT(f.v, HS) : HS;
+				const uint16_t mine = (uint16_t)(p + 1);
+				e = table[h];
+				table[h] = mine;
+			}
 			const uint32_t back = (p + 1 - e) & 0xffffu;
 			f.c = (can && e && back) ? p + 1 - back : 0u;
+			const uint32_t back2 = (p + 1 - e2) & 0xffffu;
+			f.c2 = (DEEP && can && e2 && back2) ? p + 1 - back2 : 0u;
 			if (INTRA) {
 				// a nearer occurrence inside the step replaces the table's candidate
 				const uint32_t d = intra_step_distance<INTRA>(f.v, lane);
@@ -731,7 +746,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		uint32_t crcv;
 		if constexpr (!EMIT) {
 		// ---- pass 1: the parse ------------------------------------------------
-		Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
+		Fetched f0 = { 0, 0, 0, 0 }, f1 = { 0, 0, 0, 0 };
 		Probed q0 = { 0, 0, 0 };
 		if (alive && n) {
 			fill_piece();
@@ -752,14 +767,38 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 			f1 = fetch(S + 128);
 
 			const uint32_t p = S + lane;
-			const bool can = p + HD_MIN_MATCH <= n;
-			const uint32_t cv0 = fc.v, cvh0 = fc.vh, cp = fc.c - 1;
-			const bool had = can && fc.c != 0 && cp >= lo;
-			const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
-			const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
+			const bool can = p + (DEEP ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH) <= n;
+			const uint32_t cv0 = fc.v, cvh0 = fc.vh;
+			const uint32_t room = n - p;
+			uint32_t cp = fc.c - 1;
+			bool had = can && fc.c != 0 && cp >= lo;
+			uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
+			uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
+			if (DEEP) {
+				// both positions of the bucket, verified over 16 bytes (read here, byte by byte: this kernel only takes
+				// the blocks the split path leaves -- its speed does not matter, its bytes must be the twin's);
+				// the older one is taken only when it is strictly longer
+				auto prefix16 = [&](uint32_t cpos) -> uint32_t {
+					const uint32_t lim = room < 16 ? room : 16;
+					uint32_t k = 0;
+					while (k < lim && ring8[(p + k) & (W - 1)] == ring8[(cpos + k) & (W - 1)])
+						k++;
+					return k;
+				};
+				const uint32_t cpB = fc.c2 - 1;
+				const bool hadB = can && fc.c2 != 0 && cpB >= lo;
+				const uint32_t LA = had ? prefix16(cp) : 0u, LB = hadB ? prefix16(cpB) : 0u;
+				const uint32_t LAv = LA >= 4 ? LA : 0u, LBv = LB >= 4 ? LB : 0u;
+				if (LBv > LAv) {
+					cp = cpB;
+					had = hadB;
+					const uint32_t *wb = &ring32[(cpB >> 2) & W4M];
+					cv = __builtin_amdgcn_alignbyte(wb[1], wb[0], cpB & 3);
+					cvh = __builtin_amdgcn_alignbyte(wb[2], wb[1], cpB & 3);
+				}
+			}
 			const uint32_t x = cvh ^ cvh0;
 			const uint32_t eqb = x ? (uint32_t)(__ffs((int)x) - 1) >> 3 : 4u;
-			const uint32_t room = n - p;
 			uint32_t mylen = 4 + eqb < room ? 4 + eqb : room;
 			bool ok = had && cv == cv0 && mylen >= (uint32_t)MINLEN;
 			if (LAZY) {
@@ -936,7 +975,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
 // then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
-template <int W, int H, int MINLEN, int LAZY, int INTRA>
+template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max, level);
@@ -947,7 +986,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
-		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY, INTRA>), dim3(s.count), dim3(64), 0, st, s);
+		hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY, INTRA, DEEP>), dim3(s.count), dim3(64), 0, st, s);
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0,
 				   st, s);
@@ -955,7 +994,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	DeflateArgs f = a;
 	f.split_ovf = s.split_ovf;
 	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
-	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
+	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA, DEEP>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }
 
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
@@ -967,11 +1006,11 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 	else if (level == 4)
 		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	else if (level <= 6)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
 	else if (level <= 8)
-		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
+		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
 	else
-		launch_level<HD_L9_WIN_BITS, HD_L9_HASH_BITS, HD_L9_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
+		launch_level<HD_L9_WIN_BITS, HD_L9_HASH_BITS, HD_L9_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
 	return 0;
 }
 

@@ -222,12 +222,16 @@ __device__ __forceinline__ uint8_t *split_block(uint8_t *scratch, uint32_t max_b
 }
 
 // MINLEN / LAZY / INTRA: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
-template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0, int INTRA = 0>
+// DEEP: the lazy levels' matchfinder (hipdeflate_params.h "LAZY LEVELS"): six-byte key, two positions per bucket, both verified
+template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0, int INTRA = 0, int DEEP = 0>
 __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
-	constexpr uint32_t HS = HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
+	// table entries: 16-bit positions, or (DEEP) dword buckets of two -- HS counts 16-bit units either way
+	constexpr uint32_t NB = HD_BUCKETS(WIN_BITS, HASH_BITS);
+	constexpr uint32_t HS = DEEP ? 2 * NB : HD_TABLE_ENTRIES(WIN_BITS, HASH_BITS);
+	static_assert(!DEEP || (TOK && WIN_BITS > 12), "the two-way table belongs to the parse kernels of the lazy levels");
 	constexpr uint32_t STG = 256;            // staging ring, dwords
 	constexpr uint32_t FLUSH_DW = 128;       // flushed 512 B at a time, 8 B per lane
 	constexpr uint32_t TOKQ = 128;           // token queue: < 64 waiting + <= 64 of one step
@@ -320,6 +324,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	fid.init(lane);
 	HashConsts hk;
 	hk.init(HS);
+	HashConsts6 hk6;
+	hk6.init(NB);
 	CrcLanes crc;
 	crc.init(lane, n);
 	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// largest position) stays, which is the result the CPU twin computes.
 	struct Fetched {
 		uint32_t v, vh, c;           // own bytes [p,p+4), [p+4,p+8); candidate position + 1 (0 = none)
+		uint32_t c2;                 // DEEP: the bucket's older position + 1
 	};
 	// INNER: every lane of the step has >= 9 bytes left and the block is shorter than
 	// 2^16 (all BGZF blocks; all but their last steps), so the end-of-block and the
@@ -386,20 +393,40 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
 		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
-		const bool can = INNER || p + HD_MIN_MATCH <= n;
+		const bool can = INNER || p + (DEEP ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH) <= n;
 		// (a lane past the end of the block publishes nothing; it reads slot 0, harmlessly)
-		const uint32_t ha = hash_slot_addr(f.v, hk);             // byte offset of the entry
-		uint16_t *const slot = (uint16_t *)((uint8_t *)table + (can ? ha : 0u));
-		const uint16_t mine = (uint16_t)(p + 1);
-		const uint32_t e = *slot;
-		if (can)
-			*slot = mine;
+		uint32_t e, e2 = 0;
+		if (DEEP) {
+			// one dword bucket: low half the newest position, high half the one before; every lane stores
+			// (what it read << 16) | itself -- { newest before the step, highest lane of the step } stays
+			const uint32_t ha = hash_slot_addr6(f.v, f.vh, hk6);
+			uint32_t *const slot = (uint32_t *)((uint8_t *)table + (can ? ha : 0u));
+			const uint32_t eb = *slot;
+			if (can)
+				*slot = (eb << 16) | ((p + 1) & 0xffffu);
+			e = eb & 0xffffu;
+			e2 = eb >> 16;
+		} else {
+			const uint32_t ha = hash_slot_addr(f.v, hk);             // byte offset of the entry
+			uint16_t *const slot = (uint16_t *)((uint8_t *)table + (can ? ha : 0u));
+			const uint16_t mine = (uint16_t)(p + 1);
+			e = *slot;
+			if (can)
+				*slot = mine;
+		}
+		f.c2 = 0;
 		if (INNER) {
 			f.c = e;                                         // position + 1 itself: nothing has wrapped
+			if (DEEP)
+				f.c2 = e2;
 		} else {
 			// entry -> absolute position + 1 of the latest p' < p with p' + 1 == e (mod 2^16)
 			const uint32_t back = (p + 1 - e) & 0xffffu;         // 0: an entry exactly 2^16 back, i.e. stale
 			f.c = (can && e && back) ? p + 1 - back : 0u;
+			if (DEEP) {
+				const uint32_t back2 = (p + 1 - e2) & 0xffffu;
+				f.c2 = (can && e2 && back2) ? p + 1 - back2 : 0u;
+			}
 		}
 		if (INTRA) {
 			// a nearer occurrence inside the step replaces the table's candidate
@@ -417,9 +444,20 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	struct Probed {
 		uint32_t c0, c1, c2;
 		uint32_t c3, c4, p2, p3, p4;     // K16: the candidate's and the lane's own bytes up to 16 (+ alignment)
+		uint32_t d0, d1, d2, d3, d4;     // DEEP: the five dwords under the bucket's older position
 	};
-	auto probe = [&](uint32_t c, uint32_t p) -> Probed {
+	auto probe = [&](uint32_t c, uint32_t p, uint32_t cB = 0) -> Probed {
 		Probed q;
+		if (DEEP) {
+			const uint32_t *wb = &ring32[((cB - 1) >> 2) & W4M];
+			q.d0 = wb[0];
+			q.d1 = wb[1];
+			q.d2 = wb[2];
+			q.d3 = wb[3];
+			q.d4 = wb[4];
+		} else {
+			q.d0 = q.d1 = q.d2 = q.d3 = q.d4 = 0;
+		}
 		const uint32_t *w = &ring32[((c - 1) >> 2) & W4M];
 		q.c0 = w[0];
 		q.c1 = w[1];
@@ -495,12 +533,12 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (!TOK)
 		put(lane == 0 ? (flush ? 2u : 3u) : 0u, lane == 0 ? 3u : 0u, 3u, 3u);
 
-	Fetched f0 = { 0, 0, 0 }, f1 = { 0, 0, 0 };
-	Probed q0 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	Fetched f0 = { 0, 0, 0, 0 }, f1 = { 0, 0, 0, 0 };
+	Probed q0 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	if (use_static && n) {
 		fill_piece();
 		f0 = fetch(std::false_type{}, 0);
-		q0 = probe(f0.c, lane);
+		q0 = probe(f0.c, lane, f0.c2);
 		f1 = fetch(std::false_type{}, 64);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const Fetched fc = f0;
 		const Probed qc = q0;
 		f0 = f1;
-		q0 = probe(f1.c, S + 64 + lane);   // harmless beyond n: every index is masked into the ring
+		q0 = probe(f1.c, S + 64 + lane, f1.c2);   // harmless beyond n: every index is masked into the ring
 		f1 = fetch(inner_tag, S + 128);
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
@@ -526,19 +564,60 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// ballot of ONE compare, they are combined by s_and / s_andn2 and reach the lanes again through sel().
 		const uint64_t lanem = (INNER || lanes == 64) ? ~0ull : (1ull << (lanes & 63)) - 1;   // lanes inside the block
 		const uint32_t p = S + lane;
-		const uint32_t cv0 = fc.v, cvh0 = fc.vh, c = fc.c, cp = c - 1;
-		const uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
-		const uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
-		const uint32_t x = cvh ^ cvh0;
-		const uint64_t xm = __ballot(cvh == cvh0);                            // all eight bytes agree
-		const uint32_t len8 = sel(xm, 8u, 4u + ((uint32_t)__builtin_ctz(x) >> 3));     // (x == 0: not selected)
+		const uint32_t cv0 = fc.v, cvh0 = fc.vh;
 		const uint32_t room = n - p;                  // >= 4 where a match can start
-		const uint32_t mylen = INNER ? len8 : (len8 < room ? len8 : room);     // <= 8 until a capped match is extended
+		uint32_t c = fc.c, cp = c - 1;
+		uint32_t cv = __builtin_amdgcn_alignbyte(qc.c1, qc.c0, cp & 3);
+		uint32_t cvh = __builtin_amdgcn_alignbyte(qc.c2, qc.c1, cp & 3);
+		uint32_t x = cvh ^ cvh0;
+		uint64_t xm = __ballot(cvh == cvh0);                            // all eight bytes agree
+		uint32_t len8 = sel(xm, 8u, 4u + ((uint32_t)__builtin_ctz(x) >> 3));     // (x == 0: not selected)
 		// candidate inside the window (c == 0, no candidate, makes cp = -1: one signed compare covers both;
 		// this kernel never sees a block of 2 GiB), its four bytes equal
 		uint64_t okm = __ballot((int32_t)cp >= (int32_t)lo) & __ballot(cv == cv0);
+		// bytes 8..15 of the candidate against the lane's own (valid where the first eight agree): K16, and DEEP's choice
+		uint32_t qc3 = qc.c3, qc4 = qc.c4, qc2 = qc.c2;
+		auto tail16 = [&](uint32_t w2, uint32_t w3, uint32_t w4, uint32_t cpos) -> uint32_t {
+			const uint32_t xa = __builtin_amdgcn_alignbyte(qc.p3, qc.p2, p & 3) ^ __builtin_amdgcn_alignbyte(w3, w2, cpos & 3);   // bytes 8..11
+			const uint32_t xb = __builtin_amdgcn_alignbyte(qc.p4, qc.p3, p & 3) ^ __builtin_amdgcn_alignbyte(w4, w3, cpos & 3);   // bytes 12..15
+			// (v_ffbl_b32 of 0 is -1: >> 3 and min 4 turn it into "all four agree"; ka >> 2 is 1 exactly then)
+			uint32_t fa, fb;
+			asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
+			asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
+			const uint32_t ka = (fa >> 3) < 4 ? (fa >> 3) : 4u, kb = (fb >> 3) < 4 ? (fb >> 3) : 4u;
+			return 8 + ka + (ka >> 2) * kb;
+		};
+		uint32_t len16_deep = 8;
+		if (DEEP) {
+			// the bucket's older position, verified the same way; it is taken only when it is strictly longer over
+			// 16 bytes (cut to the room that is left, as the twin's prefix lengths are)
+			const uint32_t cB = fc.c2, cpB = cB - 1;
+			const uint32_t cvB = __builtin_amdgcn_alignbyte(qc.d1, qc.d0, cpB & 3);
+			const uint32_t cvhB = __builtin_amdgcn_alignbyte(qc.d2, qc.d1, cpB & 3);
+			const uint32_t xB = cvhB ^ cvh0;
+			const uint64_t xmB = __ballot(cvhB == cvh0);
+			const uint32_t len8B = sel(xmB, 8u, 4u + ((uint32_t)__builtin_ctz(xB) >> 3));
+			const uint64_t okB = __ballot((int32_t)cpB >= (int32_t)lo) & __ballot(cvB == cv0);
+			const uint32_t l16A = tail16(qc.c2, qc.c3, qc.c4, cp), l16B = tail16(qc.d2, qc.d3, qc.d4, cpB);
+			uint32_t LA = sel(okm, sel(xm, l16A, len8), 0u), LB = sel(okB, sel(xmB, l16B, len8B), 0u);
+			if (!INNER) {
+				LA = LA < room ? LA : room;
+				LB = LB < room ? LB : room;
+			}
+			const uint64_t chB = __ballot(LB > LA);
+			c = sel(chB, cB, c);
+			cp = c - 1;
+			len8 = sel(chB, len8B, len8);
+			len16_deep = sel(chB, l16B, l16A);
+			qc2 = sel(chB, qc.d2, qc.c2);
+			qc3 = sel(chB, qc.d3, qc.c3);
+			qc4 = sel(chB, qc.d4, qc.c4);
+			xm = (xm & ~chB) | (xmB & chB);
+			okm = (okm & ~chB) | (okB & chB);
+		}
+		const uint32_t mylen = INNER ? len8 : (len8 < room ? len8 : room);     // <= 8 until a capped match is extended
 		if (!INNER)
-			okm &= __ballot(p + HD_MIN_MATCH <= n);
+			okm &= __ballot(p + (DEEP ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH) <= n);
 		if (MINLEN > HD_MIN_MATCH)
 			okm &= __ballot(mylen >= (uint32_t)MINLEN);
 		if (LAZY) {
@@ -577,11 +656,13 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		// steps on FASTQ-like data)
 		uint32_t len16 = 8;
 		const bool k16_step = K16 && (K16_EARLY || capmask != 0);
-		if (k16_step) {
+		if (DEEP) {
+			len16 = INNER ? len16_deep : (len16_deep < room ? len16_deep : room);
+		} else if (k16_step) {
 			const uint32_t *wp = &ring32[(p >> 2) & W4M], *wc = &ring32[(cp >> 2) & W4M];
-			const uint32_t c2 = qc.c2;
+			const uint32_t c2 = qc2;
 			const uint32_t p2 = K16_EARLY ? qc.p2 : wp[2], p3 = K16_EARLY ? qc.p3 : wp[3], p4 = K16_EARLY ? qc.p4 : wp[4];
-			const uint32_t c3 = K16_EARLY ? qc.c3 : wc[3], c4 = K16_EARLY ? qc.c4 : wc[4];
+			const uint32_t c3 = K16_EARLY ? qc3 : wc[3], c4 = K16_EARLY ? qc4 : wc[4];
 			const uint32_t xa = __builtin_amdgcn_alignbyte(p3, p2, p & 3) ^ __builtin_amdgcn_alignbyte(c3, c2, cp & 3);   // bytes 8..11
 			const uint32_t xb = __builtin_amdgcn_alignbyte(p4, p3, p & 3) ^ __builtin_amdgcn_alignbyte(c4, c3, cp & 3);   // bytes 12..15
 			// (v_ffbl_b32 of 0 is -1: >> 3 and min 4 turn it into "all four agree"; ka >> 2 is 1 exactly then)

@@ -232,6 +232,36 @@ __device__ __forceinline__ uint32_t hash_slot_addr(uint32_t v, const HashConsts 
 	return a;
 }
 
+// the lazy levels' key of six bytes (HD_HASH_SLOT6): vh = bytes [p+4, p+8), of which the low two count; returns the
+// BYTE offset of the dword bucket, 4 * slot
+struct HashConsts6 {
+	uint32_t k1, k2, k3, e4, m;
+	__device__ __forceinline__ void init(uint32_t buckets)
+	{
+		k1 = HD_HASH_K1;
+		k2 = HD_HASH_K2;
+		k3 = HD_HASH_K3;
+		e4 = 4 * buckets;
+		m = 0xfffcu;
+	}
+};
+__device__ __forceinline__ uint32_t hash_slot_addr6(uint32_t v, uint32_t vh, const HashConsts6 &k)
+{
+	uint32_t t1, t2, t, x, a;
+	asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(t1) : "v"(v), "v"(k.k2));
+	asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+	    : "=v"(t2) : "v"(vh), "v"(k.k3));
+	asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(v), "v"(k.k1), "v"(t1));
+	t += t2;
+	// ((t >> 16) * 4 buckets >> 16) & ~3 = 4 * (((t >> 16) * buckets) >> 16)
+	asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(x) : "v"(t), "v"(k.e4));
+	asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+	    : "=v"(a) : "v"(x), "v"(k.m));
+	return a;
+}
+
 // ---- CRC-32 ---------------------------------------------------------------
 __device__ __forceinline__ uint32_t crc_step4(const CrcTables *ct, uint32_t s, uint32_t d)
 {

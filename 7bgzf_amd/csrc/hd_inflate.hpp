@@ -51,12 +51,15 @@ constexpr uint32_t INF_FLUSHED = 1;
 #ifdef HD_INFLATE_STATS
 // experiment build only (tools/exp_inflate_stats.sh): where the tokens go
 __device__ unsigned long long g_inf_stats[8];
+__device__ unsigned long long g_inf_stats2[8];      // matches of the windows: [0] all [1] lane groups of 8 [2] of 16 [3] simple, one at a time [4] far, one at a time [5] general (fed by the window, overlapping, > 64 bytes)
+#define INF_STAT2(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats2[k], (unsigned long long)(v)); } while (0)
 __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + table build, [1] windows, [2] scalar token path, [3] whole kernel
 #define INF_STAT(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats[k], (unsigned long long)(v)); } while (0)
 #define INF_T0(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
 #define INF_T1(k, t) do { if (lane == 0) atomicAdd(&g_inf_cycles[k], __builtin_amdgcn_s_memtime() - (t)); } while (0)
 #else
 #define INF_STAT(k, v) do { } while (0)
+#define INF_STAT2(k, v) do { } while (0)
 #define INF_T0(t) do { } while (0)
 #define INF_T1(k, t) do { } while (0)
 #endif
@@ -64,6 +67,10 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
 // experiment switches (tools/exp_inflate_ab.sh rebuilds with -D...): the shipped values are the defaults
 #ifndef HD_INF_POLICY
 #define HD_INF_POLICY 0      // 1: a 16-lane-group pass only when it pays; 0: always, for every 9..16-byte match
+#endif
+#ifndef HD_INF_OWNER
+#define HD_INF_OWNER 0       // 1: short matches copied by their own lanes (measured: 146 GB/s against 160 with the lane groups --
+                             // sixteen ds_write_b8 per window and half cost the LDS path more than the vector units gained); 0: lane groups
 #endif
 #ifndef HD_INF_DEFER
 #define HD_INF_DEFER 1       // 1: the first lane-group pass of a window stays open across the scalar copies
@@ -125,7 +132,10 @@ struct InfLds {
 	uint16_t lit_sorted[288];
 	uint16_t off_sorted[32];
 	uint16_t lit_count[16], off_count[16];
-	__attribute__((aligned(16))) uint8_t ring[INF_RING];
+	union {
+		__attribute__((aligned(16))) uint8_t ring[INF_RING];
+		uint32_t ring32[INF_RING / 4];
+	};
 	union {
 		struct {
 			uint8_t cl[288 + 32 + 138 + 6];   // + worst-case RLE overrun
@@ -284,6 +294,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	const CrcTables *ct = a.ct;
 	const bool want_crc = a.crc != nullptr;
 	const bool dst_aligned = (((uintptr_t)dst) & 15) == 0;
+	[[maybe_unused]] const bool dst_al4 = (((uintptr_t)dst) & 3) == 0;
+	[[maybe_unused]] const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)L.ring;   // LDS byte address of the ring
 
 	// ---- compressed input: 256-byte pieces, one dword per lane -----------
 	const uint32_t mis = (uint32_t)((uintptr_t)src & 3);
@@ -527,8 +539,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
 			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
 			const uint64_t lit0 = real0 & s0.is_lit, lit1 = real1 & s1.is_lit;
-			L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s0.e >> 16);
-			L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s1.e >> 16);
+			auto store_literals = [&]() {
+				L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s0.e >> 16);
+				L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s1.e >> 16);
+			};
+			if (!HD_INF_OWNER)
+				store_literals();
 			const uint32_t wend = pos + cum;
 			// per-lane verdicts for the matches, so that the scalar loops below only dispatch
 			const uint64_t match0 = real0 & s0.is_len, match1 = real1 & s1.is_len;
@@ -565,8 +581,27 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// the scalar path below needs a load, three v_readlane and a dozen scalar instructions per match).
 			const uint64_t l8_0 = __ballot(s0.length <= 8), l8_1 = __ballot(s1.length <= 8);
 			const uint64_t l16_0 = __ballot(s0.length <= 16), l16_1 = __ballot(s1.length <= 16);
+#if HD_INF_OWNER
+			// OWNER COPIES.  A short match (<= 16 bytes) of either kind is copied by ITS OWN LANE: three (five) aligned
+			// dwords from the source -- the ring, or the flushed output in HBM --, v_alignbyte, then the bytes one
+			// ds_write_b8 each with the byte number as the instruction's offset, for all such matches of the window
+			// at once.  All 8 (16) bytes are written whatever the length, highest byte first: what a match writes
+			// beyond its length lands on the bytes of the tokens behind it, and those are written LATER -- the lower
+			// bytes of the other owners by the instructions that follow, the literals and every other match after
+			// this block -- or, beyond the window's end, in the ring's 64 oldest bytes, which no source may touch.
+			// No compaction, no LDS permutes, no per-match scalar work: ~25 vector instructions for all of them where
+			// the lane groups took ~36 per pass (INSTS_VALU 209 -> 199 per 64 bytes with the groups; this kernel is
+			// bound by vector issue).  Not for: a destination run that wraps the ring (one scalar test per window),
+			// a ring source whose five dwords would, a far source when the output is not 4-byte aligned.
+			const bool ring_room = (pos & (INF_RING - 1)) + cum + 16 <= INF_RING;
+			const uint64_t sw0 = __ballot((srcl0 & (INF_RING - 1)) <= INF_RING - 20), sw1 = __ballot((srcl1 & (INF_RING - 1)) <= INF_RING - 20);
+			const uint64_t vfar0 = dst_al4 ? hbm0 : 0ull, vfar1 = dst_al4 ? hbm1 : 0ull;
+			const uint64_t vec0 = ring_room ? ((simple0 & sw0) | vfar0) & l16_0 : 0ull;
+			const uint64_t vec1 = ring_room ? ((simple1 & sw1) | vfar1) & l16_1 : 0ull;
+#else
 			const uint64_t vec0 = (simple0 | hbm0) & l16_0, vec1 = (simple1 | hbm1) & l16_1;
-			uint64_t fa = hbm0 & ~vec0, fb = hbm1 & ~vec1;            // far and 17..64 bytes long: the scalar path
+#endif
+			uint64_t fa = hbm0 & ~vec0, fb = hbm1 & ~vec1;            // far and not taken above: the scalar path
 			// (FARK in flight; every one holds a register, and at 81 the kernel would lose a wave per SIMD -- the offset
 			// table's copy in registers made room: the scalar loop reads it from LDS now)
 			constexpr int FARK = 1;
@@ -607,6 +642,53 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			uint64_t done0 = 0, done1 = 0;                           // matches the lane groups took
 			bool pend = false;                                       // a lane-group pass is open: bytes pend_v for ring[pend_idx]
 			uint32_t pend_idx = 0, pend_v = 0;
+#if HD_INF_OWNER
+			{
+				auto owner_copy = [&](uint64_t vecm, uint64_t longm, uint64_t farm, uint32_t oposv, uint32_t srclv) {
+					if ((vecm >> lane) & 1) {
+						const uint32_t al = srclv & ~3u, sh = srclv & 3u;
+						uint32_t w0, w1, w2, w3, w4;
+						if ((farm >> lane) & 1) {
+							const uint32_t *g = (const uint32_t *)(dst + al);
+							w0 = g[0]; w1 = g[1]; w2 = g[2]; w3 = g[3]; w4 = g[4];
+						} else {
+							const uint32_t ri = (al & (INF_RING - 1)) >> 2;
+							w0 = L.ring32[ri]; w1 = L.ring32[ri + 1]; w2 = L.ring32[ri + 2]; w3 = L.ring32[ri + 3]; w4 = L.ring32[ri + 4];
+						}
+						const uint32_t da = ring_lds + (oposv & (INF_RING - 1));
+						if ((longm >> lane) & 1) {
+							const uint32_t b2 = __builtin_amdgcn_alignbyte(w3, w2, sh), b3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+							asm volatile("ds_write_b8_d16_hi %0, %4 offset:15\n\t"
+								     "ds_write_b8_d16_hi %0, %3 offset:14\n\t"
+								     "ds_write_b8 %0, %4 offset:13\n\t"
+								     "ds_write_b8 %0, %3 offset:12\n\t"
+								     "ds_write_b8_d16_hi %0, %2 offset:11\n\t"
+								     "ds_write_b8_d16_hi %0, %1 offset:10\n\t"
+								     "ds_write_b8 %0, %2 offset:9\n\t"
+								     "ds_write_b8 %0, %1 offset:8"
+								     :: "v"(da), "v"(b2), "v"(b2 >> 8), "v"(b3), "v"(b3 >> 8) : "memory");
+						}
+						const uint32_t b0 = __builtin_amdgcn_alignbyte(w1, w0, sh), b1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+						asm volatile("ds_write_b8_d16_hi %0, %4 offset:7\n\t"
+							     "ds_write_b8_d16_hi %0, %3 offset:6\n\t"
+							     "ds_write_b8 %0, %4 offset:5\n\t"
+							     "ds_write_b8 %0, %3 offset:4\n\t"
+							     "ds_write_b8_d16_hi %0, %2 offset:3\n\t"
+							     "ds_write_b8_d16_hi %0, %1 offset:2\n\t"
+							     "ds_write_b8 %0, %2 offset:1\n\t"
+							     "ds_write_b8 %0, %1"
+							     :: "v"(da), "v"(b0), "v"(b0 >> 8), "v"(b1), "v"(b1 >> 8) : "memory");
+					}
+				};
+				if (vec0)
+					owner_copy(vec0, vec0 & ~l8_0, hbm0, opos0, srcl0);
+				if (vec1)
+					owner_copy(vec1, vec1 & ~l8_1, hbm1, opos1, srcl1);
+				store_literals();
+				done0 = vec0;
+				done1 = vec1;
+			}
+#else
 			if (vec0 | vec1) {
 				// rel < 1024 (the window's budget), length <= 16, distance <= 32768: 10 + 5 + 16 bits
 				const uint32_t pk0 = rel0 | (s0.length << 10) | (s0.offset << 15);
@@ -653,7 +735,12 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				// instructions per match), three or more, or when everything fits one such pass (<= 4 matches);
 				// otherwise they are "simple" and go one at a time below.
 				uint64_t a0 = vec0 & l8_0, a1 = vec1 & l8_1, b0 = vec0 & ~l8_0, b1 = vec1 & ~l8_1;
-				if (HD_INF_POLICY) {
+				if (HD_INF_POLICY == 2) {
+					// a 16-lane-group pass only for a far match among the 9..16-byte ones, or two and more of them
+					const uint64_t bb = b0 | b1;
+					if (!((b0 & hbm0) | (b1 & hbm1)) && !(bb & (bb - 1)) && !(b0 && b1))
+						b0 = b1 = 0;
+				} else if (HD_INF_POLICY) {
 					const uint32_t n8 = (uint32_t)__popcll(a0) + (uint32_t)__popcll(a1);
 					const uint32_t n16 = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
 					const bool run16 = n16 && (((b0 & hbm0) | (b1 & hbm1)) != 0 || n16 >= 3 || n8 + n16 <= 4);
@@ -671,7 +758,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					group_pass(std::integral_constant<uint32_t, 16>{}, b0, b1);
 				done0 = a0 | b0;
 				done1 = a1 | b1;
+				INF_STAT2(1, __popcll(a0) + __popcll(a1));
+				INF_STAT2(2, __popcll(b0) + __popcll(b1));
 			}
+#endif
+			INF_STAT2(0, __popcll(match0) + __popcll(match1));
+			INF_STAT2(3, __popcll(simple0 & ~done0) + __popcll(simple1 & ~done1));
+			INF_STAT2(4, __popcll(hbm0 & ~vec0) + __popcll(hbm1 & ~vec1));
+			INF_STAT2(5, __popcll(match0 & ~simple0 & ~hbm0) + __popcll(match1 & ~simple1 & ~hbm1));
 			// the other simple ones, one at a time (two at a time, both reads ahead of both writes, measured 2 % slower)
 			for (uint64_t sm = simple0 & ~done0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;

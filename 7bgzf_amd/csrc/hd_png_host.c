@@ -102,6 +102,12 @@ static int load(struct image *im, FILE *f)
 		fprintf(stderr, "PNG without a usable IHDR / IDAT\n");
 		return -1;
 	}
+	/* the dimensions come from the file: DEFLATE expands at most 1032 : 1 (258 bytes per 2 bits), so an IHDR that asks
+	 * for more than its IDAT can hold is refused before anything of that size is allocated */
+	if (im->raw_len > 1032ull * im->idat_len + 64) {
+		fprintf(stderr, "IDAT is too short for the image the IHDR describes\n");
+		return -1;
+	}
 	if ((im->idat[0] & 0x0f) != 8 || ((im->idat[0] << 8 | im->idat[1]) % 31) || (im->idat[1] & 0x20)) {
 		fprintf(stderr, "IDAT is not a zlib stream\n");
 		return -1;

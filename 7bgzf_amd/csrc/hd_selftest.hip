@@ -35,18 +35,26 @@ __global__ __launch_bounds__(64) void k_selftest_slots(uint32_t *out)
 // same table entry in that instruction.  The encoder (and its CPU twin, which keeps the largest position)
 // relies on what gfx950's LDS does then: the highest lane's data stays.  This kernel checks exactly that,
 // for 16-bit entries, with conflict patterns from "all lanes on one entry" to "random over 1536 entries".
+// (the second half of the blocks does the same with ds_write_b32 on dword entries: the two-way buckets of the lazy levels)
 __global__ __launch_bounds__(64) void k_selftest_lds_order(const uint16_t *idx, uint32_t rounds, uint16_t *out)
 {
 	__shared__ uint16_t table[1536];
+	__shared__ uint32_t table32[1536];
 	const uint32_t lane = threadIdx.x;
+	const bool wide = blockIdx.x >= gridDim.x / 2;
 	for (uint32_t r = 0; r < rounds; r++) {
-		for (uint32_t i = lane; i < 1536; i += 64)
+		for (uint32_t i = lane; i < 1536; i += 64) {
 			table[i] = 0;
+			table32[i] = 0;
+		}
 		__syncthreads();
 		const uint16_t h = idx[(blockIdx.x * rounds + r) * 64 + lane];
-		table[h] = (uint16_t)(lane + 1);
+		if (wide)
+			table32[h] = 0xabcd0000u | (lane + 1);
+		else
+			table[h] = (uint16_t)(lane + 1);
 		__syncthreads();
-		out[(blockIdx.x * rounds + r) * 64 + lane] = table[h];
+		out[(blockIdx.x * rounds + r) * 64 + lane] = wide ? (uint16_t)table32[h] : table[h];
 	}
 }
 

@@ -75,6 +75,27 @@
 #define HD_HASH_K2         0xC2B2AEu
 #define HD_HASH_SLOT(v, entries) \
 	((((((uint32_t)(v) & 0xffffffu) * HD_HASH_K1 + ((uint32_t)(v) >> 16) * HD_HASH_K2) >> 16) * (uint32_t)(entries)) >> 16)
+/* LAZY LEVELS (5..9): the hash covers SIX bytes and a bucket holds TWO positions.
+ *   key      v = bytes [p, p+4), vh = bytes [p+4, p+6):  t += vh * K3 in the sum above (one more 24-bit multiply).  A
+ *            position enters the table (and looks into it) only with six bytes left.  DNA-like data has 256 distinct
+ *            4-byte keys in its reads; six bytes find the far repeats libdeflate's chains find (level 6, FASTQ-like
+ *            set: 0.285 -> 0.278 of the input with this alone).
+ *   bucket   one dword: low half the newest position of the key, high half the one before it.  A step reads the
+ *            bucket and stores (bucket << 16) | own position -- the same one LDS read and one LDS write per lane as
+ *            the one-way table; of the lanes of a step that share a bucket the highest keeps its store (as before),
+ *            so the bucket becomes { newest before the step, highest lane of the step }.
+ *   choice   both candidates are verified over 16 bytes; the older one is taken only when it is strictly longer.
+ * The role of hc_matchfinder's chain walk (lib/libdeflate/hc_matchfinder.h:183-338: depth 35 at level 6) with the
+ * depth LDS affords: 2.  tests/golden/ratio_ref.json + hdtest.RATIO_BOUNDS hold the resulting sizes against libdeflate's. */
+#define HD_HASH_K3         0x85EBCAu
+#define HD_HASH_SLOT6(v, vh, entries) \
+	((((((uint32_t)(v) & 0xffffffu) * HD_HASH_K1 + ((uint32_t)(v) >> 16) * HD_HASH_K2 + ((uint32_t)(vh) & 0xffffu) * HD_HASH_K3) >> 16) * (uint32_t)(entries)) >> 16)
+#define HD_LAZY_KEY_BYTES  6
+#define HD_LAZY_WAYS       2
+/* buckets of the two-way tables: 2560 x 4 B with the 8 KiB ring of levels 5..6 (8 parse waves per CU), 2560 with the
+ * 16 KiB ring of levels 7..8 (5 waves), 4096 at level 9 (4 waves) */
+#define HD_BUCKETS(win_bits, hash_bits) ((win_bits) == 14 && (hash_bits) == 13 ? 4096u : 2560u)
+
 /* Entries of the hash table.  LDS is granted in 1280-byte units, so the table sizes are what fills the units the ring
  * leaves: 1536 entries with the 4 KiB ring of levels 1..2 (7 units, 18 waves per CU instead of 16 with 2048) and the
  * 8 KiB ring of levels 3..4 (12 parse waves instead of 11), 2560 with the 8 KiB ring of levels 5..6 (10 parse waves

@@ -120,6 +120,10 @@ typedef struct {
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
 	unsigned intra;       /* candidates at distances 1..intra inside the step (HD_INTRA_DIST) */
+	/* the lazy levels (5..9): six-byte key, two positions per bucket (include/hipdeflate_params.h "LAZY LEVELS").  The
+	 * role of hc_matchfinder_longest_match's chain walk (lib/libdeflate/hc_matchfinder.h:183-338) at depth 2 */
+	int deep;
+	uint32_t *bucket;     /* HD_BUCKETS dwords: low half newest, high half the one before */
 } mf_t;
 
 typedef struct {
@@ -145,9 +149,11 @@ static uint32_t mf_index(const mf_t *mf, uint32_t v)
 static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
 		       unsigned minlen, int lazy, step_t *st)
 {
-	uint32_t cand[HD_WAVE];
+	uint32_t cand[HD_WAVE], cand2[HD_WAVE], pre[HD_WAVE];
 	uint8_t ok[HD_WAVE], cap8[HD_WAVE];
 	unsigned lanes = n - S < HD_WAVE ? (unsigned)(n - S) : HD_WAVE;
+	const unsigned keyb = mf->deep ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH;       /* bytes a position needs to be hashed */
+	const unsigned nbuckets = HD_BUCKETS((unsigned)__builtin_ctz(mf->win), mf->hash_bits);
 
 	/* the ring is refilled a 1 KiB piece at a time until it holds
 	 * HD_LOOKAHEAD bytes past S (or the whole input) */
@@ -159,10 +165,19 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	for (unsigned l = 0; l < lanes; l++) {          /* 1. look up */
 		size_t p = S + l;
 		ok[l] = 0;
-		if (p + HD_MIN_MATCH > n)
+		cand2[l] = 0;
+		if (p + keyb > n)
 			continue;
 		uint32_t v = load32(in + p);
-		uint32_t e = mf->table[mf_index(mf, v)];
+		uint32_t e;
+		if (mf->deep) {
+			pre[l] = mf->bucket[HD_HASH_SLOT6(v, in[p + 4] | (in[p + 5] << 8), nbuckets)];
+			e = pre[l] & 0xffffu;
+			uint32_t e2 = pre[l] >> 16, back2 = (uint32_t)(p + 1 - e2) & 0xffffu;
+			cand2[l] = (e2 && back2) ? (uint32_t)(p + 1 - back2) : 0;
+		} else {
+			e = mf->table[mf_index(mf, v)];
+		}
 		/* the latest p' < p with p' + 1 == e (mod 2^16); for inputs <= 64 KiB
 		 * that is simply e */
 		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
@@ -179,15 +194,39 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 2. publish */
 		size_t p = S + l;
-		if (p + HD_MIN_MATCH > n)
+		if (p + keyb > n)
 			continue;
 		/* the kernel's lanes race for the slot and re-write until the largest
 		 * position of the step holds it: within a step the last lane wins */
-		mf->table[mf_index(mf, load32(in + p))] = (uint16_t)(p + 1);
+		if (mf->deep)       /* every lane stores (what it READ << 16) | itself: { newest before the step, last lane of the step } */
+			mf->bucket[HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), nbuckets)] = (pre[l] << 16) | (uint16_t)(p + 1);
+		else
+			mf->table[mf_index(mf, load32(in + p))] = (uint16_t)(p + 1);
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 3. verify */
 		size_t p = S + l;
-		if (p + HD_MIN_MATCH > n || cand[l] == 0)
+		if (p + keyb > n)
+			continue;
+		if (mf->deep) {
+			/* both positions of the bucket are verified over 16 bytes (what the lanes learn in parallel at these
+			 * levels); the older one is taken only when it is strictly longer */
+			unsigned room16 = n - p < 16 ? (unsigned)(n - p) : 16, best = 0;
+			for (int w = 0; w < 2; w++) {
+				uint32_t cw = w ? cand2[l] : cand[l];
+				if (cw == 0 || cw - 1 < lo || load32(in + cw - 1) != load32(in + p))
+					continue;
+				unsigned k = 4;
+				while (k < room16 && in[p + k] == in[cw - 1 + k])
+					k++;
+				if (k > best) {
+					best = k;
+					cand[l] = cw;
+				}
+			}
+			if (!best)
+				continue;
+		}
+		if (cand[l] == 0)
 			continue;
 		size_t c = cand[l] - 1;
 		if (c < lo)
@@ -253,7 +292,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0 };                /* level 1 is the speed level: no run candidates */
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0, 0, NULL };                /* level 1 is the speed level: no run candidates */
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
@@ -599,13 +638,14 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
 }
 
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush)
+			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush, int deep)
 {
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + 64 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, intra };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, intra, deep,
+		    deep ? calloc(HD_BUCKETS(win_bits, hash_bits), 4) : NULL };
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
 	step_t st;
@@ -647,6 +687,7 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	}
 	free(b.tok);
 	free(mf.table);
+	free(mf.bucket);
 	free(tmp);
 	return ret;
 }
@@ -704,21 +745,21 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush);
+				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0);
 	if (level == 3)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
-				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush);
+				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0);
 	if (level == 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
-				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush);
+				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0);
 	if (level <= 6)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush);
+				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
 	if (level <= 8)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush);
+				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
 	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L9_WIN_BITS, HD_L9_HASH_BITS,
-			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush);
+			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,

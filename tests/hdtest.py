@@ -261,8 +261,9 @@ def corpus_fuzz(seed, count):
 RATIO_BOUNDS = {
     (1, "slz1"):        {"fastq/65280": 1.03, "text/65280": 1.16, "text/1048576": 1.19},    # static Huffman both
     (2, "libdeflate1"): {"fastq/65280": 1.055, "text/65280": 1.11, "text/1048576": 1.14},
-    (6, "libdeflate6"): {"fastq/65280": 1.11, "text/65280": 1.13, "text/1048576": 1.16},
-    (9, "libdeflate9"): {"fastq/65280": 1.14, "text/65280": 1.10, "text/1048576": 1.14},
+    # (round 3: six-byte key + two-way buckets at the lazy levels; before: 1.11 / 1.13 / 1.16 and 1.14 / 1.10 / 1.14)
+    (6, "libdeflate6"): {"fastq/65280": 1.065, "text/65280": 1.09, "text/1048576": 1.13},
+    (9, "libdeflate9"): {"fastq/65280": 1.09, "text/65280": 1.075, "text/1048576": 1.125},
 }
 
 

@@ -7,5 +7,5 @@ import ctypes, importlib, subprocess, sys, json
 sys.path.insert(0, '.')
 for stream in ("libdeflate6", "zlib6", "own"):
     p = subprocess.run([sys.executable, "tools/exp_inflate_stats_child.py", stream], capture_output=True, text=True)
-    print(stream, "\n".join(p.stdout.strip().splitlines()[-2:]) if p.stdout.strip() else p.stderr[-400:])
+    print(stream, "\n".join(p.stdout.strip().splitlines()[-3:]) if p.stdout.strip() else p.stderr[-400:])
 PY

@@ -18,3 +18,8 @@ pkg.lib().hipdeflate_test_inflate_cycles(cyc)
 tot = max(int(cyc[3]), 1)
 print({"cycles": {"headers+tables": round(int(cyc[0]) / tot, 3), "windows": round(int(cyc[1]) / tot, 3),
                    "scalar token path": round(int(cyc[2]) / tot, 3), "whole kernel (sum over waves)": tot}})
+m2 = (ctypes.c_uint64 * 8)()
+if hasattr(pkg.lib(), "hipdeflate_test_inflate_stats2"):
+    pkg.lib().hipdeflate_test_inflate_stats2(m2)
+    names2 = ["matches", "groups_of_8", "groups_of_16", "simple_scalar", "far_scalar", "general", "-", "-"]
+    print({"window matches": {n: int(v) for n, v in zip(names2, m2) if n != "-"}})
