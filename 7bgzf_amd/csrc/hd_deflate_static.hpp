@@ -899,7 +899,11 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		return use_static;
 	};
 	// fetch runs two steps ahead: a step is INNER when the lanes of step S + 128 still have 9 bytes
-	const bool small = n < 65536;
+	// (<= 2^16: the last position that enters the table is n - 4 (n - 6 at the lazy levels), so position + 1 still fits the
+	// 16-bit entries of a block of exactly 0x10000 bytes -- the reference's single-thread block size, applet/7bgzf.c:146-147.
+	// Such blocks had been running through the general steps: 244 GB/s against 323 for 0xff00-byte blocks, which rounds 1-2
+	// took for HBM channel aliasing; a start stagger of the waves, tried on that theory, only cost time.)
+	const bool small = n <= 65536;
 	// TOK: the open DEFLATE block's histograms leave for HBM and start again from zero
 	auto close_deflate_block = [&]() {
 		uint32_t *h = (uint32_t *)(rec + lay.off_hist) + ndb * 320;

@@ -52,16 +52,24 @@ constexpr uint32_t INF_FLUSHED = 1;
 // experiment build only (tools/exp_inflate_stats.sh): where the tokens go
 __device__ unsigned long long g_inf_stats[8];
 __device__ unsigned long long g_inf_stats2[8];      // matches of the windows: [0] all [1] lane groups of 8 [2] of 16 [3] simple, one at a time [4] far, one at a time [5] general (fed by the window, overlapping, > 64 bytes)
-#define INF_STAT2(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats2[k], (unsigned long long)(v)); } while (0)
+#define INF_STAT2(k, v) atomicAdd(&g_inf_stats2[k], lane == 0 ? (unsigned long long)(v) : 0ull)
+#define INF_U64(m) (((uint64_t)uniform((uint32_t)((m) >> 32)) << 32) | uniform((uint32_t)(m)))
 __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + table build, [1] windows, [2] scalar token path, [3] whole kernel
-#define INF_STAT(k, v) do { if (lane == 0) atomicAdd(&g_inf_stats[k], (unsigned long long)(v)); } while (0)
+// (every lane adds, lane 0 the value and the others zero: an `if (lane == 0)` around the atomic makes the compiler treat the
+// lane masks that live across it as divergent, and the window code keeps them in scalar registers)
+#define INF_STAT(k, v) atomicAdd(&g_inf_stats[k], lane == 0 ? (unsigned long long)(v) : 0ull)
 #define INF_T0(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
-#define INF_T1(k, t) do { if (lane == 0) atomicAdd(&g_inf_cycles[k], __builtin_amdgcn_s_memtime() - (t)); } while (0)
+// (cycles are summed in scalar registers and leave once per wave)
+#define INF_T1(k, t) do { inf_cyc[k] += __builtin_amdgcn_s_memtime() - (t); } while (0)
+#define INF_CYC_DECL unsigned long long inf_cyc[4] = { 0, 0, 0, 0 }
+#define INF_CYC_FLUSH do { for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_inf_cycles[k_], lane == 0 ? inf_cyc[k_] : 0ull); } while (0)
 #else
 #define INF_STAT(k, v) do { } while (0)
 #define INF_STAT2(k, v) do { } while (0)
 #define INF_T0(t) do { } while (0)
 #define INF_T1(k, t) do { } while (0)
+#define INF_CYC_DECL do { } while (0)
+#define INF_CYC_FLUSH do { } while (0)
 #endif
 
 // experiment switches (tools/exp_inflate_ab.sh rebuilds with -D...): the shipped values are the defaults
@@ -758,14 +766,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					group_pass(std::integral_constant<uint32_t, 16>{}, b0, b1);
 				done0 = a0 | b0;
 				done1 = a1 | b1;
-				INF_STAT2(1, __popcll(a0) + __popcll(a1));
-				INF_STAT2(2, __popcll(b0) + __popcll(b1));
+				INF_STAT2(1, __popcll(INF_U64(a0)) + __popcll(INF_U64(a1)));
+				INF_STAT2(2, __popcll(INF_U64(b0)) + __popcll(INF_U64(b1)));
 			}
 #endif
-			INF_STAT2(0, __popcll(match0) + __popcll(match1));
-			INF_STAT2(3, __popcll(simple0 & ~done0) + __popcll(simple1 & ~done1));
-			INF_STAT2(4, __popcll(hbm0 & ~vec0) + __popcll(hbm1 & ~vec1));
-			INF_STAT2(5, __popcll(match0 & ~simple0 & ~hbm0) + __popcll(match1 & ~simple1 & ~hbm1));
+			INF_STAT2(0, __popcll(INF_U64(match0)) + __popcll(INF_U64(match1)));
+			INF_STAT2(3, __popcll(INF_U64(simple0 & ~done0)) + __popcll(INF_U64(simple1 & ~done1)));
+			INF_STAT2(4, __popcll(INF_U64(hbm0 & ~vec0)) + __popcll(INF_U64(hbm1 & ~vec1)));
+			INF_STAT2(5, __popcll(INF_U64(match0 & ~simple0 & ~hbm0)) + __popcll(INF_U64(match1 & ~simple1 & ~hbm1)));
 			// the other simple ones, one at a time (two at a time, both reads ahead of both writes, measured 2 % slower)
 			for (uint64_t sm = simple0 & ~done0; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
@@ -864,6 +872,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			LT[r] = L.lit[r * 64 + lane];
 	};
 
+	INF_CYC_DECL;
 	INF_T0(t_kernel);
 	for (;;) {
 		INF_T0(t_hdr);
@@ -1102,6 +1111,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 		if (a.crc) a.crc[b] = crcv;
 	}
 	INF_T1(3, t_kernel);
+	INF_CYC_FLUSH;
 }
 
 } // namespace hd

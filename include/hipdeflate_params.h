@@ -15,9 +15,10 @@
  *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like")
  *   2      greedy parse, dynamic Huffman, level-1 window (fast on DNA-like data)
  *   3..4   greedy parse, dynamic Huffman, 8 KiB window
- *   5..6   lazy parse (one-lane lookahead), dynamic Huffman (config 5,
- *          "level-6-like")
- *   7..9   the same with a larger window and hash table
+ *   5      lazy parse (one-lane lookahead), dynamic Huffman, 8 KiB window
+ *   6      the same with a six-byte hash key and two positions per bucket, both verified
+ *          (config 5, "level-6-like"; the role of hc_matchfinder's chains at the depth LDS affords)
+ *   7..9   level 6's matchfinder with a larger window and table
  */
 #ifndef HIPDEFLATE_PARAMS_H
 #define HIPDEFLATE_PARAMS_H
@@ -50,16 +51,16 @@
 #define HD_L4_WIN_BITS     13
 #define HD_L4_HASH_BITS    11
 #define HD_L4_MIN_LEN      5
-/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring, 12 hash bits over 2560 entries: 10 parse waves per CU */
+/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring; level 5: 2560 one-way entries (10 parse waves per CU),
+ * level 6: 2560 two-way buckets (8 waves) */
 #define HD_L5_WIN_BITS     13
 #define HD_L5_HASH_BITS    12
 #define HD_L5_MIN_LEN      5
-/* levels 7..8: the same parse with a 16 KiB ring (6 parse waves per CU) */
+/* levels 7..8: level 6's parse with a 16 KiB ring (5 parse waves per CU) */
 #define HD_L7_WIN_BITS     14
 #define HD_L7_HASH_BITS    12
 #define HD_L7_MIN_LEN      5
-/* level 9: 16 KiB ring, 13 hash bits over 6144 entries (text: 4 % smaller output than levels 5..6;
- * 30 KiB of LDS, 5 waves per CU, about half the speed) */
+/* level 9: 16 KiB ring, 4096 two-way buckets (34 KiB of LDS, 4 waves per CU, about 60 % of level 6's speed) */
 #define HD_L9_WIN_BITS     14
 #define HD_L9_HASH_BITS    13
 #define HD_L9_MIN_LEN      5
@@ -75,7 +76,8 @@
 #define HD_HASH_K2         0xC2B2AEu
 #define HD_HASH_SLOT(v, entries) \
 	((((((uint32_t)(v) & 0xffffffu) * HD_HASH_K1 + ((uint32_t)(v) >> 16) * HD_HASH_K2) >> 16) * (uint32_t)(entries)) >> 16)
-/* LAZY LEVELS (5..9): the hash covers SIX bytes and a bucket holds TWO positions.
+/* LAZY LEVELS (6..9; level 5 keeps the one-way table: the faster step of the ladder): the hash covers SIX bytes and a
+ * bucket holds TWO positions.
  *   key      v = bytes [p, p+4), vh = bytes [p+4, p+6):  t += vh * K3 in the sum above (one more 24-bit multiply).  A
  *            position enters the table (and looks into it) only with six bytes left.  DNA-like data has 256 distinct
  *            4-byte keys in its reads; six bytes find the far repeats libdeflate's chains find (level 6, FASTQ-like
@@ -90,6 +92,7 @@
 #define HD_HASH_K3         0x85EBCAu
 #define HD_HASH_SLOT6(v, vh, entries) \
 	((((((uint32_t)(v) & 0xffffffu) * HD_HASH_K1 + ((uint32_t)(v) >> 16) * HD_HASH_K2 + ((uint32_t)(vh) & 0xffffu) * HD_HASH_K3) >> 16) * (uint32_t)(entries)) >> 16)
+#define HD_DEEP_LEVEL      6           /* first level with the two-way buckets */
 #define HD_LAZY_KEY_BYTES  6
 #define HD_LAZY_WAYS       2
 /* buckets of the two-way tables: 2560 x 4 B with the 8 KiB ring of levels 5..6 (8 parse waves per CU), 2560 with the

@@ -752,9 +752,9 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level == 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
 				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0);
-	if (level <= 6)
+	if (level <= 6)         /* level 5: the one-way table; level 6: the same geometry with the lazy levels' two-way buckets */
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
+				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL);
 	if (level <= 8)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
 				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
