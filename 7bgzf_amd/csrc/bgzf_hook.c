@@ -11,10 +11,13 @@
  *    hip's default as each method has one at :102-112).  BGZF_METHOD unset or empty
  *    means that default too: preloading this library IS the choice of coder (the
  *    reference's default is its zlib at level 6, :54,:102).  A BGZF_METHOD that
- *    names anything else -- the reference's CPU coders, or an unknown name, which
- *    the reference silently runs as zlib -- returns -1, the reference's "coder
- *    missing" value (:136): this library holds no CPU codec, and coding with another
- *    method than the one NAMED would be the worse surprise.
+ *    names one of the reference's CPU coders, or an unknown name (which the reference
+ *    silently runs as zlib, :54), keeps WRITING: the hip coder runs at the level the
+ *    reference would have used for that name -- its digits, else the method's default
+ *    of :102-112 (zlib / libdeflate / zlibng / cryptopp / unknown 6, 7zip 2, the others
+ *    1), cut to 9 -- and one line on stderr says so.  (Rounds 1-2 returned -1, "coder
+ *    missing", for such names: a user with BGZF_METHOD=libdeflate6 left in the
+ *    environment got failing writes where the reference compresses.)
  *  - htslib calls the hook once per 0xff00-byte block from each of its worker
  *    threads and waits for the member.  Calls that arrive together share one
  *    latency-mode batch (hipdeflate_lat_*, HD_FRAME_LATENCY: 16 wavefronts per block
@@ -25,7 +28,7 @@
  *    in a batch on the device has joined, nobody has joined for HIPDEFLATE_LINGER_US
  *    (8) or HIPDEFLATE_BATCH_US microseconds (default 60) have passed, launches, and
  *    publishes the result; the others spin on the batch's state (HIPDEFLATE_SPIN_US,
- *    default 400, then they sleep).  HOOK_CTX batches can be in flight at once (one
+ *    default 400, then they sleep on that word; with more callers than cores they sleep at once).  HOOK_CTX batches can be in flight at once (one
  *    collecting, the others on the device).  A lone caller does not wait at all.
  */
 #include <errno.h>
@@ -37,6 +40,9 @@
 #include <strings.h>
 #include <time.h>
 #include <unistd.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
 #include "hipdeflate.h"
 #include "hipdeflate_params.h"
 
@@ -46,9 +52,7 @@
 
 struct hook_batch {
 	hipdeflate_lat *lat;
-	pthread_mutex_t mu;          /* sleepers of THIS batch only (members that spun long enough) */
-	pthread_cond_t cv;
-	int sleepers;
+	int sleepers;                /* members of THIS batch asleep on `state` (futex) */
 	/* state: 0 free, 1 collecting, 2 closed (copies in flight / on the device), 3 done.  Changed under g_mu
 	 * (0 -> 1 -> 2, 3 -> 0) or by the batch's leader (2 -> 3); read with acquire loads by spinning members */
 	int state;
@@ -64,7 +68,7 @@ static struct hook_batch g_batch[HOOK_CTX];
 static int g_open = -1;       /* the batch that is collecting, -1 = none */
 static int g_active;          /* callers inside the hook right now (atomic) */
 static int g_running;         /* blocks of the batches that are closed and not yet done (under g_mu) */
-static int g_method = -1;     /* -1 unparsed, 0 not ours, 1 hip */
+static int g_method = -1;     /* -1 unparsed, 1 parsed */
 static int g_level = 1;
 static long g_window_us = 60; /* a leader never waits longer than this for the batch to fill */
 static long g_linger_us = 8;  /* ... nor longer than this after the last caller joined */
@@ -96,6 +100,19 @@ static inline int64_t now_ns(void)
 	return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
 }
 
+/* Members that have waited long enough sleep ON THE BATCH'S STATE WORD (futex): the leader's one FUTEX_WAKE releases
+ * all of them at once.  (The condition variable of rounds 1-2 handed its waiters over one by one through its mutex --
+ * microseconds each: with 64 callers on 16 cores, where members must sleep to leave the CPUs to the leaders, a 27-block
+ * batch took 376 us instead of 115 and the CPU reference won that case, 6.24 GB/s against 4.27.) */
+static inline void state_sleep(int *state, int seen)
+{
+	syscall(SYS_futex, state, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0);
+}
+static inline void state_wake_all(int *state)
+{
+	syscall(SYS_futex, state, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+}
+
 static inline void cpu_relax(void)
 {
 #if defined(__x86_64__) || defined(__i386__)
@@ -119,10 +136,22 @@ static void parse_env(void)
 			digit *= 10;
 			i--;
 		}
-		if (i == 3 && !strncasecmp(s, "hip", 3))
+		if (i == 3 && !strncasecmp(s, "hip", 3)) {
 			g_level = level >= 0 ? level : 1;
-		else
-			g_method = 0;
+		} else {
+			/* a name of the reference's table, or an unknown one (its zlib): its level, our coder */
+			static const struct { const char *name; int deflt; } ref[] = {
+				{ "zlib", 6 }, { "7zip", 2 }, { "7-zip", 2 }, { "zopfli", 1 }, { "miniz", 1 }, { "slz", 1 }, { "libslz", 1 },
+				{ "libdeflate", 6 }, { "zlibng", 6 }, { "igzip", 1 }, { "cryptopp", 6 } };
+			int deflt = 6;
+			for (size_t k = 0; k < sizeof(ref) / sizeof(ref[0]); k++)
+				if (strlen(ref[k].name) == i && !strncasecmp(s, ref[k].name, i))
+					deflt = ref[k].deflt;
+			g_level = level >= 0 ? level : deflt;
+			if (g_level > 9)
+				g_level = 9;
+			fprintf(stderr, "hipdeflate: BGZF_METHOD=%s: this library holds the hip coder only; coding with hip%d\n", s, g_level);
+		}
 	}
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
@@ -199,11 +228,6 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	pthread_mutex_lock(&g_mu);
 	if (g_method < 0)
 		parse_env();
-	if (g_method != 1) {
-		pthread_mutex_unlock(&g_mu);
-		fprintf(stderr, "hipdeflate: BGZF_METHOD must be hip<level> (or unset); no other coder in this library\n");
-		return -1;
-	}
 	if (*_dlen < 26) {                          /* bgzf_compress.c:116 */
 		pthread_mutex_unlock(&g_mu);
 		return -1;
@@ -237,8 +261,6 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 					pthread_mutex_unlock(&g_mu);
 					return -1;                          /* coder missing */
 				}
-				pthread_mutex_init(&b->mu, NULL);
-				pthread_cond_init(&b->cv, NULL);
 			}
 			__atomic_store_n(&b->n, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->ready, 0, __ATOMIC_RELAXED);
@@ -307,7 +329,9 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		pthread_mutex_lock(&g_mu);
 		g_running -= n;
 		pthread_mutex_unlock(&g_mu);
-		__atomic_store_n(&b->state, 3, __ATOMIC_RELEASE);
+		/* (an exchange, i.e. a full fence: the load of `sleepers` below must not pass this store -- a member that
+		 * has counted itself in and still reads state 2 goes to sleep) */
+		(void)__atomic_exchange_n(&b->state, 3, __ATOMIC_SEQ_CST);
 		if (g_stats) {
 			ST_ADD(st_batches, 1);
 			ST_ADD(st_blocks, n);
@@ -315,31 +339,30 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 			ST_ADD(st_ready, t_ready - t_closed);
 			ST_ADD(st_run, now_ns() - t_ready);
 		}
-		pthread_mutex_lock(&b->mu);
-		if (b->sleepers)
-			pthread_cond_broadcast(&b->cv);
-		pthread_mutex_unlock(&b->mu);
+		if (__atomic_load_n(&b->sleepers, __ATOMIC_SEQ_CST))
+			state_wake_all(&b->state);
 	} else {
 		/* spin for the batch (all members see it within a cache miss of the leader's store; a condition variable
 		 * hands its waiters over one by one, microseconds each), sleep only when it takes long */
 		/* (more callers than cores: spinning members would keep the leaders off the CPUs -- they hand the CPU on
 		 * with sched_yield() between looks instead; sleeping on the condition variable at once wakes a batch's
 		 * members one by one through its mutex, which measured 4.2 GB/s at 64 callers on 16 cores) */
+		/* more callers than cores: a spinning (or yielding) member only keeps a leader off its CPU -- those members
+		 * sleep at once; otherwise a member spins g_spin_us for its batch first (it sees the leader's store within a
+		 * cache miss) */
 		const int crowded = __atomic_load_n(&g_active, __ATOMIC_RELAXED) > g_ncpu;
-		const int64_t deadline = now_ns() + (crowded ? 4 : 1) * g_spin_us * 1000;
-		int spins = 0;
-		while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) != 3) {
-			if (crowded)
-				sched_yield();
-			else
+		const int64_t deadline = crowded ? 0 : now_ns() + g_spin_us * 1000;
+		int spins = 0, st;
+		while ((st = __atomic_load_n(&b->state, __ATOMIC_ACQUIRE)) != 3) {
+			if (crowded || ((++spins & 63) == 0 && now_ns() > deadline)) {
+				__atomic_add_fetch(&b->sleepers, 1, __ATOMIC_SEQ_CST);
+				/* (the state may be 1 or 2 here; a change to either wakes nobody, so sleep only on what is seen and
+				 * look again: FUTEX_WAIT returns at once when the word has moved on) */
+				if (__atomic_load_n(&b->state, __ATOMIC_SEQ_CST) == st)
+					state_sleep(&b->state, st);
+				__atomic_sub_fetch(&b->sleepers, 1, __ATOMIC_ACQ_REL);
+			} else {
 				cpu_relax();
-			if ((crowded || (++spins & 63) == 0) && now_ns() > deadline) {
-				pthread_mutex_lock(&b->mu);
-				b->sleepers++;
-				while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) != 3)
-					pthread_cond_wait(&b->cv, &b->mu);
-				b->sleepers--;
-				pthread_mutex_unlock(&b->mu);
 			}
 		}
 		if (g_stats)

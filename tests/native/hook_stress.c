@@ -73,7 +73,7 @@ int main(int argc, char **argv)
 	const int T = argc > 1 ? atoi(argv[1]) : 64;
 	if (argc > 2)
 		g_calls = atoi(argv[2]);
-	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)T);
+	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)(T > 8 ? T : 8));
 	for (int i = 0; i < T; i++)
 		pthread_create(&th[i], NULL, worker, (void *)(uintptr_t)i);
 	for (int i = 0; i < T; i++)

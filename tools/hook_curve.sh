@@ -16,7 +16,9 @@ for T in 1 4 8 16 64; do
   HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=hip1 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
 done
 for T in 8 16; do
-  HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=hip6 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
+  for M in hip2 hip5 hip6; do
+    HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=$M ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
+  done
 done
 if [ -x oracle/_ref/hook_bench_ref ] && [ "$2" != quick ]; then
   for T in 1 4 8 16 64; do
