@@ -31,6 +31,7 @@
  *    default 400, then they sleep on that word; with more callers than cores they sleep at once).  HOOK_CTX batches can be in flight at once (one
  *    collecting, the others on the device).  A lone caller does not wait at all.
  */
+#define _GNU_SOURCE
 #include <errno.h>
 #include <pthread.h>
 #include <sched.h>
@@ -84,9 +85,9 @@ __attribute__((destructor)) static void hook_stats_print(void)
 {
 	if (!g_stats || !st_calls)
 		return;
-	fprintf(stderr, "hipdeflate hook: %lld calls in %lld batches (%.1f blocks each); us per call: wait for a context %.1f, copy in %.1f, "
+	fprintf(stderr, "hipdeflate hook (%d usable CPUs): %lld calls in %lld batches (%.1f blocks each); us per call: wait for a context %.1f, copy in %.1f, "
 		"copy out %.1f, member waits for its batch %.1f; us per batch: leader's window %.1f, others' copies %.1f, device %.1f\n",
-		(long long)st_calls, (long long)st_batches, st_batches ? (double)st_blocks / st_batches : 0.0,
+		g_ncpu, (long long)st_calls, (long long)st_batches, st_batches ? (double)st_blocks / st_batches : 0.0,
 		st_ctx_wait / 1e3 / st_calls, st_copy_in / 1e3 / st_calls, st_copy_out / 1e3 / st_calls,
 		st_member_wait / 1e3 / (st_calls - st_batches ? st_calls - st_batches : 1), st_window / 1e3 / (st_batches ? st_batches : 1),
 		st_ready / 1e3 / (st_batches ? st_batches : 1), st_run / 1e3 / (st_batches ? st_batches : 1));
@@ -118,6 +119,50 @@ static inline void cpu_relax(void)
 #if defined(__x86_64__) || defined(__i386__)
 	__builtin_ia32_pause();
 #endif
+}
+
+/* CPUs this process may really use: the affinity mask, cut by the cgroup's CPU quota (a container on a 128-core host
+ * with 16 CPUs' worth of quota reports 128 through sysconf: members would spin where they must sleep) */
+static int usable_cpus(void)
+{
+	int n = 0;
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0)
+		n = CPU_COUNT(&set);
+	if (n <= 0) {
+		const long nc = sysconf(_SC_NPROCESSORS_ONLN);
+		n = nc > 0 ? (int)nc : 1;
+	}
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");              /* cgroup v2: "<quota> <period>" or "max <period>" */
+	if (f) {
+		long long q = 0, per = 0;
+		if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) {
+			const int c = (int)((q + per - 1) / per);
+			if (c >= 1 && c < n)
+				n = c;
+		}
+		fclose(f);
+	} else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {       /* cgroup v1 */
+		long long q = -1, per = 100000;
+		if (fscanf(f, "%lld", &q) != 1)
+			q = -1;
+		fclose(f);
+		FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+		if (g) {
+			if (fscanf(g, "%lld", &per) != 1)
+				per = 100000;
+			fclose(g);
+		}
+		if (q > 0 && per > 0) {
+			const int c = (int)((q + per - 1) / per);
+			if (c >= 1 && c < n)
+				n = c;
+		}
+	}
+	const char *o = getenv("HIPDEFLATE_CPUS");
+	if (o && *o && atoi(o) > 0)
+		n = atoi(o);
+	return n;
 }
 
 static void parse_env(void)
@@ -156,8 +201,7 @@ static void parse_env(void)
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
 		g_window_us = atol(w);
-	const long nc = sysconf(_SC_NPROCESSORS_ONLN);
-	g_ncpu = nc > 0 ? (int)nc : 1;
+	g_ncpu = usable_cpus();
 	const char *lg = getenv("HIPDEFLATE_LINGER_US");
 	if (lg && *lg)
 		g_linger_us = atol(lg);

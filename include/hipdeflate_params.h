@@ -97,7 +97,10 @@
 #define HD_LAZY_WAYS       2
 /* buckets of the two-way tables: 2560 x 4 B with the 8 KiB ring of levels 5..6 (8 parse waves per CU), 2560 with the
  * 16 KiB ring of levels 7..8 (5 waves), 4096 at level 9 (4 waves) */
-#define HD_BUCKETS(win_bits, hash_bits) ((win_bits) == 14 && (hash_bits) == 13 ? 4096u : 2560u)
+#ifndef HD_L6_BUCKETS
+#define HD_L6_BUCKETS 2560u            /* (1536: ten parse waves per CU instead of eight -- measured below) */
+#endif
+#define HD_BUCKETS(win_bits, hash_bits) ((win_bits) == 14 && (hash_bits) == 13 ? 4096u : (win_bits) == 13 ? HD_L6_BUCKETS : 2560u)
 
 /* Entries of the hash table.  LDS is granted in 1280-byte units, so the table sizes are what fills the units the ring
  * leaves: 1536 entries with the 4 KiB ring of levels 1..2 (7 units, 18 waves per CU instead of 16 with 2048) and the

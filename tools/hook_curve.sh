@@ -12,7 +12,7 @@ s.fastq_like(64<<20, seed=1234).tofile('/tmp/hook_fq.bin')
 : > $OUT/hook_curve.jsonl
 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin 0 >> $OUT/hook_curve.jsonl
 HOOK_LEVEL=6 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin 0 >> $OUT/hook_curve.jsonl
-for T in 1 4 8 16 64; do
+for T in 1 4 8 16 32 64; do
   HIPDEFLATE_HOOK_STATS=1 BGZF_METHOD=hip1 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl 2>> $OUT/hook_stats.txt
 done
 for T in 8 16; do
@@ -21,7 +21,7 @@ for T in 8 16; do
   done
 done
 if [ -x oracle/_ref/hook_bench_ref ] && [ "$2" != quick ]; then
-  for T in 1 4 8 16 64; do
+  for T in 1 4 8 16 32 64; do
     BGZF_METHOD=libdeflate1 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl
   done
   BGZF_METHOD=libdeflate6 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin 16 2 >> $OUT/hook_curve.jsonl
