@@ -38,10 +38,18 @@ def as_u8(data):
 
 
 _oracle = None
+_oracle_lock = __import__("threading").Lock()
 
 
 def oracle():
-    """liboracle.so, built on demand (gcc, < 2 s)."""
+    """liboracle.so, built on demand (gcc, < 2 s).  (Under a lock: the fuzz tools call this from a thread pool, and two
+    `make` runs writing one file handed a third thread half a library -- "file too short".)"""
+    global _oracle
+    with _oracle_lock:
+        return _oracle_locked()
+
+
+def _oracle_locked():
     global _oracle
     if _oracle is None:
         so = os.path.join(ORACLE_DIR, "liboracle.so")
