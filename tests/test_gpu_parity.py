@@ -251,6 +251,31 @@ def test_encode_phrase_blocks_match_twin(pkg, level):
             assert zlib.decompress(members[i], -15) == d, i
 
 
+@pytest.mark.parametrize("level", [1, 2, 5, 6, 9])
+def test_encode_blocks_around_two_to_the_sixteenth_match_twin(pkg, level):
+    """Blocks of exactly 0x10000 bytes (the reference's single-thread block size, applet/7bgzf.c:146-147) run through the
+    INNER steps since round 3 -- position + 1 of the last table entry still fits 16 bits --, one byte more does not: both
+    sides of the line, FASTQ-like and text, against the twin (which has no such distinction)."""
+    s = hdtest.synth()
+    blocks = []
+    for n in (0xffff, 0x10000, 0x10001, 0x10000, 0x10040, 0xff00):
+        blocks.append(bytes(s.fastq_like(n, seed=300 + len(blocks))))
+        blocks.append(bytes(s.text_like(n, seed=400 + len(blocks))))
+    data = b"".join(blocks)
+    offs, lens, o = [], [], 0
+    for b in blocks:
+        offs.append(o)
+        lens.append(len(b))
+        o += len(b)
+    slot = (0x10040 + 0x10040 // 8 + 4096 + 15) & ~15
+    members, crc, st = pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_RAW, slot=slot)
+    for i, b in enumerate(blocks):
+        assert st[i] == 0
+        r, twin = hdtest.oracle_twin(b, level, cap=slot)
+        assert r == 0 and members[i] == twin, (i, len(b), level, len(members[i]), len(twin))
+        assert zlib.decompress(members[i], -15) == b and int(crc[i]) == zlib.crc32(b)
+
+
 @pytest.mark.parametrize("level", [2, 6])
 def test_encode_many_small_blocks_across_sub_batches(pkg, level):
     """70000 blocks of 1000 bytes: more than one parse + emit launch pair of the split path (at most
