@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// unaligned 8-byte read never wrap
 	__shared__ __attribute__((aligned(W))) uint32_t ring32[W / 4 + 4];       // W-aligned: ring address = (x & (W - 1)) | base
 	// (position + 1) mod 2^16, 0 = empty
-	__shared__ __attribute__((aligned(16))) uint16_t table[HS];
+	__shared__ __attribute__((aligned(16))) uint16_t table[HS + (DEEP ? 2 : 0)];      // DEEP: + a spare dword for the deferred stores of lanes without a position
 	// TOK: no bits are made here, the staging ring's place is taken by the symbol histograms
 	// (316 counters: litlen [0,286), offset [286,316).  LDS is granted in 1280-byte units, every byte counts:
 	// where it buys another wave per CU -- the level 5-6 geometry -- the counters are 16 bits wide, two to a
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	hk.init(HS);
 	HashConsts6 hk6;
 	hk6.init(NB);
+	uint32_t pub_addr = 2u * HS, pub_val = 0;    // DEEP: the last fetch's bucket stores, issued by the next one
 	CrcLanes crc;
 	crc.init(lane, n);
 	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
@@ -385,12 +386,37 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// INNER: every lane of the step has >= 9 bytes left and the block is shorter than
 	// 2^16 (all BGZF blocks; all but their last steps), so the end-of-block and the
 	// 16-bit wrap-around handling drop out at compile time
+	// OWN_AHEAD (the parse kernels, which run two to four waves per SIMD and wait where level 1 issues): the three ring
+	// dwords under a lane's own position are read ONE STEP AHEAD of the fetch that hashes them -- a fourth pipeline
+	// stage -- so that the table lookup no longer waits for an LDS round trip inside its own step
+	// MEASURED AND SWITCHED OFF (round 3, same box): level 6 116.9 -> 112.2 GB/s, level 5 148.8 -> 143.4, level 9 68.2 -> 64.7:
+	// at two waves per SIMD every instruction costs its issue slot, the hand-over copies and seven more registers cost
+	// more than the round trip they hide.  (And not for the level-2 geometry in any case: 99 VGPRs would cost it a wave.)
+	constexpr bool OWN_AHEAD = false;
+	struct Own {
+		uint32_t w0, w1, w2;
+	};
+	auto own = [&](uint32_t S_) -> Own {
+		const uint32_t *w = &ring32[((S_ + lane) >> 2) & W4M];
+		Own o = { w[0], w[1], w[2] };
+		return o;
+	};
+	Own o1 = { 0, 0, 0 };                     // OWN_AHEAD: the dwords under S + 192 + lane
 	auto fetch = [&](auto inner_tag, uint32_t S_) -> Fetched {
 		constexpr bool INNER = decltype(inner_tag)::value;
 		Fetched f;
 		const uint32_t p = S_ + lane;
 		const uint32_t *w = &ring32[(p >> 2) & W4M];
-		const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+		uint32_t w0, w1, w2;
+		if (OWN_AHEAD && S_ >= 128) {         // (the two fetches of the prologue read their own)
+			w0 = o1.w0;
+			w1 = o1.w1;
+			w2 = o1.w2;
+		} else {
+			w0 = w[0];
+			w1 = w[1];
+			w2 = w[2];
+		}
 		f.v = __builtin_amdgcn_alignbyte(w1, w0, p & 3);
 		f.vh = __builtin_amdgcn_alignbyte(w2, w1, p & 3);
 		const bool can = INNER || p + (DEEP ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH) <= n;
@@ -399,11 +425,15 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		if (DEEP) {
 			// one dword bucket: low half the newest position, high half the one before; every lane stores
 			// (what it read << 16) | itself -- { newest before the step, highest lane of the step } stays
+			// The store waits for the bucket it is made of: issued here it parked every wave on its own LDS read once
+			// per step (SQ_WAIT_ANY 33 % of the deep parse).  It goes out at the head of the NEXT fetch instead --
+			// still in front of that step's reads, which is all the order the twin knows: a step's positions are in
+			// the table before the next step looks.  (Lanes without a position store to a spare dword behind the table.)
+			*(uint32_t *)((uint8_t *)table + pub_addr) = pub_val;
 			const uint32_t ha = hash_slot_addr6(f.v, f.vh, hk6);
-			uint32_t *const slot = (uint32_t *)((uint8_t *)table + (can ? ha : 0u));
-			const uint32_t eb = *slot;
-			if (can)
-				*slot = (eb << 16) | ((p + 1) & 0xffffu);
+			const uint32_t eb = *(const uint32_t *)((const uint8_t *)table + (can ? ha : 0u));
+			pub_addr = can ? ha : 2u * HS;
+			pub_val = (eb << 16) | ((p + 1) & 0xffffu);
 			e = eb & 0xffffu;
 			e2 = eb >> 16;
 		} else {
@@ -540,6 +570,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f0 = fetch(std::false_type{}, 0);
 		q0 = probe(f0.c, lane, f0.c2);
 		f1 = fetch(std::false_type{}, 64);
+		if (OWN_AHEAD)
+			o1 = own(128);
 	}
 	uint32_t carry = 0;                  // leading positions covered by the last match
 	// one step; false = the static stream was abandoned
@@ -558,6 +590,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		f0 = f1;
 		q0 = probe(f1.c, S + 64 + lane, f1.c2);   // harmless beyond n: every index is masked into the ring
 		f1 = fetch(inner_tag, S + 128);
+		if (OWN_AHEAD)
+			o1 = own(S + 192);                 // (every index is masked into the ring; bytes beyond the block never count)
 
 		// ---- 3. verify the candidate + first 8 bytes of its length ---------
 		// Conditions live as 64-bit lane masks in scalar registers (hd_device.hpp "lane masks"): each is the

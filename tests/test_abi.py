@@ -162,7 +162,9 @@ def test_kernel_resource_budgets():
     (v,) = emit.values()
     assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
     for k, v in sta.items():                                     # level 1 and the parse kernels of levels 2-9
-        assert v["VGPRs"] <= 128, (k, v)
+        # the level-1 geometry runs 18 waves per CU = five per SIMD on two of them: <= 96 VGPRs; the two-way parse kernels
+        # (8 / 5 / 4 waves per CU) have 168; the others <= 128 (four per SIMD)
+        assert v["VGPRs"] <= (96 if "Li12ELi11E" in k else 168 if k.endswith("ELi1EEEvNS_11DeflateArgsE") else 128), (k, v)
         units = -(-v["LDS Size"] // 1280)
         tok = "ELb1E" in k                           # parse kernels; level 1 itself is ELb0E
         deep = k.endswith("ELi1EEEvNS_11DeflateArgsE")
