@@ -74,6 +74,11 @@ static int g_level = 1;
 static long g_window_us = 60; /* a leader never waits longer than this for the batch to fill */
 static long g_linger_us = 8;  /* ... nor longer than this after the last caller joined */
 static long g_spin_us = 400;  /* a member spins this long for its batch before it sleeps */
+/* batches on the device at once.  Two run side by side at the price of one (hipdeflate_lat_run on 8 blocks, level 2: 152 us
+ * alone, 173 us each for two), a third and fourth do not (266, 297 us each -- tools/hook_bench.c HOOK_PAR): while two are out,
+ * the collecting batch stays open and grows */
+static int g_max_inflight = 2;
+static int g_inflight;         /* under g_mu; read without by a leader in its window */
 static int g_batch_target = HOOK_MAX_BATCH;
 static int g_failed;
 static int g_ncpu = 1;
@@ -207,6 +212,9 @@ static void parse_env(void)
 		g_linger_us = atol(lg);
 	const char *hs = getenv("HIPDEFLATE_HOOK_STATS");
 	g_stats = hs && *hs && *hs != '0';
+	const char *fl = getenv("HIPDEFLATE_INFLIGHT");
+	if (fl && atoi(fl) >= 1)
+		g_max_inflight = atoi(fl);
 	const char *sp = getenv("HIPDEFLATE_SPIN_US");
 	if (sp && *sp)
 		g_spin_us = atol(sp);
@@ -322,9 +330,10 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	 * (callers released together by the previous batch come back within microseconds of each other, and count
 	 * as inside while they copy their members out).  Or the batch is full. */
 	const int want = __atomic_load_n(&g_active, __ATOMIC_RELAXED) - g_running;
-	if (b->n >= g_batch_target || b->n >= HOOK_MAX_BATCH || b->n >= want) {
+	if (b->n >= HOOK_MAX_BATCH || ((b->n >= g_batch_target || b->n >= want) && g_inflight < g_max_inflight)) {
 		__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
 		g_running += b->n;
+		__atomic_add_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
 		g_open = -1;
 	}
 	pthread_mutex_unlock(&g_mu);
@@ -342,7 +351,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		 * it himself when nobody has joined for g_linger_us although callers are missing (they are busy elsewhere),
 		 * or when the window is over. */
 		if (g_window_us > 0) {
-			const int64_t t0 = now_ns(), deadline = t0 + g_window_us * 1000;
+			const int64_t t0 = now_ns(), deadline = t0 + g_window_us * 1000, hard = t0 + 2000000;
 			int64_t t_last = t0;
 			int seen = 1;
 			while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) == 1) {
@@ -352,7 +361,9 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 					seen = cur;
 					t_last = t;
 				}
-				if (t >= deadline || t - t_last >= g_linger_us * 1000)
+				/* (while g_max_inflight batches are out the window stays open -- 2 ms at most, should one hang) */
+				if ((t >= deadline || t - t_last >= g_linger_us * 1000) &&
+				    (__atomic_load_n(&g_inflight, __ATOMIC_RELAXED) < g_max_inflight || t >= hard))
 					break;
 				cpu_relax();
 			}
@@ -361,6 +372,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		if (__atomic_load_n(&b->state, __ATOMIC_RELAXED) == 1) {          /* window over */
 			__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
 			g_running += b->n;
+			__atomic_add_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
 			g_open = -1;
 		}
 		const int n = b->n;
@@ -372,6 +384,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		b->rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
 		pthread_mutex_lock(&g_mu);
 		g_running -= n;
+		__atomic_sub_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
 		pthread_mutex_unlock(&g_mu);
 		/* (an exchange, i.e. a full fence: the load of `sleepers` below must not pass this store -- a member that
 		 * has counted itself in and still reads state 2 goes to sleep) */
@@ -391,10 +404,11 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		/* (more callers than cores: spinning members would keep the leaders off the CPUs -- they hand the CPU on
 		 * with sched_yield() between looks instead; sleeping on the condition variable at once wakes a batch's
 		 * members one by one through its mutex, which measured 4.2 GB/s at 64 callers on 16 cores) */
-		/* more callers than cores: a spinning (or yielding) member only keeps a leader off its CPU -- those members
-		 * sleep at once; otherwise a member spins g_spin_us for its batch first (it sees the leader's store within a
-		 * cache miss) */
-		const int crowded = __atomic_load_n(&g_active, __ATOMIC_RELAXED) > g_ncpu;
+		/* as many callers as cores, or more: a spinning (or yielding) member only keeps a leader -- or the HIP runtime's
+		 * own thread, which a leader's hipStreamSynchronize waits for -- off its CPU: those members sleep at once (16
+		 * callers on 16 CPUs, hip2: 4.51 -> 4.76 GB/s); otherwise a member spins g_spin_us for its batch first (it
+		 * sees the leader's store within a cache miss) */
+		const int crowded = __atomic_load_n(&g_active, __ATOMIC_RELAXED) + 1 >= g_ncpu;
 		const int64_t deadline = crowded ? 0 : now_ns() + g_spin_us * 1000;
 		int spins = 0, st;
 		while ((st = __atomic_load_n(&b->state, __ATOMIC_ACQUIRE)) != 3) {

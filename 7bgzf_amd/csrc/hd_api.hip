@@ -1425,6 +1425,15 @@ int hipdeflate_test_emit_stats(uint64_t *out8)
 #endif
 
 #ifdef HD_CLOCK_STAMPS
+// diagnostic build: sums of cycles from wave start to the marks of the level-1 / parse kernel (read and cleared)
+int hipdeflate_test_clock_marks(uint64_t *out16)
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hd::g_clk_mark), 128));
+	static const uint64_t zero[16] = { 0 };
+	HD_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hd::g_clk_mark), zero, 128));
+	return 0;
+}
 // diagnostic build: per kernel { shader cycles, 100 MHz ticks, waves, - } summed over the waves since the last call
 int hipdeflate_test_clock(uint64_t *out16)
 {

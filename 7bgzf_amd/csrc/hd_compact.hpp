@@ -106,16 +106,9 @@ __global__ __launch_bounds__(256) void k_scan_finish(const uint32_t *len, uint32
 	}
 }
 
-// one wavefront per member: slots + i*stride (16-byte aligned) -> dst + dst_off[i]
-__global__ __launch_bounds__(64) void k_compact(const uint8_t *slots, uint64_t stride, const uint32_t *len,
-						const uint64_t *dst_off, uint32_t n, uint8_t *dst)
+// one wavefront copies L bytes from s (16-byte aligned) to d (any alignment), whole destination dwords in the middle
+__device__ __forceinline__ void compact_one(const uint8_t *s, uint32_t L, uint8_t *d, uint32_t lane)
 {
-	const uint32_t i = blockIdx.x, lane = threadIdx.x;
-	if (i >= n)
-		return;
-	const uint32_t L = len[i];
-	const uint8_t *s = slots + (uint64_t)i * stride;
-	uint8_t *d = dst + dst_off[i];
 	// head: bytes until d is dword aligned
 	uint32_t head = (uint32_t)((4 - ((uintptr_t)d & 3)) & 3);
 	if (head > L)
@@ -135,6 +128,16 @@ __global__ __launch_bounds__(64) void k_compact(const uint8_t *slots, uint64_t s
 	const uint32_t done = head + 4 * body;
 	if (lane < L - done)
 		d[done + lane] = s[done + lane];
+}
+
+// one wavefront per member: slots + i*stride (16-byte aligned) -> dst + dst_off[i]
+__global__ __launch_bounds__(64) void k_compact(const uint8_t *slots, uint64_t stride, const uint32_t *len,
+						const uint64_t *dst_off, uint32_t n, uint8_t *dst)
+{
+	const uint32_t i = blockIdx.x, lane = threadIdx.x;
+	if (i >= n)
+		return;
+	compact_one(slots + (uint64_t)i * stride, len[i], dst + dst_off[i], lane);
 }
 
 // RFC 1950 members (HD_FRAME_ZLIB): the Adler-32 of every block's input, written big-endian

@@ -86,10 +86,24 @@ inline uint64_t fused_scratch_bytes(uint32_t nblocks, int level)
 	return (uint64_t)dynamic_grid(nblocks, level) * DYN_SLAB_TOKENS * 4;
 }
 
-inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int level)
+// segments parsed in parts (HD_LAT_PARTS; latency mode): segments per parse + emit launch pair -- all of them unless the
+// batch is huge -- and the records they need
+inline uint32_t part_sub_batch(uint32_t nsegs, uint32_t parts)
+{
+	uint64_t sub = SPLIT_SCRATCH_BUDGET / ((uint64_t)parts * part_layout().bytes);
+	if (sub > SPLIT_SUB_BATCH_MAX)
+		sub = SPLIT_SUB_BATCH_MAX;
+	return sub < nsegs ? (uint32_t)sub : nsegs;
+}
+
+// parts != 0: the blocks are latency segments parsed in that many parts
+inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int level, uint32_t parts = 0)
 {
 	if (level < 2)
 		return 0;
+	if (parts)
+		return fused_scratch_bytes(nblocks, level) + (uint64_t)nblocks * 4 +
+		       (uint64_t)part_sub_batch(nblocks, parts) * parts * part_layout().bytes + 16;
 	return fused_scratch_bytes(nblocks, level) + (uint64_t)nblocks * 4 +                 // + the overflow flags
 	       (uint64_t)split_sub_batch(nblocks, split_max, level) * split_layout(split_max).bytes + 16;
 }
@@ -313,9 +327,11 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // EMIT = 1: emit-only mode, the second half of the level-2 split path: tokens, histograms and
 // CRC of blocks [a.first, a.first + a.count) are in the scratch (written by k_deflate_static<.., true>),
 // this kernel builds the codes and writes the members exactly as the fused mode would have.
-template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0>
+// PARTS (EMIT only): the tokens of a block lie in PARTS records, one per parse part (hipdeflate_params.h HD_LAT_PARTS)
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0, int PARTS = 0>
 __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 {
+	static_assert(!PARTS || EMIT, "parts are a matter of the emit-only kernel");
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
 	// DEEP (the lazy levels, hipdeflate_params.h "LAZY LEVELS"): dword buckets of two positions; HS counts 16-bit units
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
-		if (EMIT ? a.split_ovf[b] != 0 : (a.skip_small && a.split_ovf[b] == 0))
+		if (PARTS ? false : EMIT ? a.split_ovf[b] != 0 : (a.skip_small && a.split_ovf[b] == 0))
 			continue;                            // the other path's block
 		if (!EMIT && a.seg_limit && n > a.seg_limit)
 			continue;                            // coded in segments (hd_segment.hpp)
@@ -395,6 +411,16 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		const uint32_t paybase = 8 * hdr;
 		uint32_t ntok = 0;                   // tokens of the open DEFLATE block: in the slab + still queued
 		uint32_t ntok_slab = 0, qhead = 0, qtail = 0;
+		// PARTS: token k of the block is tok[k + sum of pgap[q] over the parts q >= 1 that start at or before k]
+		// (pcum[q] = tokens ahead of part q; pgap[q] = what is left of part q - 1's slab behind its tokens)
+		uint32_t pcum[PARTS ? PARTS : 1], pgap[PARTS ? PARTS : 1];
+		auto tix = [&](uint32_t k) -> uint32_t {
+			uint32_t o = k;
+#pragma unroll
+			for (int q = 1; q < PARTS; q++)
+				o += k >= pcum[q] ? pgap[q] : 0u;
+			return o;
+		};
 
 		auto put = [&](uint32_t code, uint32_t nbits, uint32_t bp) {
 			if (nbits) {
@@ -693,13 +719,13 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				uint32_t cur[PF], nxt[PF];
 #pragma unroll
 				for (uint32_t j = 0; j < PF; j++)
-					nxt[j] = 64 * j + lane < ntok_slab ? tok[64 * j + lane] : 0u;
+					nxt[j] = 64 * j + lane < ntok_slab ? tok[tix(64 * j + lane)] : 0u;
 				for (uint32_t base = 0; base < ntok_slab; base += 64 * PF) {
 #pragma unroll
 					for (uint32_t j = 0; j < PF; j++) {
 						cur[j] = nxt[j];
 						const uint32_t kn = base + 64 * (PF + j) + lane;
-						nxt[j] = kn < ntok_slab ? tok[kn] : 0u;
+						nxt[j] = kn < ntok_slab ? tok[tix(kn)] : 0u;
 					}
 #pragma unroll
 					for (uint32_t j = 0; j < PF; j++)
@@ -915,8 +941,51 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 		}
 		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 		} else {
-			// the parse has been done: one flush per recorded DEFLATE block
 			const uint32_t bi = b - a.first;
+			if (PARTS) {
+				// the parse has been done in parts, one wavefront each (k_deflate_static, `parted`): ONE DEFLATE block
+				// of all their tokens, its histograms the sums, its CRC from crc(A || B) = crc(A) x^(8 |B|) ^ crc(B)
+				const SplitLayout lay = part_layout();
+				const uint32_t rec_dw = (uint32_t)(lay.bytes / 4);
+				const uint8_t *rec0 = part_block(a.scratch, bi * PARTS);
+				const uint32_t np = (n + HD_LAT_PART_BYTES - 1) / HD_LAT_PART_BYTES;      // <= PARTS (the launch's promise)
+				uint32_t lf[5] = { 0, 0, 0, 0, 0 }, dfv = 0, total = 0, prev = 0;
+				{
+					// lane q moves part q's CRC to the end of the segment (the bytes behind the part appended), the lanes
+					// are XOR-ed: the shifts of all parts side by side instead of one fold after the other
+					uint32_t c = 0;
+					if (lane < np) {
+						const uint32_t end = (lane + 1) * HD_LAT_PART_BYTES < n ? (lane + 1) * HD_LAT_PART_BYTES : n;
+						c = crc_append_bytes(ct, ((const uint32_t *)(rec0 + (uint64_t)lane * lay.bytes + lay.off_rec))[1], n - end);
+					}
+					crcv = wave_xor_reduce(c);
+				}
+#pragma unroll
+				for (int q = 0; q < PARTS; q++) {
+					const uint8_t *rec = rec0 + (uint64_t)q * lay.bytes;
+					const bool there = (uint32_t)q < np;
+					const uint32_t *h = (const uint32_t *)(rec + lay.off_hist);
+#pragma unroll
+					for (int i = 0; i < 5; i++)
+						lf[i] += (there && 64 * i + lane < 288) ? h[64 * i + lane] : 0u;
+					dfv += (there && lane < 32) ? h[288 + lane] : 0u;
+					const uint32_t ntq = there ? uniform(*(const uint32_t *)(rec + lay.off_ntok)) : 0u;
+					pcum[q] = total;
+					pgap[q] = q ? rec_dw - prev : 0u;
+					total += ntq;
+					prev = ntq;
+				}
+#pragma unroll
+				for (int i = 0; i < 5; i++)
+					if (64 * i + lane < 288)
+						L.lf[64 * i + lane] = lf[i];
+				if (lane < 32)
+					L.df[lane] = dfv;
+				tok = (uint32_t *)rec0;
+				ntok_slab = total;
+				alive = flush_block(true);
+			} else {
+			// the parse has been done: one flush per recorded DEFLATE block
 			const SplitLayout lay = split_layout(a.split_max);
 			const uint8_t *rec = split_block(a.scratch, a.split_max, bi);
 			const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
@@ -934,6 +1003,7 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				ntok_slab = nt[k];
 				alive = flush_block(k + 1 == ndb);
 				t0 += nt[k];
+			}
 			}
 		}
 
@@ -978,11 +1048,24 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
-	const uint32_t sub = split_sub_batch(a.nblocks, a.split_max, level);
+	const uint32_t sub = a.parts ? part_sub_batch(a.nblocks, a.parts) : split_sub_batch(a.nblocks, a.split_max, level);
 	DeflateArgs s = a;
 	// scratch: [ fused slabs | overflow flags, one u32 per block | split records of one sub-batch ]
 	s.split_ovf = (uint32_t *)(a.scratch + fused_scratch_bytes(a.nblocks, level));
 	s.scratch = (uint8_t *)s.split_ovf + (((uint64_t)a.nblocks * 4 + 15) & ~(uint64_t)15);
+	if (a.parts) {
+		// latency segments (hd_segment.hpp sets a.parts = HD_LAT_PARTS): a parse wavefront per part, an emit wavefront per
+		// segment, and nothing for a fused kernel to take over -- a part's slab holds a token per byte
+		for (uint32_t first = 0; first < a.nblocks; first += sub) {
+			s.first = first;
+			s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
+			hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY, INTRA, DEEP>), dim3(s.count * HD_LAT_PARTS_MAX), dim3(64), 0, st, s);
+			const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
+			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, HD_LAT_PARTS_MAX>), dim3(eg),
+					   dim3(64), 0, st, s);
+		}
+		return;
+	}
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;

@@ -61,6 +61,9 @@ struct DeflateArgs {
 	uint32_t hint;                  // HD_HINT_*
 	const uint64_t *host_seg_off;
 	const uint32_t *host_seg_len;
+	// split path, latency segments of the dynamic levels (HD_LAT_PARTS): != 0 = every block of in_off/in_len is PARSED
+	// as this many parts of HD_LAT_PART_BYTES, one wavefront each, and emitted as one DEFLATE block by one
+	uint32_t parts = 0;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -203,12 +206,13 @@ struct SplitLayout {
 	uint32_t cap_tok, max_db;
 	uint64_t off_rec, off_ntok, off_hist, bytes;
 };
-__host__ __device__ inline SplitLayout split_layout(uint32_t max_block)
+// full: room for one token per byte -- the parts of a latency segment (HD_LAT_PARTS), which have no fused kernel behind them
+__host__ __device__ inline SplitLayout split_layout(uint32_t max_block, bool full = false)
 {
 	SplitLayout l;
 	// three tokens per four input bytes: text parsed with the short-table levels comes close to one per two
 	// (level 4 on the enwik-like set overflowed half its blocks at max_block / 2: 51 GB/s instead of 95)
-	l.cap_tok = max_block / 4 * 3 + 128;
+	l.cap_tok = full ? ((max_block + 64 + 15) & ~15u) : max_block / 4 * 3 + 128;
 	l.max_db = l.cap_tok / HD_DYN_BLOCK_TOKENS + 2;
 	l.off_rec = (uint64_t)l.cap_tok * 4;
 	l.off_ntok = l.off_rec + 16;
@@ -219,6 +223,12 @@ __host__ __device__ inline SplitLayout split_layout(uint32_t max_block)
 __device__ __forceinline__ uint8_t *split_block(uint8_t *scratch, uint32_t max_block, uint32_t i)
 {
 	return scratch + (uint64_t)i * split_layout(max_block).bytes;
+}
+// the record of part `i` (counted over the sub-batch: segment * parts + part) of a latency segment
+__host__ __device__ inline SplitLayout part_layout() { return split_layout(HD_LAT_PART_BYTES, true); }
+__device__ __forceinline__ uint8_t *part_block(uint8_t *scratch, uint32_t i)
+{
+	return scratch + (uint64_t)i * part_layout().bytes;
 }
 
 // MINLEN / LAZY / INTRA: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
@@ -274,13 +284,26 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)ring32;   // LDS byte address of the ring
 
 	const uint32_t lane = threadIdx.x;
-	const uint32_t b = a.first + blockIdx.x;
+	// PARTS (TOK, a.parts != 0): wavefront = part blockIdx.x % parts of segment a.first + blockIdx.x / parts.  A part behind
+	// the first one starts HD_LAT_PRIME_BYTES early: those steps fill table and window and their tokens are dropped
+	const bool parted = TOK && a.parts != 0;
+	const uint32_t b = a.first + (parted ? blockIdx.x / a.parts : blockIdx.x);
 	if (b >= a.nblocks)
 		return;
 	const ClockStamp clk(TOK ? HD_CLK_PARSE : HD_CLK_STATIC);
 	const uint8_t *src = a.in + a.in_off[b];
-	const uint32_t n = a.in_len[b];
-	if (TOK && n > a.split_max) {
+	uint32_t n = a.in_len[b];
+	uint32_t prime = 0;
+	if (parted) {
+		const uint32_t o = (blockIdx.x % a.parts) * HD_LAT_PART_BYTES;
+		if (o >= n)
+			return;                              // the segment ends before this part (the emit wave knows)
+		n = n - o < HD_LAT_PART_BYTES ? n - o : HD_LAT_PART_BYTES;
+		prime = HD_LAT_PRIME(o, n);
+		src += o - prime;
+		n += prime;
+	}
+	if (TOK && !parted && n > a.split_max) {
 		if (lane == 0)
 			a.split_ovf[b] = 1;
 		return;                              // the fused kernel takes the large blocks
@@ -314,8 +337,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (!TOK && lane < 4 && hdr)
 		stage[lane] = frame_hdr_word(a.frame, lane);
 	// TOK: where this block's tokens, histograms and record go
-	const SplitLayout lay = split_layout(TOK ? a.split_max : 0);
-	uint8_t *const rec = TOK ? split_block(a.scratch, a.split_max, blockIdx.x) : nullptr;
+	const SplitLayout lay = parted ? part_layout() : split_layout(TOK ? a.split_max : 0);
+	uint8_t *const rec = !TOK ? nullptr : parted ? part_block(a.scratch, blockIdx.x) : split_block(a.scratch, a.split_max, blockIdx.x);
 	uint32_t *const slab = (uint32_t *)rec;
 	uint32_t ntok_slab = 0, db_start = 0, ndb = 0;       // tokens stored; first token / index of the open DEFLATE block
 	int32_t db_room = HD_DYN_BLOCK_TOKENS;               // tokens until the open DEFLATE block may close (stored + queued ones counted)
@@ -328,7 +351,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	hk6.init(NB);
 	uint32_t pub_addr = 2u * HS, pub_val = 0;    // DEEP: the last fetch's bucket stores, issued by the next one
 	CrcLanes crc;
-	crc.init(lane, n);
+	// (a primed part's CRC covers [prime, n): the lanes of the priming bytes -- all in the first piece -- fold zeros from
+	// state 0, which leaves them at 0, and the register's all-ones start sits on the part's first slot)
+	crc.init(lane, n, prime);
 	uint32_t filled = 0;                 // ring holds [max(0,filled-W), filled)
 	uint4 pre = load_slot(src, n, 0, lane, aligned);
 
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		((uint4 *)ring32)[ro / 16 + lane] = v;
 		if (ro == 0 && lane == 0)
 			((uint4 *)ring32)[W / 16] = v;          // mirror of ring bytes [0,16)
-		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, v);
+		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n && piece * HD_PIECE + lane * 16 >= prime, v);
 	};
 	// ---- the front of the pipeline -------------------------------------------
 	// A step is split in three stages that run one iteration apart, so that no
@@ -972,7 +997,21 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// three-stage pipeline's hand-over (f0 <- f1 <- fetch, q0 <- probe) is register renaming instead of a
 	// dozen v_mov per step, and the refill test and its merge copies leave the steps.
 	uint32_t S = 0;
+	clk.mark(0);                                 // (diagnostic build only) prologue done
 	while (S < n && use_static) {
+		if (TOK && S < prime) {
+			// a priming step (a part of a latency segment, HD_LAT_PRIME): the front of the pipeline only -- the positions
+			// enter the table, the ring fills -- and no tokens: the twin drops them, and no match crosses the border
+			if (filled < n && filled < S + HD_LOOKAHEAD)
+				fill_piece();
+			f0 = f1;
+			q0 = probe(f1.c, S + 64 + lane, f1.c2);
+			f1 = fetch(std::false_type{}, S + 128);
+			if (OWN_AHEAD)
+				o1 = own(S + 192);
+			S += 64;
+			continue;
+		}
 		if (small && filled < n && filled < S + HD_LOOKAHEAD && S + 15 * 64 + 192 + 8 <= n) {
 			fill_piece();
 #pragma unroll 1
@@ -994,6 +1033,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	}
 	if (use_static && qtail != qhead)
 		emit_tokens(qtail - qhead);
+	clk.mark(1);                                 // steps done
 
 	// the CRC needs every piece, also when the static stream was abandoned
 	while (filled < n) {
@@ -1002,9 +1042,10 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		filled += HD_PIECE;
 		if (filled < n)
 			pre = load_slot(src, n, piece + 1, lane, aligned);
-		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n, pv);
+		crc.fold(ct, piece, piece * HD_PIECE + lane * 16 + 16 <= n && piece * HD_PIECE + lane * 16 >= prime, pv);
 	}
 	const uint32_t crcv = crc.finish(ct, lane, n, src + (n & ~15u));
+	clk.mark(2);                                 // CRC done
 
 	if (TOK) {
 		if (use_static)
@@ -1013,7 +1054,8 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			uint32_t *m = (uint32_t *)(rec + lay.off_rec);
 			m[0] = use_static ? ndb : 0xffffffffu;       // use_static false here: the slab overflowed
 			m[1] = crcv;
-			a.split_ovf[b] = use_static ? 0u : 1u;
+			if (!parted)                                 // (a part's slab holds a token per byte)
+				a.split_ovf[b] = use_static ? 0u : 1u;
 		}
 		return;
 	}

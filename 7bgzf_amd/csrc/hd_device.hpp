@@ -40,9 +40,19 @@ struct CrcTables {
 // empty and no stamp executes.
 #ifdef HD_CLOCK_STAMPS
 __device__ unsigned long long g_clk[4][4];      // [kernel]{ sum of cycles, sum of 100 MHz ticks, waves, - }
+__device__ unsigned long long g_clk_mark[16];   // [0,8) sums of cycles from a wave's start to mark(i), [8,16) waves that passed it (tools/clock_stamps_lat.py)
 struct ClockStamp {
 	unsigned long long t0, r0;
 	int k;
+	__device__ __forceinline__ void mark(int i) const
+	{
+		unsigned long long t;
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+		if (threadIdx.x == 0) {
+			atomicAdd(&g_clk_mark[i], t - t0);
+			atomicAdd(&g_clk_mark[8 + i], 1ull);
+		}
+	}
 	__device__ __forceinline__ ClockStamp(int kernel) : k(kernel)
 	{
 		asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
@@ -61,6 +71,7 @@ struct ClockStamp {
 #else
 struct ClockStamp {
 	__device__ __forceinline__ ClockStamp(int) {}
+	__device__ __forceinline__ void mark(int) const {}
 };
 #endif
 enum { HD_CLK_STATIC = 0, HD_CLK_DYNAMIC = 1, HD_CLK_INFLATE = 2, HD_CLK_PARSE = 3 };
@@ -292,14 +303,27 @@ __device__ __forceinline__ uint32_t gf_mul(uint32_t a, uint32_t b)
 	return p;
 }
 
+// the CRC state `s` followed by n more bytes that another CRC covers: s * x^(8 n), by the P2 operators
+__device__ inline uint32_t crc_append_bytes(const CrcTables *ct, uint32_t s, uint64_t n)
+{
+	for (int j = 0; n && j < 24; j++, n >>= 1)
+		if (n & 1)
+			s = crc_shift(ct->P2[j], s);
+	for (; n; n--)                                    // 16 MiB units beyond 2^24 bytes
+		s = crc_shift(ct->P2[23], crc_shift(ct->P2[23], s));
+	return s;
+}
+
 // Per-lane strided CRC accumulator.  The input is consumed in 1 KiB pieces;
 // lane l owns the 16-byte slot j = 64 k + l of piece k.  fold() is called once
 // per piece with that slot's bytes, finish() aligns and combines the 64 lanes.
 struct CrcLanes {
 	uint32_t s;
-	__device__ __forceinline__ void init(uint32_t lane, uint32_t n)
+	// first: the CRC covers bytes [first, n) -- first a multiple of 16 below 1024, n - first >= 16 unless first == 0;
+	// the caller folds the slots below `first` as not full
+	__device__ __forceinline__ void init(uint32_t lane, uint32_t n, uint32_t first = 0)
 	{
-		s = (lane == 0 && n >= 16) ? 0xffffffffu : 0u;
+		s = (lane == first / 16 && n >= 16) ? 0xffffffffu : 0u;
 	}
 	// CHAIN: the same value with four loads in flight instead of twenty (the fused dynamic kernel sits at its
 	// register budget): skip 1008 zero bytes, then four dependent slicing-by-4 steps

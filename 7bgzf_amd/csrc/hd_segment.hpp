@@ -60,7 +60,8 @@ inline uint64_t segmented_scratch_bytes(uint32_t nblocks, uint32_t cap, int leve
 	const uint32_t S = seg_slots_per_block(cap, seg), rb = seg_round_blocks(nblocks, S);
 	if (level < 2)
 		return seg_round_bytes(rb, S, seg) + 64;
-	return dynamic_scratch_bytes(nblocks, cap, level) + seg_round_bytes(rb, S, seg) + dynamic_scratch_bytes(rb * S, seg_stride(seg), level) + 64;
+	return dynamic_scratch_bytes(nblocks, cap, level) + seg_round_bytes(rb, S, seg) +
+	       dynamic_scratch_bytes(rb * S, seg_stride(seg), level, HD_LAT_PARTS(level, seg)) + 64;
 }
 
 __global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
@@ -77,28 +78,14 @@ __global__ __launch_bounds__(256) void k_seg_table(SegArgs g)
 	g.seg_len[t] = sl;
 }
 
-// the CRC state `s` followed by n more bytes that another CRC covers: s * x^(8 n), by the P2 operators
-__device__ inline uint32_t crc_append_bytes(const CrcTables *ct, uint32_t s, uint64_t n)
-{
-	for (int j = 0; n && j < 24; j++, n >>= 1)
-		if (n & 1)
-			s = crc_shift(ct->P2[j], s);
-	for (; n; n--)                                    // 16 MiB units beyond 2^24 bytes
-		s = crc_shift(ct->P2[23], crc_shift(ct->P2[23], s));
-	return s;
-}
-
 // One WAVEFRONT per member, lane k = segment k (members of more than 64 segments: in rounds): where each
 // segment's payload goes (a prefix sum of the segment sizes), the container bytes around them, and the
 // CRC-32 of the whole from the CRCs of the parts -- crc(A || B) = crc(A) * x^(8 |B|) ^ crc(B), so every lane
 // moves its segment's CRC to the end of the member with ONE table step (SM: m full segments behind it) and
 // the lanes are XOR-ed; a ragged last segment adds its length once, behind the sum.  (A single thread per
 // member walking the segments with bit-serial GF(2) products took 33 us -- a third of a latency-mode call.)
-__global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
+__device__ __forceinline__ void seg_stitch_member(const SegArgs &g, uint32_t t, uint32_t lane)
 {
-	const uint32_t t = blockIdx.x, lane = threadIdx.x;
-	if (t >= g.count)
-		return;
 	const DeflateArgs &a = g.a;
 	const CrcTables *ct = a.ct;
 	const uint32_t i = g.first + t, len = a.in_len[i];
@@ -185,6 +172,12 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 	}
 }
 
+__global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
+{
+	if (blockIdx.x < g.count)
+		seg_stitch_member(g, blockIdx.x, threadIdx.x);
+}
+
 // a.scratch: segmented_scratch_bytes(a.nblocks, capacity, level).  `code(args)` launches the level's
 // ordinary coding of a batch (the level-1 kernel, or launch_deflate_dynamic): once for the caller's blocks
 // with seg_limit set -- it takes the blocks up to the limit, the one way such a block is coded whatever
@@ -242,8 +235,11 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		s.scratch = inner;
 		s.split_max = stride;
 		s.seg_limit = 0;
+		s.parts = HD_LAT_PARTS(level, seg);             // latency segments of the dynamic levels: parsed in parts
 		if ((r = code(s)))
 			return r;
+		// (one launch for both -- wavefront 0 of a 16-wave workgroup stitches, then all gather -- measured no faster: 20.6 us
+		// against 11.3 + 6.4 at level 1, the launch gap it saves is ~2 us)
 		hipLaunchKernelGGL(k_seg_stitch, dim3(g.count), dim3(64), 0, st, g);
 		hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)stride,
 				   (const uint32_t *)g.seg_olen, (const uint64_t *)g.seg_dst, ns, a.out);

@@ -157,6 +157,26 @@
  * segments at level 1 (4080 bytes: the 4 KiB window never held more) and 8 at the dynamic levels; its worst case,
  * 16 x 4090 + 2 + 26, still fits a BGZF member. */
 #define HD_LAT_SEG_BYTES(level) ((level) <= 1 ? 4080u : 8160u)
+/* ... and at the dynamic levels a latency segment is PARSED in parts of HD_LAT_PART_BYTES, one wavefront each (its own table
+ * and window, no match out of the part's own wavefront's sight), while ONE wavefront builds one code over the tokens of all
+ * parts and emits them as one DEFLATE block.  The parse of a wavefront that is alone on its SIMD is serial work at ~0.6 us
+ * per 64-byte step -- 105 of the 190 us a level-2 batch of sixteen 0xff00-byte blocks took.  A second Huffman header per 4080
+ * bytes -- segments half the size, the alternative -- costs 4 % of ratio; parts cost under 1 %.
+ *   A part behind the first of its segment is PRIMED: its wavefront starts HD_LAT_PRIME_BYTES early and runs those steps
+ * without making tokens (positions enter the table, the ring fills), so the first matches may reach back across the border.
+ * The 16-block test set of tools (FASTQ-like | text), level 2 and 6, bytes out / bytes in:
+ *     whole 8160-byte segments                 0.2979 | 0.432    level 6 0.2820
+ *     2 parts of 4080, not primed              0.3064 | 0.4396
+ *     2 parts of 4080, primed with 512         0.3007 | 0.4347           0.2841
+ *     4 parts of 2048, primed with 512 (this)  0.3009 | 0.4410           0.2832
+ *     8 parts of 1024, primed with 512         0.3002 | 0.4473           0.2828  (146 instead of 155 us per batch; not taken)
+ * Parts of less than 64 bytes go without priming (the CRC lanes want 16 bytes of their own).  HD_LAT_PRIME: o = the part's
+ * offset in its segment, n = its bytes.  HD_LAT_PARTS: 0 = not a latency segment of a dynamic level, parsed whole. */
+#define HD_LAT_PART_BYTES  2048u
+#define HD_LAT_PRIME_BYTES 512u
+#define HD_LAT_PRIME(o, n) ((o) >= HD_LAT_PRIME_BYTES && (n) >= 64u ? HD_LAT_PRIME_BYTES : 0u)
+#define HD_LAT_PARTS_MAX   4u
+#define HD_LAT_PARTS(level, seg) ((level) >= 2 && (seg) == HD_LAT_SEG_BYTES(level) ? HD_LAT_PARTS_MAX : 0u)
 
 /* one compressed stream handed to the inflate kernel must be shorter than this: it keeps stream positions
  * as 32-bit bit counts (8 n + 64 + 24 < 2^32) */

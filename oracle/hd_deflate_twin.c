@@ -637,8 +637,12 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
 	return 0;
 }
 
+/* part: 0, or -- a latency-mode segment (HD_LAT_PARTS) -- the bytes each of its PARSE parts covers: every part is parsed on
+ * its own (fresh table, fresh window, no match across the border: one wavefront each on the device), the tokens of all parts
+ * then make ONE DEFLATE block with one code (the emit wavefront's) */
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush, int deep)
+			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush, int deep,
+			   unsigned part)
 {
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
@@ -653,25 +657,45 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 
 	memset(&b, 0, sizeof(b));
 	b.tok = malloc((HD_DYN_BLOCK_TOKENS + 64) * 4);
-	unsigned carry = 0;
-	for (size_t S = 0; S < n && alive; S += HD_WAVE) {
-		parse_step(&mf, in, n, S, carry, minlen, lazy, &st);
-		carry = st.carry_out;
-		for (unsigned l = 0; l < st.lanes; l++) {
-			if (st.is_match[l]) {
-				unsigned sym, eb, ev;
-				b.tok[b.ntok++] = HD_TOKEN_MATCH | ((uint32_t)(st.len[l] - 3) << 16) | (st.dist[l] - 1);
-				len_slot(st.len[l], &sym, &eb, &ev);
-				b.lf[sym]++;
-				off_slot(st.dist[l], &sym, &eb, &ev);
-				b.df[sym]++;
-			} else if (st.is_lit[l]) {
-				b.tok[b.ntok++] = in[S + l];
-				b.lf[in[S + l]]++;
-			}
+	const size_t nbk = deep ? HD_BUCKETS(win_bits, hash_bits) : 0;
+	if (part)
+		b.tok = realloc(b.tok, (n + HD_DYN_BLOCK_TOKENS + 64) * 4);     /* (never closed early: one block) */
+	for (size_t ps = 0; ps < n && alive; ps += part ? part : n) {
+		/* a part behind the first starts HD_LAT_PRIME_BYTES early; the tokens of those steps are dropped (HD_LAT_PRIME) */
+		const size_t plen = part && n - ps > part ? part : n - ps;
+		const size_t prime = part ? HD_LAT_PRIME(ps, plen) : 0;
+		const uint8_t *pin = in + ps - prime;
+		const size_t pn = plen + prime;
+		unsigned carry = 0;
+		if (ps) {
+			memset(mf.table, 0, ((size_t)1 << hash_bits) * 2);
+			if (deep)
+				memset(mf.bucket, 0, nbk * 4);
+			mf.filled = 0;
 		}
-		if (b.ntok >= HD_DYN_BLOCK_TOKENS && S + HD_WAVE < n)
-			alive = flush_dyn_block(&w, &b, 0, 8 * (uint64_t)limit);
+		for (size_t S = 0; S < pn && alive; S += HD_WAVE) {
+			if (S == prime)
+				carry = 0;
+			parse_step(&mf, pin, pn, S, carry, minlen, lazy, &st);
+			carry = st.carry_out;
+			if (S < prime)
+				continue;
+			for (unsigned l = 0; l < st.lanes; l++) {
+				if (st.is_match[l]) {
+					unsigned sym, eb, ev;
+					b.tok[b.ntok++] = HD_TOKEN_MATCH | ((uint32_t)(st.len[l] - 3) << 16) | (st.dist[l] - 1);
+					len_slot(st.len[l], &sym, &eb, &ev);
+					b.lf[sym]++;
+					off_slot(st.dist[l], &sym, &eb, &ev);
+					b.df[sym]++;
+				} else if (st.is_lit[l]) {
+					b.tok[b.ntok++] = pin[S + l];
+					b.lf[pin[S + l]]++;
+				}
+			}
+			if (!part && b.ntok >= HD_DYN_BLOCK_TOKENS && S + HD_WAVE < n)
+				alive = flush_dyn_block(&w, &b, 0, 8 * (uint64_t)limit);
+		}
 	}
 	if (alive)
 		alive = flush_dyn_block(&w, &b, !flush, 8 * (uint64_t)limit);
@@ -701,7 +725,8 @@ void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, u
 	memcpy(lens_out, h.len, nsyms);
 }
 
-static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat);
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat,
+		unsigned part);
 
 /* levels >= 1, blocks longer than HD_SEG_LIMIT (include/hipdeflate_params.h) -- or, in latency mode, longer than
  * `seg` = HD_LAT_SEG_BYTES(level): independent `seg`-byte segments in flush form one behind the other, then the empty
@@ -716,7 +741,7 @@ static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source,
 	for (size_t s = 0; s < sourceLen; s += seg) {
 		size_t n = sourceLen - s < seg ? sourceLen - s : seg;
 		size_t room = *destLen - o;
-		int r = twin(dest + o, &room, source + s, n, level, 1, 0);
+		int r = twin(dest + o, &room, source + s, n, level, 1, 0, HD_LAT_PARTS(level, seg) ? HD_LAT_PART_BYTES : 0);
 		if (r)
 			return r;
 		o += room;
@@ -730,7 +755,8 @@ static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source,
 }
 
 /* lat: latency mode (HD_FRAME_LATENCY) */
-static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat)
+static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat,
+		unsigned part)
 {
 	/* (the per-block codecs and the hook take the latency form only when the room covers its worst case, and the
 	 * ordinary form otherwise -- as libdeflate_deflate they succeed whenever the stored form fits) */
@@ -745,43 +771,43 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0);
+				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part);
 	if (level == 3)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
-				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0);
+				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part);
 	if (level == 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
-				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0);
+				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0, part);
 	if (level <= 6)         /* level 5: the one-way table; level 6: the same geometry with the lazy levels' two-way buckets */
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL);
+				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part);
 	if (level <= 8)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
+				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part);
 	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L9_WIN_BITS, HD_L9_HASH_BITS,
-			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1);
+			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 0, 0);
+	return twin(dest, destLen, source, sourceLen, level, 0, 0, 0);
 }
 
 /* the same encoder in HD_FRAME_RAW_FLUSH form (include/hipdeflate.h) */
 int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			   size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 1, 0);
+	return twin(dest, destLen, source, sourceLen, level, 1, 0, 0);
 }
 
 /* ... in latency mode (HD_FRAME_LATENCY): what bgzf_compress, hip_deflate and hip_deflate_flush produce */
 int hdo_deflate_twin_lat(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 0, 1);
+	return twin(dest, destLen, source, sourceLen, level, 0, 1, 0);
 }
 
 int hdo_deflate_twin_lat_flush(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 1, 1);
+	return twin(dest, destLen, source, sourceLen, level, 1, 1, 0);
 }

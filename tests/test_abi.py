@@ -143,24 +143,25 @@ def test_kernel_resource_budgets():
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/\w+\])?: (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
-    # k_deflate_dynamic<W, H, MINLEN, LAZY, EMIT, INTRA, DEEP>: the emit-only instantiation has EMIT = 1
-    emit = {k: v for k, v in kernels.items() if re.search(r"k_deflate_dynamicILi\d+ELi\d+ELi\d+ELi\d+ELi1ELi\d+ELi\d+EEEv", k)}
+    # k_deflate_dynamic<W, H, MINLEN, LAZY, EMIT, INTRA, DEEP, PARTS>: the emit-only instantiations have EMIT = 1 (PARTS = 0, and
+    # HD_LAT_PARTS_MAX for the latency segments parsed in parts)
+    emit = {k: v for k, v in kernels.items() if re.search(r"k_deflate_dynamicILi\d+ELi\d+ELi\d+ELi\d+ELi1ELi\d+ELi\d+ELi\d+EEEv", k)}
     dyn = {k: v for k, v in kernels.items() if "k_deflate_dynamic" in k and k not in emit}
     sta = {k: v for k, v in kernels.items() if "k_deflate_static" in k}
     inf = {k: v for k, v in kernels.items() if "k_inflate" in k}
-    assert len(dyn) == 7 and len(emit) == 1 and len(sta) == 8 and len(inf) == 1, list(kernels)
+    assert len(dyn) == 7 and len(emit) == 2 and len(sta) == 8 and len(inf) == 1, list(kernels)
     for k, v in kernels.items():
         assert v["ScratchSize"] == 0, (k, v)
     for k, v in dyn.items():
         assert v["VGPRs"] <= 168, (k, v)
         # LDS is granted in 1280-byte units (measured: 10 waves of 15584 B do not fit a CU, of 15328 B do)
         units = -(-v["LDS Size"] // 1280)
-        deep = k.endswith("ELi1EEEvNS_11DeflateArgsE")          # the two-way tables (levels 6..9)
+        deep = k.endswith("ELi1ELi0EEEvNS_11DeflateArgsE")      # the two-way tables (levels 6..9)
         want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else (18 if deep else 14) if "Li13ELi12E" in k else \
             25 if "Li14ELi12E" in k else 32
         assert units <= want, (k, v)                 # 10 / 9 / 7 / 5 / 4 waves per CU: dynamic_grid()
-    (v,) = emit.values()
-    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
+    for v in emit.values():
+        assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
     for k, v in sta.items():                                     # level 1 and the parse kernels of levels 2-9
         # the level-1 geometry runs 18 waves per CU = five per SIMD on two of them: <= 96 VGPRs; the two-way parse kernels
         # (8 / 5 / 4 waves per CU) have 168; the others <= 128 (four per SIMD)

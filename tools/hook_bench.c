@@ -72,6 +72,37 @@ static void *run(void *arg)
 	return NULL;
 }
 
+#ifdef HOOK_BENCH_LAT
+/* HOOK_PAR=k (with threads = 0): k threads, each with its own latency context, run hipdeflate_lat_run on HOOK_N blocks side
+ * by side -- what concurrent batches cost one another on the device and in the runtime, without the hook */
+struct par {
+	pthread_t th;
+	int level, n;
+	double us;
+};
+static void *par_run(void *arg)
+{
+	struct par *p = (struct par *)arg;
+	hipdeflate_lat *c = hipdeflate_lat_open(p->level, HD_FRAME_BGZF | HD_FRAME_LATENCY, 256, 0xff00);
+	uint32_t lens[256];
+	if (!c)
+		return NULL;
+	for (int i = 0; i < p->n; i++) {
+		memcpy(hipdeflate_lat_input(c, (uint32_t)i), g_data + (size_t)i * g_block, g_block);
+		lens[i] = (uint32_t)g_block;
+	}
+	hipdeflate_lat_run(c, lens, (uint32_t)p->n);
+	const int reps = 2000;
+	const double t0 = now();
+	for (int r = 0; r < reps; r++)
+		if (hipdeflate_lat_run(c, lens, (uint32_t)p->n))
+			break;
+	p->us = (now() - t0) * 1e6 / reps;
+	hipdeflate_lat_close(c);
+	return NULL;
+}
+#endif
+
 int main(int argc, char **argv)
 {
 	if (argc < 2) {
@@ -117,22 +148,54 @@ int main(int argc, char **argv)
 	if (T == 0) {
 		/* the device side alone: hipdeflate_lat_run() on n blocks, one caller, no threads */
 		const int level = getenv("HOOK_LEVEL") ? atoi(getenv("HOOK_LEVEL")) : 1;
+		if (getenv("HOOK_PAR")) {
+			const int k = atoi(getenv("HOOK_PAR")), n = getenv("HOOK_N") ? atoi(getenv("HOOK_N")) : 8;
+			struct par ps[64];
+			if (k < 1 || k > 64 || n < 1 || n > 256)
+				return 2;
+			for (int i = 0; i < k; i++) {
+				ps[i].level = level;
+				ps[i].n = n;
+				ps[i].us = 0;
+				pthread_create(&ps[i].th, NULL, par_run, &ps[i]);
+			}
+			double sum = 0;
+			for (int i = 0; i < k; i++) {
+				pthread_join(ps[i].th, NULL);
+				sum += ps[i].us;
+			}
+			printf("{\"lat_run_parallel\": %d, \"blocks\": %d, \"level\": %d, \"us\": %.1f, \"GBps_in\": %.3f}\n", k, n, level,
+			       sum / k, k * n * g_block / (sum / k) / 1e3);
+			return 0;
+		}
 		hipdeflate_lat *c = hipdeflate_lat_open(level, HD_FRAME_BGZF | HD_FRAME_LATENCY, 256, 0xff00);
 		if (!c)
 			return 1;
 		uint32_t lens[256];
+		const int only = getenv("HOOK_N") ? atoi(getenv("HOOK_N")) : 0;  /* one batch size (for a kernel trace) */
 		for (int n = 1; n <= 256; n *= 2) {
+			if (only && n != only)
+				continue;
 			for (int i = 0; i < n; i++) {
 				memcpy(hipdeflate_lat_input(c, (uint32_t)i), g_data + (size_t)i * g_block, g_block);
 				lens[i] = (uint32_t)g_block;
 			}
 			hipdeflate_lat_run(c, lens, (uint32_t)n);
 			const int reps = 200;
-			const double t0 = now();
-			for (int r = 0; r < reps; r++)
+			/* HOOK_TOUCH=1: the input is written anew by the CPU before every run, as the hook's callers do (the time
+			 * of the copy is not counted): what the device side costs when its input sits in the CPU's caches */
+			const int touch = getenv("HOOK_TOUCH") != NULL;
+			double sum = 0;
+			for (int r = 0; r < reps; r++) {
+				if (touch)
+					for (int i = 0; i < n; i++)
+						memcpy(hipdeflate_lat_input(c, (uint32_t)i), g_data + (size_t)((i + r) % 512) * g_block, g_block);
+				const double t0 = now();
 				if (hipdeflate_lat_run(c, lens, (uint32_t)n))
 					return 1;
-			const double us = (now() - t0) * 1e6 / reps;
+				sum += now() - t0;
+			}
+			const double us = sum * 1e6 / reps;
 			printf("{\"lat_run_blocks\": %d, \"level\": %d, \"us\": %.1f, \"GBps_in\": %.3f}\n", n, level, us, n * g_block / us / 1e3);
 		}
 		hipdeflate_lat_close(c);
