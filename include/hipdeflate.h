@@ -57,8 +57,8 @@ extern "C" {
 
 /* OR'ed into `frame`: LATENCY MODE for batches far smaller than the machine (hipdeflate_params.h, HD_LAT_SEG_BYTES):
  * levels >= 1 code every block longer than 4080 (level 1) / 8160 (levels >= 2) bytes as independent flushed segments
- * of that size, one wavefront each, stitched on the device -- a 0xff00-byte block is done in about a tenth of the
- * time one wavefront needs for it.  The bytes differ from the throughput form (both are what the CPU twin gives for
+ * of that size, one wavefront each (levels >= 2: four parse wavefronts per segment, HD_LAT_PART_BYTES), stitched on
+ * the device -- a 0xff00-byte block is done in about a tenth of the time one wavefront needs for it.  The bytes differ from the throughput form (both are what the CPU twin gives for
  * the same mode); bgzf_compress, hip_deflate and hip_deflate_flush use this mode. */
 #define HD_FRAME_LATENCY 0x100
 
