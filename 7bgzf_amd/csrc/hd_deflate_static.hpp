@@ -64,6 +64,9 @@ struct DeflateArgs {
 	// split path, latency segments of the dynamic levels (HD_LAT_PARTS): != 0 = every block of in_off/in_len is PARSED
 	// as this many parts of HD_LAT_PART_BYTES, one wavefront each, and emitted as one DEFLATE block by one
 	uint32_t parts = 0;
+	// != 0: in_off / in_len are the segment table of a latency-mode launch with this many slots per block; a segment that
+	// is not the first of its block is PRIMED with the HD_LAT_PRIME_BYTES before it (the end of its predecessor)
+	uint32_t seg_slots = 0;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)
@@ -293,16 +296,21 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const ClockStamp clk(TOK ? HD_CLK_PARSE : HD_CLK_STATIC);
 	const uint8_t *src = a.in + a.in_off[b];
 	uint32_t n = a.in_len[b];
-	uint32_t prime = 0;
+	// PRIMED (latency mode): the wavefront starts `prime` bytes ahead of what it codes and runs those steps as the front of
+	// the pipeline only -- table and window are warm when its own bytes begin, and its first matches may reach back
+	uint32_t prime = (HD_LAT_SEG_PRIME && a.seg_slots && b % a.seg_slots) ? HD_LAT_PRIME(HD_LAT_PRIME_BYTES, n) : 0u;
 	if (parted) {
 		const uint32_t o = (blockIdx.x % a.parts) * HD_LAT_PART_BYTES;
 		if (o >= n)
 			return;                              // the segment ends before this part (the emit wave knows)
 		n = n - o < HD_LAT_PART_BYTES ? n - o : HD_LAT_PART_BYTES;
-		prime = HD_LAT_PRIME(o, n);
-		src += o - prime;
-		n += prime;
+		prime = o ? HD_LAT_PRIME(o, n) : HD_LAT_PRIME(prime, n);
+		src += o;
 	}
+	const uint8_t *const src_own = src;          // what this wavefront codes: [src_own, src_own + n_own)
+	const uint32_t n_own = n;
+	src -= prime;
+	n += prime;
 	if (TOK && !parted && n > a.split_max) {
 		if (lane == 0)
 			a.split_ovf[b] = 1;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
 		cap64 = 65536;
 	const uint32_t cap = (uint32_t)cap64;
-	const uint32_t stored = HD_STORED_SIZE(n);
+	const uint32_t stored = HD_STORED_SIZE(n_own);
 	// the static stream survives only while it stays strictly below the stored
 	// size and inside the slot (twin: deflate_static(), `limit`)
 	uint32_t limit = stored - 1;
@@ -999,9 +1007,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t S = 0;
 	clk.mark(0);                                 // (diagnostic build only) prologue done
 	while (S < n && use_static) {
-		if (TOK && S < prime) {
-			// a priming step (a part of a latency segment, HD_LAT_PRIME): the front of the pipeline only -- the positions
-			// enter the table, the ring fills -- and no tokens: the twin drops them, and no match crosses the border
+		if (S < prime) {
+			// a priming step (latency mode, HD_LAT_PRIME): the front of the pipeline only -- the positions enter the
+			// table, the ring fills -- and no tokens: the twin drops them, and no match crosses the border
 			if (filled < n && filled < S + HD_LOOKAHEAD)
 				fill_piece();
 			f0 = f1;
@@ -1062,7 +1070,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (use_static && (uint64_t)(bitpos - paybase) + 7 > 8ull * limit)
 		use_static = false;
 	if (!use_static) {
-		write_stored_member(a, b, src, n, crcv, lane);
+		write_stored_member(a, b, src_own, n_own, crcv, lane);
 		return;
 	}
 
@@ -1084,7 +1092,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	if (trl) {
 		uint32_t tcode = 0, nb = 0;
 		if (lane < trl / 2) {
-			tcode = frame_trl_field(a.frame, lane, crcv, n);
+			tcode = frame_trl_field(a.frame, lane, crcv, n_own);
 			nb = 16;
 		}
 		const uint32_t incl = wave_incl_scan(nb);

@@ -236,6 +236,7 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		s.split_max = stride;
 		s.seg_limit = 0;
 		s.parts = HD_LAT_PARTS(level, seg);             // latency segments of the dynamic levels: parsed in parts
+		s.seg_slots = seg != HD_SEG_BYTES ? S : 0;      // latency segments: primed with the end of their predecessor
 		if ((r = code(s)))
 			return r;
 		// (one launch for both -- wavefront 0 of a 16-wave workgroup stitches, then all gather -- measured no faster: 20.6 us

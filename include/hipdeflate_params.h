@@ -170,11 +170,19 @@
  *     2 parts of 4080, primed with 512         0.3007 | 0.4347           0.2841
  *     4 parts of 2048, primed with 512 (this)  0.3009 | 0.4410           0.2832
  *     8 parts of 1024, primed with 512         0.3002 | 0.4473           0.2828  (146 instead of 155 us per batch; not taken)
- * Parts of less than 64 bytes go without priming (the CRC lanes want 16 bytes of their own).  HD_LAT_PRIME: o = the part's
- * offset in its segment, n = its bytes.  HD_LAT_PARTS: 0 = not a latency segment of a dynamic level, parsed whole. */
+ * A SEGMENT that is not the first of its block is primed the same way, at every level (at level 1 it is the only priming
+ * there is): it starts 512 bytes inside its predecessor.  DEFLATE allows the reach -- the segments of a member are one
+ * stream --, and a fresh window every 4080 bytes was what latency mode cost: FASTQ-like level 1 0.4812 -> 0.4586, level 2
+ * 0.3009 -> 0.2954, level 6 0.2832 -> 0.2800; text level 1 0.6537 -> 0.6313.
+ * Parts and segments of less than 64 bytes go without priming (the CRC lanes want 16 bytes of their own).  HD_LAT_PRIME:
+ * o = the bytes of the block ahead of the part / segment, n = its own bytes.  HD_LAT_PARTS: 0 = not a latency segment of a
+ * dynamic level, parsed whole. */
 #define HD_LAT_PART_BYTES  2048u
 #define HD_LAT_PRIME_BYTES 512u
 #define HD_LAT_PRIME(o, n) ((o) >= HD_LAT_PRIME_BYTES && (n) >= 64u ? HD_LAT_PRIME_BYTES : 0u)
+#ifndef HD_LAT_SEG_PRIME
+#define HD_LAT_SEG_PRIME   1           /* 0: segments are not primed, only parts (A/B builds: tools/exp_seg_prime.sh) */
+#endif
 #define HD_LAT_PARTS_MAX   4u
 #define HD_LAT_PARTS(level, seg) ((level) >= 2 && (seg) == HD_LAT_SEG_BYTES(level) ? HD_LAT_PARTS_MAX : 0u)
 

@@ -281,8 +281,10 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
 static void put_flush_suffix(bw_t *w);
 
 /* ---- level 1: greedy + static Huffman, streaming ------------------------ */
+/* prime: 0, or -- a latency-mode segment behind the first of its block (HD_LAT_PRIME) -- the bytes before `in` whose steps run
+ * ahead of the segment's own: they fill table and window, their tokens are dropped, no match crosses the border */
 static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			  unsigned win_bits, unsigned hash_bits, int flush)
+			  unsigned win_bits, unsigned hash_bits, int flush, size_t prime)
 {
 	/* flush form: 5 bytes are kept free for the suffix (put_flush_suffix) */
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
@@ -301,9 +303,17 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	bw_put(&w, flush ? 0 : 1, 1);       /* BFINAL */
 	bw_put(&w, 1, 2);       /* BTYPE = 01 */
 	unsigned carry = 0;
+	const uint8_t *const in_own = in;
+	const size_t n_own = n;
+	in -= prime;
+	n += prime;
 	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
+		if (S == prime)
+			carry = 0;
 		parse_step(&mf, in, n, S, carry, HD_MIN_MATCH, 0, &st);
 		carry = st.carry_out;
+		if (S < prime)
+			continue;
 		/* the kernel knows the step's bit count (wave prefix sum) before it
 		 * writes anything; once the stream plus the end-of-block code can no
 		 * longer fit in `limit` bytes it abandons the static stream for good */
@@ -336,7 +346,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 		*destLen = (size_t)((w.bitpos + 7) >> 3);
 		memcpy(dest, tmp, *destLen);
 	} else {
-		ret = write_stored(dest, destLen, in, n, flush);
+		ret = write_stored(dest, destLen, in_own, n_own, flush);
 	}
 	free(mf.table);
 	free(tmp);
@@ -642,7 +652,7 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
  * then make ONE DEFLATE block with one code (the emit wavefront's) */
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
 			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush, int deep,
-			   unsigned part)
+			   unsigned part, size_t segprime)
 {
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
@@ -663,7 +673,7 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	for (size_t ps = 0; ps < n && alive; ps += part ? part : n) {
 		/* a part behind the first starts HD_LAT_PRIME_BYTES early; the tokens of those steps are dropped (HD_LAT_PRIME) */
 		const size_t plen = part && n - ps > part ? part : n - ps;
-		const size_t prime = part ? HD_LAT_PRIME(ps, plen) : 0;
+		const size_t prime = !part ? 0 : ps ? HD_LAT_PRIME(ps, plen) : HD_LAT_PRIME(segprime, plen);   /* (the segment's own priming: its first part's) */
 		const uint8_t *pin = in + ps - prime;
 		const size_t pn = plen + prime;
 		unsigned carry = 0;
@@ -726,7 +736,7 @@ void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, u
 }
 
 static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat,
-		unsigned part);
+		unsigned part, size_t prime);
 
 /* levels >= 1, blocks longer than HD_SEG_LIMIT (include/hipdeflate_params.h) -- or, in latency mode, longer than
  * `seg` = HD_LAT_SEG_BYTES(level): independent `seg`-byte segments in flush form one behind the other, then the empty
@@ -741,7 +751,9 @@ static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source,
 	for (size_t s = 0; s < sourceLen; s += seg) {
 		size_t n = sourceLen - s < seg ? sourceLen - s : seg;
 		size_t room = *destLen - o;
-		int r = twin(dest + o, &room, source + s, n, level, 1, 0, HD_LAT_PARTS(level, seg) ? HD_LAT_PART_BYTES : 0);
+		/* latency segments behind the first are primed with the end of their predecessor (HD_LAT_PRIME) */
+		int r = twin(dest + o, &room, source + s, n, level, 1, 0, HD_LAT_PARTS(level, seg) ? HD_LAT_PART_BYTES : 0,
+			     (HD_LAT_SEG_PRIME && s && seg != HD_SEG_BYTES) ? HD_LAT_PRIME(HD_LAT_PRIME_BYTES, n) : 0);
 		if (r)
 			return r;
 		o += room;
@@ -756,7 +768,7 @@ static int twin_segmented(uint8_t *dest, size_t *destLen, const uint8_t *source,
 
 /* lat: latency mode (HD_FRAME_LATENCY) */
 static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level, int flush, unsigned lat,
-		unsigned part)
+		unsigned part, size_t prime)
 {
 	/* (the per-block codecs and the hook take the latency form only when the room covers its worst case, and the
 	 * ordinary form otherwise -- as libdeflate_deflate they succeed whenever the stored form fits) */
@@ -768,46 +780,46 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level <= 0)
 		return write_stored(dest, destLen, source, sourceLen, flush);   /* level 0 = the stored branch */
 	if (level == 1)
-		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush);
+		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush, prime);
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part);
+				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part, prime);
 	if (level == 3)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
-				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part);
+				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part, prime);
 	if (level == 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
-				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0, part);
+				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0, part, prime);
 	if (level <= 6)         /* level 5: the one-way table; level 6: the same geometry with the lazy levels' two-way buckets */
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part);
+				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part, prime);
 	if (level <= 8)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part);
+				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part, prime);
 	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L9_WIN_BITS, HD_L9_HASH_BITS,
-			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part);
+			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part, prime);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
 		     size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 0, 0, 0);
+	return twin(dest, destLen, source, sourceLen, level, 0, 0, 0, 0);
 }
 
 /* the same encoder in HD_FRAME_RAW_FLUSH form (include/hipdeflate.h) */
 int hdo_deflate_twin_flush(uint8_t *dest, size_t *destLen, const uint8_t *source,
 			   size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 1, 0, 0);
+	return twin(dest, destLen, source, sourceLen, level, 1, 0, 0, 0);
 }
 
 /* ... in latency mode (HD_FRAME_LATENCY): what bgzf_compress, hip_deflate and hip_deflate_flush produce */
 int hdo_deflate_twin_lat(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 0, 1, 0);
+	return twin(dest, destLen, source, sourceLen, level, 0, 1, 0, 0);
 }
 
 int hdo_deflate_twin_lat_flush(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t sourceLen, int level)
 {
-	return twin(dest, destLen, source, sourceLen, level, 1, 1, 0);
+	return twin(dest, destLen, source, sourceLen, level, 1, 1, 0, 0);
 }
