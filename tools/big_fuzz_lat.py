@@ -1,0 +1,62 @@
+"""Wide differential run of LATENCY mode on the GPU box (round 3: parse parts, primed parts and segments): block lengths
+around every border the mode knows (segment 4080 / 8160, part 2048, prime 512, the 64-byte priming threshold) and random
+ones, FASTQ-like / text / noise / fuzz content, levels 1..9, plain and flush form: kernel bytes == twin bytes, zlib inflates
+them, CRC-32 right.  usage: python tools/big_fuzz_lat.py [random_blocks_per_seed] [seeds...]"""
+import importlib
+import os
+import sys
+import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import hdtest  # noqa: E402
+import numpy as np  # noqa: E402
+
+pkg = importlib.import_module("7bgzf_amd")
+synth = hdtest.synth()
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+seeds = [int(a) for a in sys.argv[2:]] or [31, 32, 33]
+edges = sorted(set(b + d for b in (512, 2048, 4080, 4096, 6144, 8160, 8192, 12240, 16320, 24480, 32640, 0xff00)
+                   for d in (-65, -64, -63, -17, -16, -15, -1, 0, 1, 15, 16, 17, 63, 64, 65, 511, 512, 513) if b + d > 0))
+t0 = time.time()
+total = bad = 0
+for seed in seeds:
+    rng = np.random.default_rng(seed)
+    lens = edges + [int(x) for x in rng.integers(1, 70000, count)]
+    fq = bytes(synth.fastq_like(1 << 20, seed=seed))
+    tx = bytes(synth.text_like(1 << 20, seed=seed + 1000))
+    fz = b"".join(hdtest.corpus_fuzz(seed, 200))
+    blocks = []
+    for i, n in enumerate(lens):
+        kind = i % 4
+        if kind == 3:
+            blocks.append(bytes(rng.integers(0, 256, n, dtype=np.uint8)))
+        else:
+            src = (fq, tx, fz)[kind]
+            o = int(rng.integers(0, max(1, len(src) - n)))
+            blocks.append((src[o:o + n] * (n // max(1, len(src[o:o + n])) + 1))[:n])
+    blob, offs = bytearray(), []
+    for b in blocks:
+        offs.append(len(blob))
+        blob += b + bytes(-len(b) % 16)
+    blob, ln = bytes(blob), [len(b) for b in blocks]
+    for level in (1, 2, 4, 5, 6, 7, 9):
+        for frame, twin_fn in ((pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin),
+                               (pkg.FRAME_RAW_FLUSH | pkg.FRAME_LATENCY, hdtest.codec_twin_flush)):
+            slot = int(pkg.lib().hipdeflate_bound(max(ln), level))
+            members, crc, st = pkg.batch_deflate(blob, offs, ln, level, frame, slot=slot)
+            with ThreadPoolExecutor(min(64, os.cpu_count() or 16)) as ex:
+                twins = list(ex.map(lambda b: twin_fn(b, level, cap=slot), blocks))
+            for i, b in enumerate(blocks):
+                total += 1
+                ok = st[i] == 0 and twins[i][0] == 0 and members[i] == twins[i][1] and int(crc[i]) == zlib.crc32(b)
+                if ok:
+                    tail = b"\x03\x00" if (frame & 0xff) == pkg.FRAME_RAW_FLUSH else b""
+                    ok = zlib.decompressobj(-15).decompress(members[i] + tail) == b
+                if not ok:
+                    bad += 1
+                    print("MISMATCH seed %d block %d len %d level %d frame %#x st %d" % (seed, i, len(b), level, frame, st[i]), flush=True)
+        print("seed %d level %d done, %d comparisons so far, %d bad, %.0f s" % (seed, level, total, bad, time.time() - t0), flush=True)
+print("BIG_FUZZ_LAT %s: %d comparisons, %d bad" % ("OK" if bad == 0 else "FAILED", total, bad))
