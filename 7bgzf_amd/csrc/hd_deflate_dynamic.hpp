@@ -30,9 +30,9 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
 	// one persistent wave per LDS slot of the level (levels 2-4: 14.5 KiB -> 10 resident per CU
-	// -- 11 do not fit, measured --; 5: 16 KiB -> 9; with the two-way tables 6: 21 KiB -> 7; 7-8: 29 KiB -> 5;
-	// 9: 35 KiB -> 4); a grid larger than what is resident would run its tail serially
-	const uint32_t per_cu = level >= 9 ? 4u : level >= 7 ? 5u : level >= 6 ? 7u : level >= 5 ? 9u : 10u;
+	// -- 11 do not fit, measured --; 5: 16 KiB -> 9; with the two-way tables 6: 21 KiB -> 7; 7: 29 KiB -> 5;
+	// 8: 35 KiB -> 4; 9: 60 KiB -> 2); a grid larger than what is resident would run its tail serially
+	const uint32_t per_cu = level >= 9 ? 2u : level >= 8 ? 4u : level >= 7 ? 5u : level >= 6 ? 7u : level >= 5 ? 9u : 10u;
 	const uint32_t slots = 256u * per_cu;
 	return nblocks < slots ? nblocks : slots;
 }
@@ -47,7 +47,7 @@ constexpr uint32_t SPLIT_SUB_BATCH_MAX = 65536;
 // resident waves of the parse kernel of a level (tests/test_abi.py::test_kernel_resource_budgets)
 inline uint32_t parse_slots(int level)
 {
-	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 5 ? 10u : level <= 6 ? 8u : level <= 8 ? 5u : 4u);
+	return 256u * (level == 2 ? 18u : level <= 4 ? 12u : level <= 5 ? 10u : level <= 6 ? 8u : level <= 7 ? 5u : level <= 8 ? 4u : 2u);
 }
 
 inline uint32_t split_sub_batch(uint32_t nblocks, uint32_t split_max, int level)
@@ -1092,8 +1092,10 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 0>(a, level, st);
 	else if (level <= 6)
 		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
-	else if (level <= 8)
+	else if (level <= 7)
 		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
+	else if (level == 8)
+		launch_level<HD_L8_WIN_BITS, HD_L8_HASH_BITS, HD_L8_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
 	else
 		launch_level<HD_L9_WIN_BITS, HD_L9_HASH_BITS, HD_L9_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
 	return 0;

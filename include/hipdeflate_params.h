@@ -56,12 +56,18 @@
 #define HD_L5_WIN_BITS     13
 #define HD_L5_HASH_BITS    12
 #define HD_L5_MIN_LEN      5
-/* levels 7..8: level 6's parse with a 16 KiB ring (5 parse waves per CU) */
+/* level 7: level 6's parse with a 16 KiB ring (5 parse waves per CU); level 8: the same with 4096 buckets (4 waves: round 2-3's
+ * level 9) */
 #define HD_L7_WIN_BITS     14
 #define HD_L7_HASH_BITS    12
 #define HD_L7_MIN_LEN      5
-/* level 9: 16 KiB ring, 4096 two-way buckets (34 KiB of LDS, 4 waves per CU, about 60 % of level 6's speed) */
-#define HD_L9_WIN_BITS     14
+#define HD_L8_WIN_BITS     14
+#define HD_L8_HASH_BITS    13
+#define HD_L8_MIN_LEN      5
+/* level 9: the reference's window -- a 32 KiB ring -- and 6144 two-way buckets: 57 KiB of LDS, 2 waves per CU, about half of
+ * level 7's speed for 2 % fewer bytes on text (16 KiB ring + 4096 buckets, rounds 2-3: 0.4135 -> 0.4057 on 0xff00-byte text
+ * blocks, 0.3845 -> 0.3771 on 1 MiB ones; FASTQ-like unchanged: DNA repeats are nearer than 16 KiB or much farther than 32) */
+#define HD_L9_WIN_BITS     15
 #define HD_L9_HASH_BITS    13
 #define HD_L9_MIN_LEN      5
 
@@ -95,12 +101,12 @@
 #define HD_DEEP_LEVEL      6           /* first level with the two-way buckets */
 #define HD_LAZY_KEY_BYTES  6
 #define HD_LAZY_WAYS       2
-/* buckets of the two-way tables: 2560 x 4 B with the 8 KiB ring of levels 5..6 (8 parse waves per CU), 2560 with the
- * 16 KiB ring of levels 7..8 (5 waves), 4096 at level 9 (4 waves) */
+/* buckets of the two-way tables: 2560 x 4 B with the 8 KiB ring of levels 5..6 (8 parse waves per CU), 2560 / 4096 with the
+ * 16 KiB ring of levels 7 / 8 (5 / 4 waves), 6144 with the 32 KiB ring of level 9 (2 waves) */
 #ifndef HD_L6_BUCKETS
 #define HD_L6_BUCKETS 2560u            /* (1536: ten parse waves per CU instead of eight -- measured below) */
 #endif
-#define HD_BUCKETS(win_bits, hash_bits) ((win_bits) == 14 && (hash_bits) == 13 ? 4096u : (win_bits) == 13 ? HD_L6_BUCKETS : 2560u)
+#define HD_BUCKETS(win_bits, hash_bits) ((win_bits) == 15 ? 6144u : (win_bits) == 14 && (hash_bits) == 13 ? 4096u : (win_bits) == 13 ? HD_L6_BUCKETS : 2560u)
 
 /* Entries of the hash table.  LDS is granted in 1280-byte units, so the table sizes are what fills the units the ring
  * leaves: 1536 entries with the 4 KiB ring of levels 1..2 (7 units, 18 waves per CU instead of 16 with 2048) and the

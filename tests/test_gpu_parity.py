@@ -41,7 +41,7 @@ def test_selftest(pkg):
 # ---- encode ----------------------------------------------------------------------
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_encode_matches_twin_small_corpus(pkg, level):
     corpus = hdtest.corpus_small()
     names = list(corpus)
@@ -210,7 +210,7 @@ def test_streaming_pipe_matches_batch_api(pkg, level, frame, block):
     assert pkg.pipe_compress(b"", level, fr, block, 4, 2) == b""
 
 
-@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 9])
+@pytest.mark.parametrize("level", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_encode_fuzz_blocks_match_twin(pkg, level):
     """160 seeded structured-random blocks per level (hdtest.corpus_fuzz), unaligned starts included:
     kernel bytes == twin bytes, and zlib inflates them back."""

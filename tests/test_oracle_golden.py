@@ -312,7 +312,7 @@ def test_zlib_gzip_frames_match_reference_wrappers():
     assert o.hdo_gzip_frame(buf.ctypes.data, len(p) + 17, p.ctypes.data, len(p), 0, 0, 0) == 0
 
 
-@pytest.mark.parametrize("level", [2, 3, 4, 6, 7, 9])
+@pytest.mark.parametrize("level", [2, 3, 4, 6, 7, 8, 9])
 def test_twin_dynamic_codes_stay_valid_on_deep_trees(level):
     """Code lengths are limited to 15 (litlen/offset) and 7 (precode) bits.  Inputs whose Huffman tree has
     leaves more than one level below the limit (Fibonacci-like frequencies; the code-length alphabet of

@@ -95,7 +95,7 @@ def test_twin_output_accepted_by_all_reference_inflaters(ref):
     decs = (ref.libdeflate_inflate, ref.igzip_inflate, ref.zlib_inflate, ref.zlibutil_auto_inflate)
     n_checked = 0
     for name, data in inputs.items():
-        for level in (0, 1, 2, 3, 4, 5, 6, 7, 9):
+        for level in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
             for enc in (hdtest.oracle_twin, hdtest.codec_twin):
                 r, z = enc(data, level)
                 assert r == 0, (name, level)

@@ -33,7 +33,7 @@ for seed in seeds:
         lens.append(len(b))
         blob += b + bytes(-len(b) % 16)
     blob = bytes(blob)
-    for level in (1, 2, 3, 4, 5, 6, 7, 9):
+    for level in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         for frame, twin_fn in ((pkg.FRAME_RAW, hdtest.oracle_twin), (pkg.FRAME_RAW_FLUSH, hdtest.oracle_twin_flush),
                                (pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin),
                                (pkg.FRAME_RAW_FLUSH | pkg.FRAME_LATENCY, hdtest.codec_twin_flush)):

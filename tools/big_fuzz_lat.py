@@ -42,7 +42,7 @@ for seed in seeds:
         offs.append(len(blob))
         blob += b + bytes(-len(b) % 16)
     blob, ln = bytes(blob), [len(b) for b in blocks]
-    for level in (1, 2, 4, 5, 6, 7, 9):
+    for level in (1, 2, 4, 5, 6, 7, 8, 9):
         for frame, twin_fn in ((pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin),
                                (pkg.FRAME_RAW_FLUSH | pkg.FRAME_LATENCY, hdtest.codec_twin_flush)):
             slot = int(pkg.lib().hipdeflate_bound(max(ln), level))
