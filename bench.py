@@ -502,7 +502,8 @@ class Bench:
 
 def level_name(level):
     return ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else \
-        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy (6-byte key, two-way buckets)" if level >= 6 else
+        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy (6-byte key, two-way buckets, 32 KiB window)" if level >= 9 else
+                                                   "lazy (6-byte key, two-way buckets)" if level >= 6 else
                                                    "lazy (one-way)" if level == 5 else "greedy")) if level >= 2 \
         else "level 0: stored"
 
@@ -679,8 +680,10 @@ def main():
                 return out
             return run
         note("migz_l6_text", migz(6))
-        # level 5 = the one-way lazy parse (round 2's level 6): the speed end of the same trade
+        # level 5 = the one-way lazy parse (round 2's level 6): the speed end of the same trade; level 9 = the ratio end
+        # (the reference's 32 KiB window)
         note("migz_l5_text", migz(5))
+        note("migz_l9_text", migz(9))
         line["configs"] = configs
 
     if rank == 0:
