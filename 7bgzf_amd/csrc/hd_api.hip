@@ -1419,7 +1419,7 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 int hipdeflate_test_emit_stats(uint64_t *out8)
 {
 	HD_CHECK(hipDeviceSynchronize());
-	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_emit_stats), 64));
+	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_emit_stats), 128));
 	return 0;
 }
 #endif

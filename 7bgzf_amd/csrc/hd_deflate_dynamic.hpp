@@ -110,12 +110,20 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int 
 
 #ifdef HD_EMIT_STATS
 // experiment build only: cycles of the emit-only kernel by phase (tools/exp_emit_stats.sh)
-__device__ unsigned long long g_emit_stats[8];
+__device__ unsigned long long g_emit_stats[16];
 #define EMIT_T0() const unsigned long long t_ph = EMIT ? clock64() : 0ull
 #define EMIT_T(k) do { if (EMIT && lane == 0) atomicAdd(&g_emit_stats[k], clock64() - t_ph); } while (0)
 #else
 #define EMIT_T0() do { } while (0)
 #define EMIT_T(k) do { } while (0)
+#endif
+#ifdef HD_EMIT_STATS
+// ... and of build_code for the litlen alphabet, cumulative from its entry: [8 + k]
+#define BUILD_T0() const unsigned long long t_bc = clock64()
+#define BUILD_T(k) do { if (nsyms == 288 && lane == 0) atomicAdd(&g_emit_stats[8 + (k)], clock64() - t_bc); } while (0)
+#else
+#define BUILD_T0() do { } while (0)
+#define BUILD_T(k) do { } while (0)
 #endif
 
 struct HuffScratch {
@@ -133,6 +141,7 @@ struct HuffScratch {
 __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms, uint32_t maxbits, uint32_t *out,
 					 HuffScratch &h, uint32_t lane)
 {
+	BUILD_T0();
 	// working copy, dummies so that at least two symbols are used
 	uint32_t nu = 0;
 	for (uint32_t base = 0; base < nsyms; base += 64) {
@@ -169,6 +178,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			at += (uint32_t)__popcll(m);
 		}
 	}
+	BUILD_T(0);
 	for (uint32_t base = 0; base < nu; base += 64) {
 		const uint32_t x = base + lane;
 		const uint32_t mine = x < nu ? keys[x] : 0xffffffffu;
@@ -184,59 +194,128 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 		h.blc[lane] = 0;
 		h.next[lane] = 0;
 	}
-	// The serial parts run on lane 0 against LDS, ~100 cycles a round trip, so they are written to keep
-	// as few loads as possible on the critical path (same algorithm and results as the twin's loops).
-	if (lane == 0) {
-		// two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2.  The heads of both
-		// queues are held in registers (the leaf queue one element ahead), a node's weight is the
-		// sum of two register values, and a freshly made node that is the internal head is taken
-		// from the register it was computed in.
-		uint32_t i = 0, j = nu, k = nu;
-		uint32_t lv = h.nf[0], lv2 = nu > 1 ? h.nf[1] : 0u;     // leaf head and the one behind it
-		uint32_t iv = 0;                                      // internal head, valid while j < k
-		while (k < 2 * nu - 1) {
+	BUILD_T(1);
+	// The serial part: the two-queue merge and the depths of its nodes.
+	nu = uniform(nu);
+	if (nu <= 128) {
+		// Up to 128 used symbols -- every offset and precode alphabet, the litlen alphabet of DNA-like data and most text --:
+		// the queues live in REGISTERS, element x in lane x % 64 of register x / 64, and the whole wave runs the loop in
+		// step.  A head is two v_readlane and a scalar select, a store is two compare-and-select pairs over all lanes, the
+		// loop state is scalar registers and no instruction of the loop waits for LDS: ~50 instructions per node where the
+		// LDS form below spends 105 and five round trips (38 of the 65 us an emit wavefront of a latency batch took).
+		constexpr uint32_t INF = 0xffffffffu;
+		const uint32_t lane1 = lane + 64;
+		auto rd2 = [&](uint32_t r0, uint32_t r1, uint32_t x) -> uint32_t {
+			const uint32_t v0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, (int)(x & 63));
+			const uint32_t v1 = (uint32_t)__builtin_amdgcn_readlane((int)r1, (int)(x & 63));
+			return (x & 64) ? v1 : v0;
+		};
+		auto wr2 = [&](uint32_t &r0, uint32_t &r1, uint32_t x, uint32_t v) {
+			r0 = lane == x ? v : r0;
+			r1 = lane1 == x ? v : r1;
+		};
+		uint32_t LW0 = lane < nu ? h.nf[lane] : INF, LW1 = lane1 < nu ? h.nf[lane1] : INF;     // leaf weights, ascending
+		uint32_t NW0 = 0, NW1 = 0;           // node weights, in the order the nodes are made (node m: the twin's k = nu + m)
+		uint32_t LP0 = 0, LP1 = 0, NP0 = 0, NP1 = 0;                                           // parents, as node numbers
+		// an empty queue's head weighs INF, so "take the leaf" is one compare (ties: the leaf first); a freshly made
+		// node that finds the node queue empty is its head
+		uint32_t i = 0, j = 0, m = 0;
+		uint32_t lv = rd2(LW0, LW1, 0), lv2 = nu > 1 ? rd2(LW0, LW1, 1) : INF, iv = INF;
+		while (m + 1 < nu) {
 			uint32_t sum = 0;
 #pragma unroll
 			for (int t = 0; t < 2; t++) {
-				if (i < nu && (j >= k || lv <= iv)) {
+				if (lv <= iv) {
 					sum += lv;
-					h.parent[i] = (uint16_t)k;
+					wr2(LP0, LP1, i, m);
 					i++;
 					lv = lv2;
-					lv2 = i + 1 < nu ? h.nf[i + 1] : 0u;
+					lv2 = i + 1 < nu ? rd2(LW0, LW1, i + 1) : INF;
 				} else {
 					sum += iv;
-					h.parent[j] = (uint16_t)k;
+					wr2(NP0, NP1, j, m);
 					j++;
-					iv = j < k ? h.nf[j] : 0u;
+					iv = j < m ? rd2(NW0, NW1, j) : INF;
 				}
 			}
-			h.nf[k] = sum;
-			if (j == k)
+			wr2(NW0, NW1, m, sum);
+			if (iv == INF)
 				iv = sum;
-			k++;
+			m++;
 		}
-		// depths of the internal nodes, root first (a parent has the larger index); the next
-		// node's parent index is loaded while this one's depth is on its way
-		h.depth[2 * nu - 2] = 0;
-		if (nu > 2) {
-			uint32_t pn = h.parent[2 * nu - 3];
-			for (int x = (int)(2 * nu - 3); x >= (int)nu; x--) {
-				const uint32_t pc = pn;
-				if (x > (int)nu)
-					pn = h.parent[x - 1];
-				h.depth[x] = (uint8_t)(h.depth[pc] + 1);
+		// depths of the nodes, root (the last one made: depth 0) first: a parent has the larger number
+		uint32_t ND0 = 0, ND1 = 0;
+		for (uint32_t x = nu - 2; x-- > 0;)
+			wr2(ND0, ND1, x, rd2(ND0, ND1, rd2(NP0, NP1, x)) + 1);
+		// the leaves' depths, through LDS: a lane's parent is any node
+		if (lane + 1 < nu)
+			h.depth[lane] = (uint8_t)ND0;
+		if (lane1 + 1 < nu)
+			h.depth[lane1] = (uint8_t)ND1;
+		if (lane < nu) {
+			const uint32_t d = (uint32_t)h.depth[LP0] + 1;
+			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+		}
+		if (lane1 < nu) {
+			const uint32_t d = (uint32_t)h.depth[LP1] + 1;
+			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+		}
+	} else {
+		// The serial parts run on lane 0 against LDS, ~100 cycles a round trip, so they are written to keep
+		// as few loads as possible on the critical path (same algorithm and results as the twin's loops).
+		if (lane == 0) {
+			// two-queue merge: leaves 0..nu-1 ascending, internal nodes nu..2nu-2.  The heads of both
+			// queues are held in registers (the leaf queue one element ahead), a node's weight is the
+			// sum of two register values, and a freshly made node that is the internal head is taken
+			// from the register it was computed in.
+			uint32_t i = 0, j = nu, k = nu;
+			uint32_t lv = h.nf[0], lv2 = nu > 1 ? h.nf[1] : 0u;     // leaf head and the one behind it
+			uint32_t iv = 0;                                      // internal head, valid while j < k
+			while (k < 2 * nu - 1) {
+				uint32_t sum = 0;
+	#pragma unroll
+				for (int t = 0; t < 2; t++) {
+					if (i < nu && (j >= k || lv <= iv)) {
+						sum += lv;
+						h.parent[i] = (uint16_t)k;
+						i++;
+						lv = lv2;
+						lv2 = i + 1 < nu ? h.nf[i + 1] : 0u;
+					} else {
+						sum += iv;
+						h.parent[j] = (uint16_t)k;
+						j++;
+						iv = j < k ? h.nf[j] : 0u;
+					}
+				}
+				h.nf[k] = sum;
+				if (j == k)
+					iv = sum;
+				k++;
+			}
+			// depths of the internal nodes, root first (a parent has the larger index); the next
+			// node's parent index is loaded while this one's depth is on its way
+			h.depth[2 * nu - 2] = 0;
+			if (nu > 2) {
+				uint32_t pn = h.parent[2 * nu - 3];
+				for (int x = (int)(2 * nu - 3); x >= (int)nu; x--) {
+					const uint32_t pc = pn;
+					if (x > (int)nu)
+						pn = h.parent[x - 1];
+					h.depth[x] = (uint8_t)(h.depth[pc] + 1);
+				}
+			}
+		}
+		// leaves: depth and level counts by all lanes; leaves deeper than maxbits are cut back to maxbits
+		for (uint32_t base = 0; base < nu; base += 64) {
+			const uint32_t x = base + lane;
+			if (x < nu) {
+				const uint32_t d = (uint32_t)h.depth[h.parent[x]] + 1;
+				atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
 			}
 		}
 	}
-	// leaves: depth and level counts by all lanes; leaves deeper than maxbits are cut back to maxbits
-	for (uint32_t base = 0; base < nu; base += 64) {
-		const uint32_t x = base + lane;
-		if (x < nu) {
-			const uint32_t d = (uint32_t)h.depth[h.parent[x]] + 1;
-			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
-		}
-	}
+	BUILD_T(2);
 	if (lane == 0) {
 		// The cut leaves the code over-subscribed by `excess` codewords of length maxbits (Kraft sum in
 		// units of 2^-maxbits); every pass gives one back: a leaf moves one level down, a maxbits leaf
@@ -262,6 +341,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			h.next[bits] = code;
 		}
 	}
+	BUILD_T(3);
 	// lengths: the leaf at sorted position x gets `bits` where the level counts,
 	// walked from maxbits down, reach x  (smallest frequency = longest code)
 	for (uint32_t base = 0; base < nsyms; base += 64)
@@ -279,6 +359,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 		if (x < nu)
 			out[h.order[x]] = bits << 16;
 	}
+	BUILD_T(4);
 	// canonical codewords in symbol order: next[len] + rank among equal lengths
 	uint32_t run[16];
 #pragma unroll
@@ -300,6 +381,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			out[s] = (len << 16) | (__brev(cw) >> (32 - len));
 		}
 	}
+	BUILD_T(5);
 }
 
 struct DynLds {

@@ -10,7 +10,7 @@ nb, B = 16, 0xff00
 data = synth.fastq_like(nb * B, seed=1234)
 offs = np.arange(nb, dtype=np.uint64) * B
 lens = np.full(nb, B, dtype=np.uint32)
-out = (ctypes.c_uint64 * 8)()
+out = (ctypes.c_uint64 * 16)()
 pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_BGZF | pkg.FRAME_LATENCY, slot=65536)
 pkg.lib().hipdeflate_test_emit_stats(out)
 v0 = [int(x) for x in out]
@@ -21,4 +21,6 @@ pkg.lib().hipdeflate_test_emit_stats(out)
 v = [(int(x) - y) / reps / (nb * 8) for x, y in zip(out, v0)]       # cycles per emit wave (8 segments per block)
 # marks 1..3 are cumulative from the same start (EMIT_T0 after the code construction)
 print({"level": level, "cycles_per_segment": {"build_codes": round(v[0]), "lens_rle": round(v[1]), "precode_costs_header": round(v[2] - v[1]),
-       "tokens": round(v[3] - v[2])}})
+       "tokens": round(v[3] - v[2])},
+       "build_code_litlen_cumulative": dict(zip(["copy+keys", "rank sort", "merge+depths+leaf levels", "overflow+first codes", "lengths", "codewords"],
+                                                 [round(x) for x in v[8:14]]))})
