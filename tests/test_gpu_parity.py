@@ -865,8 +865,8 @@ def test_latency_context_api(pkg):
 
 def test_hook_method_table():
     """BGZF_METHOD as the hook reads it (bgzf_compress.c:53-113 parses it once per process, so every case is its own
-    process): hip<l> and hip -> that level; unset / empty -> hip at its default level 1 (preloading the library is the
-    choice of coder); a method this library does not hold -- the reference's CPU coders, unknown names the reference
+    process): hip<l> -> that level, hip -> its default level 1; unset / empty -> hip at the level of the reference's
+    default (its zlib at 6, bgzf_compress.c:54,:102); a method this library does not hold -- the reference's CPU coders, unknown names the reference
     would silently run as zlib -- keeps writing: hip at the level the reference would have used for that name (its
     digits, else the method's default of bgzf_compress.c:102-112, cut to 9)."""
     import subprocess
@@ -886,7 +886,7 @@ else:
 assert pkg.bgzf_compress_hook(b"")[1] == pkg.BGZF_EOF
 print("ok")
 ''' % (hdtest.ROOT, os.path.join(hdtest.ROOT, "tests"))
-    for method, want in ((None, 1), ("", 1), ("hip", 1), ("HIP3", 3), ("hip6", 6), ("hip0", 0), ("libdeflate6", 6),
+    for method, want in ((None, 6), ("", 6), ("hip", 1), ("HIP3", 3), ("hip6", 6), ("hip0", 0), ("libdeflate6", 6),
                          ("zlib", 6), ("nosuchcoder7", 7), ("hipster2", 2), ("libdeflate", 6), ("igzip", 1), ("libdeflate12", 9),
                          ("nosuchcoder", 6)):
         env = dict(os.environ)

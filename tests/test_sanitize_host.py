@@ -28,7 +28,7 @@ def _build(tmp_path, flags, name):
 
 def _run(exe, threads, calls, extra_env=None):
     env = dict(os.environ)
-    env.pop("BGZF_METHOD", None)                 # unset: hip at its default level
+    env.pop("BGZF_METHOD", None)                 # unset: hip at the reference's default level (6)
     env.update(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
                TSAN_OPTIONS="halt_on_error=1", HIPDEFLATE_HOOK_STATS="1")
     env.update(extra_env or {})
