@@ -305,7 +305,11 @@ static int code_batch(const hd::DeflateArgs &a, int level, hipStream_t st)
 	if (level <= 1) {
 		hd::DeflateArgs b = a;
 		b.level = level;
-		hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false>), dim3(a.nblocks), dim3(64), 0, st, b);
+		if (a.seg_slots)                    // latency segments: the instantiation with priming compiled in
+			hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false, HD_MIN_MATCH, 0, 0, 0, true>), dim3(a.nblocks),
+					   dim3(64), 0, st, b);
+		else
+			hipLaunchKernelGGL((hd::k_deflate_static<HD_L1_WIN_BITS, HD_L1_HASH_BITS, false>), dim3(a.nblocks), dim3(64), 0, st, b);
 		return 0;
 	}
 	return hd::launch_deflate_dynamic(a, level, st);

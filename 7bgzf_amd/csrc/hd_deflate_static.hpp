@@ -236,9 +236,12 @@ __device__ __forceinline__ uint8_t *part_block(uint8_t *scratch, uint32_t i)
 
 // MINLEN / LAZY / INTRA: the parse variants of the dynamic levels (hd_deflate_dynamic.hpp), used with TOK
 // DEEP: the lazy levels' matchfinder (hipdeflate_params.h "LAZY LEVELS"): six-byte key, two positions per bucket, both verified
-template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0, int INTRA = 0, int DEEP = 0>
+// PRIMED: the instantiation latency-mode launches use -- parts and priming (HD_LAT_PRIME) are compiled in.  The parse kernels
+// always have them; the level-1 kernel of the 16 GiB runs does not (with them in, 0.5 % slower for nothing)
+template <int WIN_BITS, int HASH_BITS, bool TOK, int MINLEN = HD_MIN_MATCH, int LAZY = 0, int INTRA = 0, int DEEP = 0, bool PRIMED = TOK>
 __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 {
+	static_assert(PRIMED || !TOK, "the parse kernels are always built with the latency-mode paths");
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
 	// table entries: 16-bit positions, or (DEEP) dword buckets of two -- HS counts 16-bit units either way
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	const uint32_t lane = threadIdx.x;
 	// PARTS (TOK, a.parts != 0): wavefront = part blockIdx.x % parts of segment a.first + blockIdx.x / parts.  A part behind
 	// the first one starts HD_LAT_PRIME_BYTES early: those steps fill table and window and their tokens are dropped
-	const bool parted = TOK && a.parts != 0;
+	const bool parted = PRIMED && TOK && a.parts != 0;
 	const uint32_t b = a.first + (parted ? blockIdx.x / a.parts : blockIdx.x);
 	if (b >= a.nblocks)
 		return;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	uint32_t n = a.in_len[b];
 	// PRIMED (latency mode): the wavefront starts `prime` bytes ahead of what it codes and runs those steps as the front of
 	// the pipeline only -- table and window are warm when its own bytes begin, and its first matches may reach back
-	uint32_t prime = (HD_LAT_SEG_PRIME && a.seg_slots && b % a.seg_slots) ? HD_LAT_PRIME(HD_LAT_PRIME_BYTES, n) : 0u;
+	uint32_t prime = (PRIMED && HD_LAT_SEG_PRIME && a.seg_slots && b % a.seg_slots) ? HD_LAT_PRIME(HD_LAT_PRIME_BYTES, n) : 0u;
 	if (parted) {
 		const uint32_t o = (blockIdx.x % a.parts) * HD_LAT_PART_BYTES;
 		if (o >= n)
@@ -1006,20 +1009,19 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	// dozen v_mov per step, and the refill test and its merge copies leave the steps.
 	uint32_t S = 0;
 	clk.mark(0);                                 // (diagnostic build only) prologue done
+	// priming steps (latency mode, HD_LAT_PRIME): the front of the pipeline only -- the positions enter the table, the ring
+	// fills -- and no tokens: the twin drops them, and no match crosses the border.  (A loop of its own, ahead of the main
+	// one: inside it the same lines cost the level-1 kernel 0.8 % of its 16 GiB rate.)
+	for (; S < prime && use_static; S += 64) {
+		if (filled < n && filled < S + HD_LOOKAHEAD)
+			fill_piece();
+		f0 = f1;
+		q0 = probe(f1.c, S + 64 + lane, f1.c2);
+		f1 = fetch(std::false_type{}, S + 128);
+		if (OWN_AHEAD)
+			o1 = own(S + 192);
+	}
 	while (S < n && use_static) {
-		if (S < prime) {
-			// a priming step (latency mode, HD_LAT_PRIME): the front of the pipeline only -- the positions enter the
-			// table, the ring fills -- and no tokens: the twin drops them, and no match crosses the border
-			if (filled < n && filled < S + HD_LOOKAHEAD)
-				fill_piece();
-			f0 = f1;
-			q0 = probe(f1.c, S + 64 + lane, f1.c2);
-			f1 = fetch(std::false_type{}, S + 128);
-			if (OWN_AHEAD)
-				o1 = own(S + 192);
-			S += 64;
-			continue;
-		}
 		if (small && filled < n && filled < S + HD_LOOKAHEAD && S + 15 * 64 + 192 + 8 <= n) {
 			fill_piece();
 #pragma unroll 1
