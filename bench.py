@@ -635,6 +635,13 @@ def main():
         def note(name, fn):
             try:
                 configs[name] = fn()
+                # HBM-side bytes of one step of this config, where an earlier counter run left them (tools/traffic_pmc.sh)
+                tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
+                if os.path.exists(tf) and "error" not in configs[name]:
+                    tj = json.load(open(tf))
+                    configs[name]["traffic"] = tj.get("hbm_bytes_per_launch")
+                    configs[name]["traffic_source"] = ("profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes over this config "
+                                                       "in an earlier run (all kernels of a step; see its `reading`); not measured by this process" % name)
             except Exception as ex:                     # an extra config must not take the headline down
                 configs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             B.free()
