@@ -378,3 +378,25 @@ def test_twin_ratio_envelope(level, refkey):
             total += len(z)
         got = total / e["ref_bytes"][refkey]
         assert got <= hdtest.RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))
+
+
+@pytest.mark.parametrize("level,bound", [(1, 1.02), (2, 1.035), (6, 1.033)])
+def test_twin_latency_form_ratio_envelope(level, bound):
+    """Latency mode (the hook's and the per-block codecs' form: 4080 / 8160-byte segments, four parse parts per segment at
+    the dynamic levels) against the ordinary form of the same level, on the 0xff00-byte FASTQ-like set: with every segment
+    and part primed by the 512 bytes before it (HD_LAT_PRIME) the segments cost 1.2 % at level 1, 2.5 % at level 2 (eight
+    Huffman headers per block instead of one) and 2.4 % at level 6; with unprimed segments the 16 GiB runs measured 6.4 %, 4.5 %
+    and 3.7 % (round 3).  A change that drops the priming, or parses parts cold, fails here."""
+    for name, e, data in hdtest.ratio_sets():
+        if name != "fastq/65280":
+            continue
+        lat = plain = 0
+        for b in range(e["nblocks"]):
+            chunk = data[b * e["block"]:(b + 1) * e["block"]]
+            r, z = hdtest.codec_twin(chunk, level, cap=65536 - 26)
+            assert r == 0
+            lat += len(z)
+            r, z = hdtest.oracle_twin(chunk, level, cap=len(chunk) + len(chunk) // 8 + 4096)
+            assert r == 0
+            plain += len(z)
+        assert lat / plain <= bound, (level, round(lat / plain, 4))
