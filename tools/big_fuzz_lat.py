@@ -38,9 +38,10 @@ for seed in seeds:
             o = int(rng.integers(0, max(1, len(src) - n)))
             blocks.append((src[o:o + n] * (n // max(1, len(src[o:o + n])) + 1))[:n])
     blob, offs = bytearray(), []
-    for b in blocks:
+    for i, b in enumerate(blocks):
+        blob += bytes((i * 5) % 16 if i % 3 == 0 else -len(blob) % 16)      # every third start is unaligned
         offs.append(len(blob))
-        blob += b + bytes(-len(b) % 16)
+        blob += b
     blob, ln = bytes(blob), [len(b) for b in blocks]
     for level in (1, 2, 4, 5, 6, 7, 8, 9):
         for frame, twin_fn in ((pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin),
