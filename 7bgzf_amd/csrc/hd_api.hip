@@ -1420,10 +1420,10 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 }
 
 #ifdef HD_EMIT_STATS
-int hipdeflate_test_emit_stats(uint64_t *out8)
+int hipdeflate_test_emit_stats(uint64_t *out16)   // [0,8) phases of the emit kernel, [8,16) of build_code for the litlen alphabet
 {
 	HD_CHECK(hipDeviceSynchronize());
-	HD_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hd::g_emit_stats), 128));
+	HD_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hd::g_emit_stats), 128));
 	return 0;
 }
 #endif

@@ -9,7 +9,7 @@ try:
 except SystemExit:
     pass
 pkg = importlib.import_module("7bgzf_amd")
-out = (ctypes.c_uint64 * 8)()
+out = (ctypes.c_uint64 * 16)()
 pkg.lib().hipdeflate_test_emit_stats(out)
 names = ["build litlen+offset codes", "lens copy + RLE (lane 0)", "precode, costs, header", "token loop (cumulative marks)"]
 v = [int(x) for x in out]
