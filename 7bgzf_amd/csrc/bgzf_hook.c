@@ -11,7 +11,7 @@
  *    hip's default as each method has one at :102-112).  BGZF_METHOD unset or empty
  *    is the reference's default, its zlib at level 6 (:54,:102), i.e. hip6: whoever
  *    preloads this library in place of the reference's gets the bytes-per-block class
- *    he had (rounds 1-3 answered with hip1, 0.45 of the input where zlib-6 makes 0.26;
+ *    he had (until late in round 3 the answer was hip1, 0.45 of the input where zlib-6 makes 0.26;
  *    hip6 makes 0.277).  A BGZF_METHOD that
  *    names one of the reference's CPU coders, or an unknown name (which the reference
  *    silently runs as zlib, :54), keeps WRITING: the hip coder runs at the level the
@@ -403,9 +403,6 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	} else {
 		/* spin for the batch (all members see it within a cache miss of the leader's store; a condition variable
 		 * hands its waiters over one by one, microseconds each), sleep only when it takes long */
-		/* (more callers than cores: spinning members would keep the leaders off the CPUs -- they hand the CPU on
-		 * with sched_yield() between looks instead; sleeping on the condition variable at once wakes a batch's
-		 * members one by one through its mutex, which measured 4.2 GB/s at 64 callers on 16 cores) */
 		/* as many callers as cores, or more: a spinning (or yielding) member only keeps a leader -- or the HIP runtime's
 		 * own thread, which a leader's hipStreamSynchronize waits for -- off its CPU: those members sleep at once (16
 		 * callers on 16 CPUs, hip2: 4.51 -> 4.76 GB/s); otherwise a member spins g_spin_us for its batch first (it
