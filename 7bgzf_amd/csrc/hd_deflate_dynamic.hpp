@@ -21,6 +21,7 @@
 // HBM traffic: input once, output once, + 8 B per token for the slab (L2/MALL
 // resident in practice).
 #pragma once
+#include <type_traits>
 #include "hd_deflate_static.hpp"
 
 namespace hd {
@@ -410,8 +411,10 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // CRC of blocks [a.first, a.first + a.count) are in the scratch (written by k_deflate_static<.., true>),
 // this kernel builds the codes and writes the members exactly as the fused mode would have.
 // PARTS (EMIT only): the tokens of a block lie in PARTS records, one per parse part (hipdeflate_params.h HD_LAT_PARTS)
+// ... and the workgroup has a SECOND wavefront that builds the offset code while the first builds the litlen code (an emit
+// wavefront of a latency batch is alone on its CU: the two constructions one behind the other were 30 of its 55 us)
 template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0, int PARTS = 0>
-__global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
+__global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArgs a)
 {
 	static_assert(!PARTS || EMIT, "parts are a matter of the emit-only kernel");
 	constexpr uint32_t W = 1u << WIN_BITS;
@@ -441,12 +444,23 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 	constexpr uint32_t TOKQ = 128;
 	__shared__ uint32_t tokq[EMIT ? 1 : TOKQ];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
-	const uint32_t lane = threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t b_end = EMIT ? (a.first + a.count < a.nblocks ? a.first + a.count : a.nblocks) : a.nblocks;
+	__shared__ typename std::conditional<(PARTS > 0), HuffScratch, uint32_t>::type hs2;   // the second wavefront's construction scratch
+	if (PARTS && threadIdx.x >= 64) {
+		// PARTS: the second wavefront.  It walks the same blocks as the first and meets it at two barriers per block -- the
+		// histograms are in L.df / the offset code is in Bd.dcode (flush_block) -- and does nothing else
+		for (uint32_t b = a.first + blockIdx.x; b < b_end; b += gridDim.x) {
+			__syncthreads();
+			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, *(HuffScratch *)&hs2, lane);
+			__syncthreads();
+		}
+		return;
+	}
 	const ClockStamp clk(HD_CLK_DYNAMIC);
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
 
-	const uint32_t b_end = EMIT ? (a.first + a.count < a.nblocks ? a.first + a.count : a.nblocks) : a.nblocks;
 	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
@@ -605,8 +619,13 @@ __global__ __launch_bounds__(64) void k_deflate_dynamic(DeflateArgs a)
 				L.lf[256] += 1;                     // end of block
 			{
 				EMIT_T0();
+				if (PARTS)
+					__syncthreads();                    // the second wavefront starts on the offset code
 				build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane);
-				build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, Bd.hs, lane);
+				if (PARTS)
+					__syncthreads();                    // ... and has it
+				else
+					build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, Bd.hs, lane);
 				EMIT_T(0);
 			}
 			EMIT_T0();
@@ -1144,7 +1163,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 			hipLaunchKernelGGL((k_deflate_static<W, H, true, MINLEN, LAZY, INTRA, DEEP>), dim3(s.count * HD_LAT_PARTS_MAX), dim3(64), 0, st, s);
 			const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, HD_LAT_PARTS_MAX>), dim3(eg),
-					   dim3(64), 0, st, s);
+					   dim3(128), 0, st, s);                 // (two wavefronts per workgroup: see the kernel)
 		}
 		return;
 	}

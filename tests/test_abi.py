@@ -160,8 +160,11 @@ def test_kernel_resource_budgets():
         want = 12 if ("Li13ELi11E" in k or "Li12ELi11E" in k) else (18 if deep else 14) if "Li13ELi12E" in k else \
             25 if "Li14ELi12E" in k else 32 if "Li14ELi13E" in k else 48
         assert units <= want, (k, v)                 # 10 / 9 / 7 / 5 / 4 / 2 waves per CU: dynamic_grid()
-    for v in emit.values():
-        assert v["VGPRs"] <= 128 and v["LDS Size"] <= 8 * 1280, v    # 16 waves per CU: launch_level()
+    for k, v in emit.items():
+        # 16 waves per CU: launch_level().  The PARTS instantiation (latency segments: a handful of workgroups on an empty
+        # chip) is two wavefronts and two construction scratches per workgroup
+        parts = re.search(r"ELi0EEEvNS_11DeflateArgsE$", k) is None
+        assert v["VGPRs"] <= 128 and v["LDS Size"] <= (13 if parts else 8) * 1280, (k, v)
     for k, v in sta.items():                                     # level 1 and the parse kernels of levels 2-9
         # the level-1 geometry runs 18 waves per CU = five per SIMD on two of them: <= 96 VGPRs; the two-way parse kernels
         # (8 / 5 / 4 waves per CU) have 168; the others <= 128 (four per SIMD)
