@@ -55,8 +55,8 @@ BGZF_BLOCK = 0xff00            # applet/7bgzf.c:146-147
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", default="encode", choices=["encode", "decode"])
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--gib", type=float, default=None,
