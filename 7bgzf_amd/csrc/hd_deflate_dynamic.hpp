@@ -388,7 +388,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 struct DynLds {
 	uint32_t lf[288], df[32];          // histograms of the open DEFLATE block
 	uint32_t pcode[19], pfreq[19];
-	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen
+	uint32_t misc[8];                  // 0: #items  1: hlit  2: hdist  3: hclen  4: PARTS: the segment's CRC-32 (second wavefront)
 };
 
 // Scratch of the code construction.  It is only live while a DEFLATE block is being
@@ -453,6 +453,22 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		for (uint32_t b = a.first + blockIdx.x; b < b_end; b += gridDim.x) {
 			__syncthreads();
 			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, *(HuffScratch *)&hs2, lane);
+			{
+				// ... and the segment's CRC-32 from its parts': lane q moves part q's CRC to the end of the segment (the
+				// bytes behind the part appended: a chain of dependent table loads), the lanes are XOR-ed
+				const uint32_t n = a.in_len[b];
+				const SplitLayout lay = part_layout();
+				const uint8_t *rec0 = part_block(a.scratch, (b - a.first) * PARTS);
+				const uint32_t np = (n + HD_LAT_PART_BYTES - 1) / HD_LAT_PART_BYTES;
+				uint32_t c = 0;
+				if (lane < np) {
+					const uint32_t end = (lane + 1) * HD_LAT_PART_BYTES < n ? (lane + 1) * HD_LAT_PART_BYTES : n;
+					c = crc_append_bytes(a.ct, ((const uint32_t *)(rec0 + (uint64_t)lane * lay.bytes + lay.off_rec))[1], n - end);
+				}
+				c = wave_xor_reduce(c);
+				if (lane == 0)
+					L.misc[4] = c;
+			}
 			__syncthreads();
 		}
 		return;
@@ -1051,16 +1067,6 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				const uint8_t *rec0 = part_block(a.scratch, bi * PARTS);
 				const uint32_t np = (n + HD_LAT_PART_BYTES - 1) / HD_LAT_PART_BYTES;      // <= PARTS (the launch's promise)
 				uint32_t lf[5] = { 0, 0, 0, 0, 0 }, dfv = 0, total = 0, prev = 0;
-				{
-					// lane q moves part q's CRC to the end of the segment (the bytes behind the part appended), the lanes
-					// are XOR-ed: the shifts of all parts side by side instead of one fold after the other
-					uint32_t c = 0;
-					if (lane < np) {
-						const uint32_t end = (lane + 1) * HD_LAT_PART_BYTES < n ? (lane + 1) * HD_LAT_PART_BYTES : n;
-						c = crc_append_bytes(ct, ((const uint32_t *)(rec0 + (uint64_t)lane * lay.bytes + lay.off_rec))[1], n - end);
-					}
-					crcv = wave_xor_reduce(c);
-				}
 #pragma unroll
 				for (int q = 0; q < PARTS; q++) {
 					const uint8_t *rec = rec0 + (uint64_t)q * lay.bytes;
@@ -1085,6 +1091,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				tok = (uint32_t *)rec0;
 				ntok_slab = total;
 				alive = flush_block(true);
+				crcv = uniform(L.misc[4]);              // (the second wavefront's, behind the barriers of flush_block)
 			} else {
 			// the parse has been done: one flush per recorded DEFLATE block
 			const SplitLayout lay = split_layout(a.split_max);
