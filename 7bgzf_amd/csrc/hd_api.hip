@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -1152,6 +1153,10 @@ struct hipdeflate_lat {
 	bool latency = true;
 	uint32_t seg = 0, seg_limit = 0, S = 0;                         // segment bytes, limit, segment slots per block
 	size_t meta_seg = 0;                                            // offset of the segment table in the meta buffer
+	// completion without hipStreamSynchronize (HIPDEFLATE_LAT_POLL): the run's last kernel stores the run's number here
+	size_t flag_off = 0;                                            // ... in the meta buffer (pinned, device-visible)
+	Buf d_count;                                                    // the word its workgroups count themselves off on
+	uint32_t epoch = 0;
 };
 
 hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes)
@@ -1178,9 +1183,11 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 	// [ in_off u64 | in_len, out_len, crc, status u32 | seg_off u64 [max_blocks * S] | seg_len u32 [max_blocks * S] ]
 	c->meta_seg = (((size_t)max_blocks * (8 + 4 + 4 + 4 + 4)) + 15) & ~(size_t)15;
 	const size_t meta = c->meta_seg + (size_t)max_blocks * c->S * 12 + 64;
+	c->flag_off = meta - 16;
 	const uint64_t scr = scratch_need(max_blocks, c->slot, level, c->latency);
 	if (c->h_in.reserve((size_t)max_blocks * c->in_stride) || c->h_out.reserve((size_t)max_blocks * c->slot) ||
-	    c->h_meta.reserve(meta) || (scr && c->d_scratch.reserve(scr)) ||
+	    c->h_meta.reserve(meta) || (scr && c->d_scratch.reserve(scr)) || c->d_count.reserve(16) ||
+	    hipMemset(c->d_count.p, 0, 16) != hipSuccess ||
 	    hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess ||
 	    hipHostGetDevicePointer((void **)&c->din, c->h_in.p, 0) != hipSuccess ||
 	    hipHostGetDevicePointer((void **)&c->dout, c->h_out.p, 0) != hipSuccess ||
@@ -1261,8 +1268,29 @@ static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int
 	a.hint = seg_limit ? hint : 0;
 	a.host_seg_off = seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;
 	a.host_seg_len = seg_limit ? (const uint32_t *)((const uint64_t *)(c->dmeta + c->meta_seg) + (size_t)mb * c->S) : nullptr;
+	// the segmented path's last kernel can report by itself (members of up to 64 segments, at least one segmented block)
+	static const bool poll_on = [] { const char *e = getenv("HIPDEFLATE_LAT_POLL"); return e && *e && *e != '0'; }();
+	const bool poll = poll_on && seg_limit && c->S <= 64 && !(a.hint & hd::HD_HINT_NO_SEG);
+	volatile uint32_t *flag = (volatile uint32_t *)((uint8_t *)c->h_meta.p + c->flag_off);
+	if (poll) {
+		a.done_flag = (uint32_t *)(c->dmeta + c->flag_off);
+		a.done_count = (uint32_t *)c->d_count.p;
+		a.done_epoch = ++c->epoch ? c->epoch : ++c->epoch;      // (never 0: the word starts as 0)
+	}
 	if ((r = launch_deflate(a, c->level, c->st)))
 		return r;
+	if (poll) {
+		// ~100 us of kernels: look at the word; should it not come (a fault), the stream's own wait tells
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint32_t spins = 0; __atomic_load_n((const uint32_t *)flag, __ATOMIC_ACQUIRE) != a.done_epoch; spins++) {
+			__builtin_ia32_pause();
+			if ((spins & 4095) == 4095 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+				HD_CHECK(hipStreamSynchronize(c->st));
+				break;
+			}
+		}
+		return 0;
+	}
 	HD_CHECK(hipStreamSynchronize(c->st));
 	return 0;
 }
@@ -1299,6 +1327,7 @@ void hipdeflate_lat_close(hipdeflate_lat *c)
 	c->h_out.release();
 	c->h_meta.release();
 	c->d_scratch.release();
+	c->d_count.release();
 	delete c;
 }
 

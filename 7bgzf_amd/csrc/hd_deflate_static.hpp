@@ -67,6 +67,11 @@ struct DeflateArgs {
 	// != 0: in_off / in_len are the segment table of a latency-mode launch with this many slots per block; a segment that
 	// is not the first of its block is PRIMED with the HD_LAT_PRIME_BYTES before it (the end of its predecessor)
 	uint32_t seg_slots = 0;
+	// latency contexts: the last launch of a run (k_seg_finish) tells the host it is done by itself -- its last workgroup
+	// stores `done_epoch` into `done_flag` (pinned host memory) behind a system-scope fence -- so the caller polls a word
+	// instead of going through hipStreamSynchronize.  done_count: a device word the workgroups count themselves off on
+	uint32_t *done_flag = nullptr, *done_count = nullptr;
+	uint32_t done_epoch = 0;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)

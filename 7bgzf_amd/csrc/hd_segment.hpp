@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_seg_stitch(SegArgs g)
 // block's first wavefront also folds the CRC and writes the frame, exactly as k_seg_stitch does.  No barrier, no second
 // launch behind the first: 6.5 us + 8 us + the gap between them become ~9 us of a latency batch.  (A workgroup of sixteen
 // wavefronts per member, wavefront 0 stitching and a barrier ahead of the gather, was measured slower than the two launches.)
-__global__ __launch_bounds__(64) void k_seg_finish(SegArgs g, const uint8_t *slots, uint32_t stride)
+__device__ __forceinline__ void seg_finish_one(const SegArgs &g, const uint8_t *slots, uint32_t stride)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t t = blockIdx.x / g.S, k = blockIdx.x % g.S;
@@ -259,6 +259,20 @@ __global__ __launch_bounds__(64) void k_seg_finish(SegArgs g, const uint8_t *slo
 	}
 }
 
+__global__ __launch_bounds__(64) void k_seg_finish(SegArgs g, const uint8_t *slots, uint32_t stride)
+{
+	seg_finish_one(g, slots, stride);
+	if (g.a.done_flag) {
+		// every wavefront's stores are out at system scope before it counts itself off; the last one to do so tells the host
+		__threadfence_system();
+		if (threadIdx.x == 0 && atomicAdd(g.a.done_count, 1u) == gridDim.x - 1) {
+			__hip_atomic_store(g.a.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__threadfence_system();
+			__hip_atomic_store(g.a.done_flag, g.a.done_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
+
 // a.scratch: segmented_scratch_bytes(a.nblocks, capacity, level).  `code(args)` launches the level's
 // ordinary coding of a batch (the level-1 kernel, or launch_deflate_dynamic): once for the caller's blocks
 // with seg_limit set -- it takes the blocks up to the limit, the one way such a block is coded whatever
@@ -321,6 +335,8 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		if ((r = code(s)))
 			return r;
 		if (S <= 64) {
+			if (first + rb < a.nblocks)
+				g.a.done_flag = nullptr;                       // (only the last round's launch tells the host)
 			hipLaunchKernelGGL(k_seg_finish, dim3(ns), dim3(64), 0, st, g, (const uint8_t *)slots, stride);
 		} else {
 			hipLaunchKernelGGL(k_seg_stitch, dim3(g.count), dim3(64), 0, st, g);
