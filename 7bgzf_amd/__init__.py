@@ -48,6 +48,8 @@ EXPORTS = [
     "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
     "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
     "hipdeflate_compact_span_dev",
+    "hipdeflate_init_devices", "hipdeflate_device_count", "hipdeflate_use_device",
+    "hipdeflate_pipe_open_on", "hipdeflate_unpipe_open_on", "hipdeflate_lat_open_on",
     "hipdeflate_pipe_members", "hipdeflate_lat_open", "hipdeflate_lat_input", "hipdeflate_lat_run", "hipdeflate_lat_output", "hipdeflate_lat_close",
 ]
 
@@ -94,6 +96,14 @@ def lib():
     L.hipdeflate_bound.restype = ctypes.c_uint64
     L.hipdeflate_bound.argtypes = [ctypes.c_uint64, ctypes.c_int]
     L.hipdeflate_init.argtypes = [ctypes.c_int]
+    L.hipdeflate_init_devices.argtypes = [_vp, ctypes.c_int]
+    L.hipdeflate_use_device.argtypes = [ctypes.c_int]
+    L.hipdeflate_pipe_open_on.restype = _vp
+    L.hipdeflate_pipe_open_on.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+    L.hipdeflate_unpipe_open_on.restype = _vp
+    L.hipdeflate_unpipe_open_on.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    L.hipdeflate_lat_open_on.restype = _vp
+    L.hipdeflate_lat_open_on.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
     sz_p = ctypes.POINTER(ctypes.c_size_t)
     L.hip_deflate.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]
     L.hip_deflate_flush.argtypes = [_vp, sz_p, _vp, ctypes.c_size_t, ctypes.c_int]

@@ -309,7 +309,10 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		if (k < HOOK_CTX) {
 			b = &g_batch[k];
 			if (!b->lat) {
-				b->lat = hipdeflate_lat_open(g_level, HD_FRAME_BGZF | HD_FRAME_LATENCY, HOOK_MAX_BATCH, HOOK_BLOCK);
+				/* batch context k lives on entry k of the device list (HIPDEFLATE_DEVICES), round robin */
+				const int ndev = hipdeflate_device_count();
+				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, g_level, HD_FRAME_BGZF | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
+								HOOK_BLOCK);
 				if (!b->lat) {
 					g_failed = 1;
 					pthread_mutex_unlock(&g_mu);

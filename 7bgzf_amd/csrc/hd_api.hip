@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -108,8 +111,17 @@ struct Ctx {
 	bool tiles_used = false;
 };
 
-Ctx g;
+// One context per entry of the device list (hipdeflate_init(devices...)).  An entry is a HIP device ordinal;
+// the same ordinal may appear twice (HIPDEFLATE_DEVICES=0,0: two independent contexts on one card -- how the multi-device
+// hosts are rehearsed on a one-GPU box).  A thread works on the entry hipdeflate_use_device() chose for it (default: entry
+// 0); pipes and latency contexts keep the entry they were opened on.
+constexpr int HD_MAX_CTX = 32;
+Ctx g_all[HD_MAX_CTX];
+int g_want[HD_MAX_CTX];              // the device ordinal asked for per entry (-1: from the environment)
+int g_nctx = 0;                      // entries configured (0: not yet -- the first use reads the environment)
+thread_local int t_cur = 0;
 std::mutex g_init_mu;
+inline Ctx &cur() { return g_all[t_cur]; }
 
 } // namespace
 int hd_probe_lds_order(void);        // hd_selftest.hip
@@ -231,7 +243,33 @@ void build_crc_tables(CrcTables *t)
 	}
 }
 
-int ctx_init(int device)
+// (g_init_mu held) the device list, once: an explicit list, or the environment -- HIPDEFLATE_DEVICES=0,1,... (a list),
+// HIPDEFLATE_DEVICE / LOCAL_RANK (one ordinal: a torch.distributed rank owns one card), else device 0
+void configure_locked(const int *devices, int n)
+{
+	if (g_nctx)
+		return;
+	if (devices && n > 0) {
+		for (int i = 0; i < n && i < HD_MAX_CTX; i++)
+			g_want[g_nctx++] = devices[i];
+		return;
+	}
+	const char *s = getenv("HIPDEFLATE_DEVICES");
+	if (s && *s) {
+		while (*s && g_nctx < HD_MAX_CTX) {
+			char *end = nullptr;
+			const long v = strtol(s, &end, 10);
+			if (end == s)
+				break;
+			g_want[g_nctx++] = (int)(v < 0 ? 0 : v);
+			s = *end == ',' ? end + 1 : end;
+		}
+	}
+	if (!g_nctx)
+		g_want[g_nctx++] = -1;
+}
+
+int ctx_init(Ctx &g, int device)
 {
 	std::lock_guard<std::mutex> lk(g_init_mu);
 	if (g.ready)
@@ -268,7 +306,7 @@ int ctx_init(int device)
 	HD_CHECK(hipMemcpy(g.d_ct, h, sizeof(CrcTables), hipMemcpyHostToDevice));
 	free(h);
 	// Several lanes' ds_write_b16 to one table entry in one instruction: the highest lane's data must stay (the parse
-	// kernels and their CPU twin lean on it, hd_deflate_static.hpp fetch()).  Probed once per process: on a device
+	// kernels and their CPU twin lean on it, hd_deflate_static.hpp fetch()).  Probed once per context: on a device
 	// that arbitrates differently the streams would still be valid DEFLATE but not the twin's bytes, and ranks of one
 	// job could disagree -- refused rather than run.
 	if (const int bad = hd_probe_lds_order()) {
@@ -281,24 +319,44 @@ int ctx_init(int device)
 		return g.failed = HD_E_NODEVICE;
 	}
 	g.device = device;
-	snprintf(g.desc, sizeof(g.desc), "hipdeflate 0.1 on device %d: %s (%s), %d CUs, %.0f GiB", device, prop.name,
+	snprintf(g.desc, sizeof(g.desc), "hipdeflate 0.2 on device %d: %s (%s), %d CUs, %.0f GiB", device, prop.name,
 		 prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
 	g.ready = true;
 	return 0;
 }
 
-inline int ensure()
+// entry `idx` of the device list, created on first use
+inline int ensure_ctx(int idx)
 {
-	return g.ready ? 0 : ctx_init(-1);
+	Ctx &g = g_all[idx];
+	if (g.ready)
+		return 0;
+	{
+		std::lock_guard<std::mutex> lk(g_init_mu);
+		configure_locked(nullptr, 0);
+		if (idx >= g_nctx)
+			return HD_E_ARG;
+	}
+	return ctx_init(g, g_want[idx]);
 }
+// the calling thread's context
+inline int ensure() { return ensure_ctx(t_cur); }
 
 // the host-pointer entry points may be called from any thread; the device of
-// the calling thread must be ours
-inline int bind_device()
+// the calling thread must be the context's
+inline int bind_device(const Ctx &g)
 {
 	HD_CHECK(hipSetDevice(g.device));
 	return 0;
 }
+inline int bind_device() { return bind_device(cur()); }
+
+// the methods of a pipe / latency context run on the entry it was opened on, whatever entry the calling thread has chosen
+struct OnCtx {
+	int keep;
+	explicit OnCtx(int idx) : keep(t_cur) { t_cur = idx; }
+	~OnCtx() { t_cur = keep; }
+};
 
 // the ordinary coding of a batch at `level`: one wave per block
 static int code_batch(const hd::DeflateArgs &a, int level, hipStream_t st)
@@ -338,35 +396,90 @@ inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 extern "C" {
 
-int hipdeflate_init(int device) { return ctx_init(device); }
+int hipdeflate_init(int device)
+{
+	{
+		std::lock_guard<std::mutex> lk(g_init_mu);
+		configure_locked(&device, 1);
+	}
+	return ensure();
+}
+
+int hipdeflate_init_devices(const int *devices, int n)
+{
+	if (!devices || n < 1 || n > HD_MAX_CTX)
+		return HD_E_ARG;
+	{
+		std::lock_guard<std::mutex> lk(g_init_mu);
+		if (g_nctx) {                                     // a list is already in force: the same one is fine
+			if (g_nctx != n)
+				return HD_E_ARG;
+			for (int i = 0; i < n; i++)
+				if (g_want[i] != devices[i] && !(g_all[i].ready && g_all[i].device == devices[i]))
+					return HD_E_ARG;
+		}
+		configure_locked(devices, n);
+	}
+	const int keep = t_cur;
+	int r = 0;
+	for (int i = 0; i < n && !r; i++) {
+		t_cur = i;
+		r = ensure();
+	}
+	t_cur = keep;
+	return r;
+}
+
+int hipdeflate_device_count(void)
+{
+	std::lock_guard<std::mutex> lk(g_init_mu);
+	configure_locked(nullptr, 0);
+	return g_nctx;
+}
+
+int hipdeflate_use_device(int index)
+{
+	if (index < 0 || index >= hipdeflate_device_count())
+		return HD_E_ARG;
+	t_cur = index;
+	return ensure();
+}
 
 int hipdeflate_available(void) { return ensure(); }
 
-const char *hipdeflate_version(void) { return g.desc; }
+const char *hipdeflate_version(void) { return cur().desc; }
+
+static void infb_drain();
 
 void hipdeflate_shutdown(void)
 {
+	codec_pool_drain();                                  // the per-block codecs' contexts (their own locks)
+	infb_drain();
 	std::lock_guard<std::mutex> lk(g_init_mu);
-	if (!g.ready)
-		return;
-	(void)hipSetDevice(g.device);
-	(void)hipDeviceSynchronize();                        // launches on callers' streams may still use our scratch
-	codec_pool_drain();                                  // the per-block codecs' latency contexts
-	for (Buf *b : { &g.d_in, &g.d_meta, &g.d_slots, &g.d_packed, &g.d_scratch, &g.d_scan, &g.h_in, &g.h_meta,
-			&g.h_out, &g.d_tok, &g.d_tiles })
-		b->release();
-	(void)hipFree(g.d_ct);
-	(void)hipStreamDestroy(g.stream);
-	if (g.ev_tok)
-		(void)hipEventDestroy(g.ev_tok);
-	if (g.ev_tiles)
-		(void)hipEventDestroy(g.ev_tiles);
-	g.ev_tok = g.ev_tiles = nullptr;
-	g.st_tok = g.st_tiles = nullptr;
-	g.tok_used = g.tiles_used = false;
-	g.d_ct = nullptr;
-	g.stream = nullptr;
-	g.ready = false;
+	for (int i = 0; i < HD_MAX_CTX; i++) {
+		Ctx &g = g_all[i];
+		g.failed = 0;
+		if (!g.ready)
+			continue;
+		(void)hipSetDevice(g.device);
+		(void)hipDeviceSynchronize();                        // launches on callers' streams may still use our scratch
+		for (Buf *b : { &g.d_in, &g.d_meta, &g.d_slots, &g.d_packed, &g.d_scratch, &g.d_scan, &g.h_in, &g.h_meta,
+				&g.h_out, &g.d_tok, &g.d_tiles })
+			b->release();
+		(void)hipFree(g.d_ct);
+		(void)hipStreamDestroy(g.stream);
+		if (g.ev_tok)
+			(void)hipEventDestroy(g.ev_tok);
+		if (g.ev_tiles)
+			(void)hipEventDestroy(g.ev_tiles);
+		g.ev_tok = g.ev_tiles = nullptr;
+		g.st_tok = g.st_tiles = nullptr;
+		g.tok_used = g.tiles_used = false;
+		g.d_ct = nullptr;
+		g.stream = nullptr;
+		g.ready = false;
+	}
+	g_nctx = 0;                                          // the next use configures again (environment or an explicit list)
 }
 
 static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level, bool latency)
@@ -398,6 +511,7 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 				 int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
 				 void *crc32, void *status, void *stream)
 {
+	Ctx &g = cur();
 	int r = ensure();
 	if (r)
 		return r;
@@ -461,6 +575,7 @@ static int batch_inflate_dev(const void *in, const void *in_off, const void *in_
 			     const void *out_off, const void *out_cap, void *out_len, void *crc32, void *status, void *stream,
 			     uint32_t flags)
 {
+	Ctx &g = cur();
 	int r = ensure();
 	if (r)
 		return r;
@@ -504,6 +619,7 @@ int hipdeflate_batch_inflate_flush_dev(const void *in, const void *in_off, const
 int hipdeflate_scan_sizes_dev(const void *out_len, uint32_t nblocks, uint64_t base, void *dst_off, void *total,
 			      void *stream)
 {
+	Ctx &g = cur();
 	int r = ensure();
 	if (r)
 		return r;
@@ -563,6 +679,7 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 			     int level, int frame, uint8_t *out, uint64_t out_stride, uint32_t out_cap,
 			     uint32_t *out_len, uint32_t *crc32, int32_t *status)
 {
+	Ctx &g = cur();
 	int r = ensure();
 	if (r)
 		return r;
@@ -572,7 +689,7 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 	    (frame & ~HD_FRAME_LATENCY) > HD_FRAME_GZIP)
 		return HD_E_ARG;
 	std::lock_guard<std::mutex> lk(g.mu);
-	if ((r = bind_device()))
+	if ((r = bind_device(g)))
 		return r;
 
 	// pack the blocks 16-byte aligned into pinned memory (one H2D, aligned fast path)
@@ -659,6 +776,7 @@ static int batch_inflate_host(const uint8_t *in, const uint64_t *in_off, const u
 			      uint8_t *out, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
 			      uint32_t *crc32, int32_t *status, uint32_t flags)
 {
+	Ctx &g = cur();
 	int r = ensure();
 	if (r)
 		return r;
@@ -755,6 +873,7 @@ struct PipeSlot {
 };
 
 struct hipdeflate_pipe {
+	int ctx = 0;                                 // entry of the device list the pipe lives on
 	int level, frame, depth;
 	uint32_t block, per_batch;
 	size_t slot_stride;
@@ -773,6 +892,7 @@ hipdeflate_pipe *hipdeflate_pipe_open(int level, int frame, uint32_t block_bytes
 	    depth < 2 || depth > 16 || (uint64_t)block_bytes * blocks_per_batch > 0xffff0000ull)
 		return nullptr;
 	hipdeflate_pipe *p = new hipdeflate_pipe;
+	p->ctx = t_cur;
 	p->level = level;
 	p->frame = frame;
 	p->depth = depth;
@@ -783,19 +903,38 @@ hipdeflate_pipe *hipdeflate_pipe_open(int level, int frame, uint32_t block_bytes
 	if (frame == HD_FRAME_BGZF && p->slot_stride > 65536)
 		p->slot_stride = 65536;
 	p->slots.resize(depth);
-	const size_t in_cap = (size_t)block_bytes * blocks_per_batch;
-	const size_t meta = (size_t)blocks_per_batch * (8 + 4 + 4 + 4 + 4 + 8) + 16;
+	// A slot's memory is pinned / allocated when the slot is first handed out (pipe_slot_alloc): pinning costs ~0.3 ms per
+	// MiB, and a stream that ends after one batch -- or a caller that wants its first bytes soon -- should not wait for
+	// `depth` batches' worth of it.  Only the streams are made here.
 	for (PipeSlot &s : p->slots) {
-		if (s.h_in.reserve(in_cap) || s.d_in.reserve(in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
-		    s.d_slots.reserve(p->slot_stride * blocks_per_batch + 16) ||
-		    s.d_packed.reserve(p->slot_stride * blocks_per_batch + 16) ||
-		    s.h_out.reserve(p->slot_stride * blocks_per_batch + 16) ||
-		    hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+		if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
 			hipdeflate_pipe_close(p);
 			return nullptr;
 		}
 	}
 	return p;
+}
+
+// (the caller is the one thread that does input() / submit() on this pipe)
+static int pipe_slot_alloc(hipdeflate_pipe *p, PipeSlot &s)
+{
+	if (s.h_in.p)
+		return 0;
+	const size_t in_cap = (size_t)p->block * p->per_batch;
+	const size_t meta = (size_t)p->per_batch * (8 + 4 + 4 + 4 + 4 + 8) + 16;
+	if (s.h_in.reserve(in_cap) || s.d_in.reserve(in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
+	    s.d_slots.reserve(p->slot_stride * p->per_batch + 16) || s.d_packed.reserve(p->slot_stride * p->per_batch + 16))
+		return HD_E_NOMEM;
+	return 0;
+}
+
+hipdeflate_pipe *hipdeflate_pipe_open_on(int index, int level, int frame, uint32_t block_bytes, uint32_t blocks_per_batch,
+					 int depth)
+{
+	if (index < 0 || index >= hipdeflate_device_count())
+		return nullptr;
+	const OnCtx on(index);
+	return hipdeflate_pipe_open(level, frame, block_bytes, blocks_per_batch, depth);
 }
 
 uint8_t *hipdeflate_pipe_input(hipdeflate_pipe *p, size_t *cap)
@@ -807,6 +946,13 @@ uint8_t *hipdeflate_pipe_input(hipdeflate_pipe *p, size_t *cap)
 	if (s.state == 1)
 		return nullptr;                          // input() twice without submit()
 	p->cv.wait(lk, [&] { return s.state == 0; });
+	lk.unlock();
+	{
+		const OnCtx on(p->ctx);
+		if (ensure() || bind_device() || pipe_slot_alloc(p, s))
+			return nullptr;
+	}
+	lk.lock();
 	s.state = 1;
 	if (cap)
 		*cap = (size_t)p->block * p->per_batch;
@@ -825,8 +971,9 @@ int hipdeflate_pipe_submit(hipdeflate_pipe *p, size_t nbytes)
 			return HD_E_ARG;
 	}
 	PipeSlot &s = *sp;
-	int r = bind_device();
-	if (r)
+	const OnCtx on(p->ctx);
+	int r = ensure();
+	if (r || (r = bind_device()))
 		return r;
 	s.nbytes = nbytes;
 	s.nb = (uint32_t)((nbytes + p->block - 1) / p->block);
@@ -884,8 +1031,9 @@ int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nby
 		sp = &p->slots[p->n_out % p->depth];
 	}
 	PipeSlot &s = *sp;
-	int r = bind_device();
-	if (r)
+	const OnCtx on(p->ctx);
+	int r = ensure();
+	if (r || (r = bind_device()))
 		return r;
 	int bad = 0;
 	size_t total = 0;
@@ -903,6 +1051,9 @@ int hipdeflate_pipe_result(hipdeflate_pipe *p, const uint8_t **data, size_t *nby
 		memcpy(s.doff.data(), (const uint8_t *)s.h_meta.p + (size_t)12 * s.nb, (size_t)8 * s.nb);
 		for (uint32_t i = 0; i < s.nb; i++)
 			bad |= h_st[i] != 0;
+		// the pinned landing buffer follows what the data needs (+ 25 %), not the worst case of the slots
+		if (s.h_out.reserve(total + 16))
+			return HD_E_NOMEM;
 		HD_CHECK(hipMemcpyAsync(s.h_out.p, s.d_packed.p, total, hipMemcpyDeviceToHost, s.st));
 		HD_CHECK(hipStreamSynchronize(s.st));
 	}
@@ -941,6 +1092,9 @@ void hipdeflate_pipe_close(hipdeflate_pipe *p)
 {
 	if (!p)
 		return;
+	const OnCtx on(p->ctx);
+	Ctx &g = cur();
+	(void)hipSetDevice(g.device);
 	(void)hipDeviceSynchronize();
 	for (PipeSlot &s : p->slots) {
 		s.h_in.release();
@@ -966,6 +1120,7 @@ void hipdeflate_pipe_close(hipdeflate_pipe *p)
 /* ---- streaming decoder ---------------------------------------------------------- */
 
 struct hipdeflate_unpipe {
+	int ctx = 0;
 	int depth;
 	uint32_t max_members;
 	size_t in_cap, out_cap;
@@ -983,21 +1138,38 @@ hipdeflate_unpipe *hipdeflate_unpipe_open(uint32_t max_members, size_t in_cap, s
 	if (!max_members || !in_cap || !out_cap || depth < 2 || depth > 16 || in_cap > 0xffff0000ull)
 		return nullptr;
 	hipdeflate_unpipe *p = new hipdeflate_unpipe;
+	p->ctx = t_cur;
 	p->depth = depth;
 	p->max_members = max_members;
 	p->in_cap = in_cap;
 	p->out_cap = out_cap;
 	p->slots.resize(depth);
-	const size_t meta = (size_t)max_members * (8 + 8 + 4 + 4 + 4 + 4 + 4) + 64;
-	for (PipeSlot &s : p->slots) {
-		if (s.h_in.reserve(in_cap) || s.d_in.reserve(in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
-		    s.d_slots.reserve(out_cap + 16) || s.h_out.reserve(out_cap + 16) ||
-		    hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+	for (PipeSlot &s : p->slots) {                            // memory: when a slot is first handed out (unpipe_slot_alloc)
+		if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
 			hipdeflate_unpipe_close(p);
 			return nullptr;
 		}
 	}
 	return p;
+}
+
+static int unpipe_slot_alloc(hipdeflate_unpipe *p, PipeSlot &s)
+{
+	if (s.h_in.p)
+		return 0;
+	const size_t meta = (size_t)p->max_members * (8 + 8 + 4 + 4 + 4 + 4 + 4) + 64;
+	if (s.h_in.reserve(p->in_cap) || s.d_in.reserve(p->in_cap + 16) || s.h_meta.reserve(meta) || s.d_meta.reserve(meta) ||
+	    s.d_slots.reserve(p->out_cap + 16) || s.h_out.reserve(p->out_cap + 16))
+		return HD_E_NOMEM;
+	return 0;
+}
+
+hipdeflate_unpipe *hipdeflate_unpipe_open_on(int index, uint32_t max_members, size_t in_cap, size_t out_cap, int depth)
+{
+	if (index < 0 || index >= hipdeflate_device_count())
+		return nullptr;
+	const OnCtx on(index);
+	return hipdeflate_unpipe_open(max_members, in_cap, out_cap, depth);
 }
 
 uint8_t *hipdeflate_unpipe_input(hipdeflate_unpipe *p, size_t *cap)
@@ -1009,6 +1181,13 @@ uint8_t *hipdeflate_unpipe_input(hipdeflate_unpipe *p, size_t *cap)
 	if (s.state == 1)
 		return nullptr;
 	p->cv.wait(lk, [&] { return s.state == 0; });
+	lk.unlock();
+	{
+		const OnCtx on(p->ctx);
+		if (ensure() || bind_device() || unpipe_slot_alloc(p, s))
+			return nullptr;
+	}
+	lk.lock();
 	s.state = 1;
 	if (cap)
 		*cap = p->in_cap;
@@ -1028,8 +1207,9 @@ int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const
 			return HD_E_ARG;
 	}
 	PipeSlot &s = *sp;
-	int r = bind_device();
-	if (r)
+	const OnCtx on(p->ctx);
+	int r = ensure();
+	if (r || (r = bind_device()))
 		return r;
 	// pinned table: ioff[n] ooff[n] (u64) | ilen[n] ocap[n] (u32); results olen[n] crc[n] st[n] behind it
 	const uint32_t n = nmembers;
@@ -1091,8 +1271,9 @@ int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t 
 		sp = &p->slots[p->n_out % p->depth];
 	}
 	PipeSlot &s = *sp;
-	int r = bind_device();
-	if (r)
+	const OnCtx on(p->ctx);
+	int r = ensure();
+	if (r || (r = bind_device()))
 		return r;
 	int verdict = 0;
 	if (s.nb) {
@@ -1117,6 +1298,9 @@ void hipdeflate_unpipe_close(hipdeflate_unpipe *p)
 {
 	if (!p)
 		return;
+	const OnCtx on(p->ctx);
+	Ctx &g = cur();
+	(void)hipSetDevice(g.device);
 	(void)hipDeviceSynchronize();
 	for (PipeSlot &s : p->slots) {
 		s.h_in.release();
@@ -1144,6 +1328,7 @@ void hipdeflate_unpipe_close(hipdeflate_unpipe *p)
  * copy under a lock), device scratch for the segments, one stream.  run() = a handful of launches + one
  * synchronisation.  Contexts are independent: two of them overlap on the device. */
 struct hipdeflate_lat {
+	int ctx = 0;                                                    // entry of the device list
 	int level = 1, frame = HD_FRAME_BGZF;
 	uint32_t max_blocks = 0, in_stride = 0, slot = 0;
 	hipStream_t st = nullptr;
@@ -1168,6 +1353,7 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 	    max_block_bytes > (64u << 20))
 		return nullptr;
 	hipdeflate_lat *c = new hipdeflate_lat;
+	c->ctx = t_cur;
 	c->level = level;
 	c->frame = fr;
 	c->latency = (frame & HD_FRAME_LATENCY) != 0;
@@ -1202,6 +1388,14 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 	return c;
 }
 
+hipdeflate_lat *hipdeflate_lat_open_on(int index, int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes)
+{
+	if (index < 0 || index >= hipdeflate_device_count())
+		return nullptr;
+	const OnCtx on(index);
+	return hipdeflate_lat_open(level, frame, max_blocks, max_block_bytes);
+}
+
 uint8_t *hipdeflate_lat_input(hipdeflate_lat *c, uint32_t i)
 {
 	return c && i < c->max_blocks ? (uint8_t *)c->h_in.p + (size_t)i * c->in_stride : nullptr;
@@ -1217,6 +1411,8 @@ static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int
 	if (!n)
 		return 0;
 	// (a context may outlive hipdeflate_shutdown(), which frees the shared tables: ensure() brings them back)
+	const OnCtx on(c->ctx);
+	Ctx &g = cur();
 	int r = ensure();
 	if (r || (r = bind_device()))
 		return r;
@@ -1319,6 +1515,8 @@ void hipdeflate_lat_close(hipdeflate_lat *c)
 {
 	if (!c)
 		return;
+	if (g_all[c->ctx].ready)
+		(void)hipSetDevice(g_all[c->ctx].device);
 	if (c->st) {
 		(void)hipStreamSynchronize(c->st);
 		(void)hipStreamDestroy(c->st);
@@ -1353,7 +1551,11 @@ static hipdeflate_lat *codec_acquire(int level)
 			return c;
 		}
 	}
-	return hipdeflate_lat_open(level, HD_FRAME_RAW | HD_FRAME_LATENCY, 1, CODEC_BLOCK);
+	// a new context: the per-block codecs' contexts are spread over the device list
+	static unsigned rr = 0;
+	const int ndev = hipdeflate_device_count();
+	const unsigned turn = __atomic_fetch_add(&rr, 1u, __ATOMIC_RELAXED);
+	return hipdeflate_lat_open_on(ndev > 0 ? (int)(turn % (unsigned)ndev) : 0, level, HD_FRAME_RAW | HD_FRAME_LATENCY, 1, CODEC_BLOCK);
 }
 
 static void codec_release(hipdeflate_lat *c, int level)
@@ -1431,10 +1633,109 @@ int hip_deflate_flush(unsigned char *dest, size_t *destLen, const unsigned char 
 	return deflate_one(dest, destLen, source, sourceLen, level, HD_FRAME_RAW_FLUSH);
 }
 
-static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, uint32_t flags)
+/* ---- per-block decoder: hip_inflate / hip_inflate_flush -----------------------------------------------------------
+ * The role of zlibutil_auto_inflate (lib/zlibutil.c:82-93 -> libdeflate_inflate :194-204) as the reference calls it: a
+ * THREAD PER BLOCK, -@N of them at once (applet/7bgzf.c:330-345).  One stream is one wavefront's serial work, so what a
+ * GPU can give such callers is all of them at once: concurrent calls are coalesced into one launch of the latency kernel
+ * (k_inflate_lat: the whole window in LDS) over a batch's pinned, device-visible memory -- every caller copies its own
+ * stream in and its own output out with no lock held, the kernel reads and writes that memory itself (no copy engine),
+ * the first caller of a batch leads it (closes it once every caller that is inside and not already on the device has
+ * joined, launches, waits), the others sleep on the batch's state word.  No process-wide lock around the decoding:
+ * INFB_CTX batches can be collecting / running side by side, spread over the device list.  A stream or an output
+ * larger than a batch's arena goes alone through the host-buffer batch call. */
+constexpr uint32_t INFB_SLOTS = 64;                           // streams per batch
+constexpr size_t INFB_IN_ARENA = (size_t)5 << 20;             // 64 x (64 KiB + the stored form's overhead) and room to spare
+constexpr size_t INFB_OUT_ARENA = (size_t)4 << 20;            // 64 x 64 KiB
+constexpr int INFB_CTX = 8;
+
+struct InfBatch {
+	int ctx = -1;                                             // entry of the device list
+	hipStream_t st = nullptr;
+	Buf h_in{ nullptr, 0, true }, h_out{ nullptr, 0, true }, h_meta{ nullptr, 0, true };
+	uint8_t *din = nullptr, *dout = nullptr, *dmeta = nullptr;   // device views of the pinned buffers
+	uint32_t state = 0;                                       // futex word: 0 free, 1 collecting, 2 closed (running), 3 done
+	int n = 0;
+	size_t in_used = 0, out_used = 0;
+	uint32_t flags = 0;
+	int ready = 0, taken = 0, sleepers = 0, rc = 0;
+	// the pinned table, device-visible: in_off u64[S] | out_off u64[S] | in_len, out_cap, out_len, status u32[S]
+	uint64_t *in_off() { return (uint64_t *)h_meta.p; }
+	uint64_t *out_off() { return in_off() + INFB_SLOTS; }
+	uint32_t *in_len() { return (uint32_t *)(out_off() + INFB_SLOTS); }
+	uint32_t *out_cap() { return in_len() + INFB_SLOTS; }
+	uint32_t *out_len() { return out_cap() + INFB_SLOTS; }
+	int32_t *status() { return (int32_t *)(out_len() + INFB_SLOTS); }
+};
+InfBatch g_infb[INFB_CTX];
+std::mutex g_inf_mu;
+std::condition_variable g_inf_free;
+int g_inf_open = -1;                                          // the collecting batch
+int g_inf_active = 0, g_inf_running = 0;                      // callers inside inflate_one / in batches that are closed
+long g_inf_window_ns = 100000, g_inf_linger_ns = 15000;       // HIPDEFLATE_INFLATE_WINDOW_US / _LINGER_US
+int g_inf_failed = 0;
+
+static void infb_sleep(uint32_t *w, uint32_t seen) { syscall(SYS_futex, w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+static void infb_wake_all(uint32_t *w) { syscall(SYS_futex, w, FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0); }
+static inline int64_t infb_now()
 {
-	if (!dest || !destLen || (!source && sourceLen) || sourceLen >= HD_INFLATE_MAX_IN)
-		return HD_E_ARG;
+	return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// (g_inf_mu held) a batch context's memory and stream, once
+static int infb_create(InfBatch &b, int k)
+{
+	if (b.st)
+		return 0;
+	static const bool env_once = [] {
+		if (const char *w = getenv("HIPDEFLATE_INFLATE_WINDOW_US"))
+			g_inf_window_ns = atol(w) * 1000;
+		if (const char *w = getenv("HIPDEFLATE_INFLATE_LINGER_US"))
+			g_inf_linger_ns = atol(w) * 1000;
+		return true;
+	}();
+	(void)env_once;
+	const int ndev = hipdeflate_device_count();
+	b.ctx = ndev > 0 ? k % ndev : 0;
+	const OnCtx on(b.ctx);
+	if (ensure() || bind_device())
+		return HD_E_NODEVICE;
+	const size_t meta = (size_t)INFB_SLOTS * (8 + 8 + 4 + 4 + 4 + 4);
+	if (b.h_in.reserve(INFB_IN_ARENA + 64) || b.h_out.reserve(INFB_OUT_ARENA + 64) || b.h_meta.reserve(meta) ||
+	    hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&b.din, b.h_in.p, 0) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&b.dout, b.h_out.p, 0) != hipSuccess ||
+	    hipHostGetDevicePointer((void **)&b.dmeta, b.h_meta.p, 0) != hipSuccess) {
+		b.h_in.release();
+		b.h_out.release();
+		b.h_meta.release();
+		if (b.st)
+			(void)hipStreamDestroy(b.st);
+		b.st = nullptr;
+		return HD_E_NOMEM;
+	}
+	return 0;
+}
+
+static void infb_drain()                                      // hipdeflate_shutdown(): idle batch contexts are closed
+{
+	std::lock_guard<std::mutex> lk(g_inf_mu);
+	for (InfBatch &b : g_infb) {
+		if (!b.st || __atomic_load_n(&b.state, __ATOMIC_ACQUIRE) != 0)
+			continue;
+		if (g_all[b.ctx].ready)
+			(void)hipSetDevice(g_all[b.ctx].device);
+		(void)hipStreamSynchronize(b.st);
+		(void)hipStreamDestroy(b.st);
+		b.st = nullptr;
+		b.h_in.release();
+		b.h_out.release();
+		b.h_meta.release();
+	}
+	g_inf_failed = 0;
+}
+
+static int inflate_alone(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, uint32_t flags)
+{
 	uint64_t ioff = 0, ooff = 0;
 	uint32_t ilen = (uint32_t)sourceLen, olen = 0;
 	uint32_t ocap = *destLen > 0xfffffff0u ? 0xfffffff0u : (uint32_t)*destLen;
@@ -1446,6 +1747,180 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 		return st;
 	*destLen = olen;
 	return 0;
+}
+
+static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, uint32_t flags)
+{
+	if (!dest || !destLen || (!source && sourceLen) || sourceLen >= HD_INFLATE_MAX_IN)
+		return HD_E_ARG;
+	const size_t ocap = *destLen > 0xfffffff0u ? 0xfffffff0u : *destLen;
+	const size_t in_need = up16(sourceLen + 4), out_need = up16(ocap);       // (+4: the kernel reads whole dwords)
+	if (in_need > INFB_IN_ARENA / 4 || out_need > INFB_OUT_ARENA / 4)
+		return inflate_alone(dest, destLen, source, sourceLen, flags);
+
+	/* ---- join the collecting batch, or open one ------------------------------------------------------------- */
+	std::unique_lock<std::mutex> lk(g_inf_mu);
+	if (g_inf_failed) {
+		const int f = g_inf_failed;
+		lk.unlock();
+		return f == HD_E_NOMEM ? inflate_alone(dest, destLen, source, sourceLen, flags) : f;
+	}
+	g_inf_active++;
+	InfBatch *b = nullptr;
+	for (;;) {
+		if (g_inf_open >= 0) {
+			b = &g_infb[g_inf_open];
+			if (b->flags == flags && b->n < (int)INFB_SLOTS && b->in_used + in_need <= INFB_IN_ARENA &&
+			    b->out_used + out_need <= INFB_OUT_ARENA)
+				break;
+			// it cannot take this stream: closed as it stands (its leader finds it so), a new one is opened
+			__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
+			g_inf_running += b->n;
+			g_inf_open = -1;
+		}
+		int k;
+		for (k = 0; k < INFB_CTX && __atomic_load_n(&g_infb[k].state, __ATOMIC_ACQUIRE) != 0; k++)
+			;
+		if (k < INFB_CTX) {
+			b = &g_infb[k];
+			if (const int r = infb_create(*b, k)) {
+				g_inf_failed = r;
+				g_inf_active--;
+				lk.unlock();
+				return r == HD_E_NOMEM ? inflate_alone(dest, destLen, source, sourceLen, flags) : r;
+			}
+			b->n = 0;
+			b->in_used = b->out_used = 0;
+			b->flags = flags;
+			b->rc = 0;
+			__atomic_store_n(&b->ready, 0, __ATOMIC_RELAXED);
+			__atomic_store_n(&b->taken, 0, __ATOMIC_RELAXED);
+			__atomic_store_n(&b->state, 1u, __ATOMIC_RELEASE);
+			g_inf_open = k;
+			break;
+		}
+		g_inf_free.wait(lk);                              // every batch context is busy: wait for one to drain
+	}
+	const int idx = b->n;
+	const bool leader = idx == 0;
+	const size_t my_in = b->in_used, my_out = b->out_used;
+	b->in_off()[idx] = my_in;
+	b->out_off()[idx] = my_out;
+	b->in_len()[idx] = (uint32_t)sourceLen;
+	b->out_cap()[idx] = (uint32_t)ocap;
+	b->in_used += in_need;
+	b->out_used += out_need;
+	__atomic_store_n(&b->n, idx + 1, __ATOMIC_RELAXED);
+	// everybody who could join has: the callers inside that are not in a closed batch are all here (or the batch is full)
+	if (b->n >= (int)INFB_SLOTS || b->n >= g_inf_active - g_inf_running) {
+		__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
+		g_inf_running += b->n;
+		g_inf_open = -1;
+	}
+	lk.unlock();
+
+	if (sourceLen)
+		memcpy((uint8_t *)b->h_in.p + my_in, source, sourceLen);      /* own stream, no lock held */
+	__atomic_add_fetch(&b->ready, 1, __ATOMIC_RELEASE);
+
+	if (leader) {
+		// others join while the window is open; whoever completes the batch (above) closes it, or the leader does when
+		// nobody has joined for the linger time although callers are missing, or when the window is over
+		if (g_inf_window_ns > 0) {
+			const int64_t t0 = infb_now(), deadline = t0 + g_inf_window_ns;
+			int64_t t_last = t0;
+			int seen = 1;
+			while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) == 1) {
+				const int64_t t = infb_now();
+				const int now_n = __atomic_load_n(&b->n, __ATOMIC_RELAXED);
+				if (now_n != seen) {
+					seen = now_n;
+					t_last = t;
+				}
+				if (t >= deadline || t - t_last >= g_inf_linger_ns)
+					break;
+				__builtin_ia32_pause();
+			}
+		}
+		lk.lock();
+		if (__atomic_load_n(&b->state, __ATOMIC_RELAXED) == 1) {
+			__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
+			g_inf_running += b->n;
+			g_inf_open = -1;
+		}
+		const int n = b->n;
+		lk.unlock();
+		while (__atomic_load_n(&b->ready, __ATOMIC_ACQUIRE) < n)             /* the others are still copying in */
+			__builtin_ia32_pause();
+		int rc = 0;
+		{
+			const OnCtx on(b->ctx);
+			if (!(rc = ensure()) && !(rc = bind_device())) {
+				hd::InflateArgs a;
+				a.in = b->din;
+				a.in_off = (const uint64_t *)b->dmeta;
+				a.out_off = a.in_off + INFB_SLOTS;
+				a.in_len = (const uint32_t *)(a.out_off + INFB_SLOTS);
+				a.out_cap = a.in_len + INFB_SLOTS;
+				a.out_len = (uint32_t *)(a.out_cap + INFB_SLOTS);
+				a.status = (int32_t *)(a.out_len + INFB_SLOTS);
+				a.nblocks = (uint32_t)n;
+				a.out = b->dout;
+				a.crc = nullptr;
+				a.ct = cur().d_ct;
+				a.flags = b->flags;
+				hipLaunchKernelGGL(hd::k_inflate_lat, dim3((uint32_t)n), dim3(64), 0, b->st, a);
+				if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->st) != hipSuccess) {
+					fprintf(stderr, "hipdeflate: hip_inflate: the latency kernel did not run\n");
+					rc = HD_E_NODEVICE;
+				}
+			}
+		}
+		b->rc = rc;
+		lk.lock();
+		g_inf_running -= n;
+		lk.unlock();
+		(void)__atomic_exchange_n(&b->state, 3u, __ATOMIC_SEQ_CST);   /* (a full fence: the load of `sleepers` must not pass it) */
+		if (__atomic_load_n(&b->sleepers, __ATOMIC_SEQ_CST))
+			infb_wake_all(&b->state);
+	} else {
+		// a batch is about a millisecond of device time: look for a moment (a batch of short streams), then sleep on the word
+		const int64_t spin_until = infb_now() + 20000;
+		uint32_t st;
+		int spins = 0;
+		while ((st = __atomic_load_n(&b->state, __ATOMIC_ACQUIRE)) != 3) {
+			if ((++spins & 63) == 0 && infb_now() > spin_until) {
+				__atomic_add_fetch(&b->sleepers, 1, __ATOMIC_SEQ_CST);
+				if (__atomic_load_n(&b->state, __ATOMIC_SEQ_CST) == st)
+					infb_sleep(&b->state, st);
+				__atomic_sub_fetch(&b->sleepers, 1, __ATOMIC_ACQ_REL);
+			} else {
+				__builtin_ia32_pause();
+			}
+		}
+	}
+	const int rc = b->rc, nb = b->n;
+	int ret = rc;
+	if (!rc) {
+		const int32_t st = b->status()[idx];
+		const uint32_t olen = b->out_len()[idx];
+		if (st) {
+			ret = st;
+		} else {
+			if (olen)
+				memcpy(dest, (const uint8_t *)b->h_out.p + my_out, olen);   /* own output, no lock held */
+			*destLen = olen;
+		}
+	}
+	const bool last = __atomic_add_fetch(&b->taken, 1, __ATOMIC_ACQ_REL) == nb;
+	lk.lock();
+	g_inf_active--;
+	if (last) {
+		__atomic_store_n(&b->state, 0u, __ATOMIC_RELEASE);                /* drained: the context can collect again */
+		g_inf_free.notify_all();
+	}
+	lk.unlock();
+	return ret;
 }
 
 #ifdef HD_EMIT_STATS

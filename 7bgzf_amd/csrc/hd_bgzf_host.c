@@ -9,7 +9,10 @@
  *     hd7bgzf -d  < in.bgz > out
  *     hd7bgzf -M -b1024 -G6 < in > out.migz    (MiGz framing, block = b KiB)
  *     hd7bgzf -G1 --index out.bgz.gzi < in > out.bgz     (+ bgzip's .gzi block index)
- *     hd7bgzf -G1 -@8 -i in -o out.bgz                    (file to file: N threads pread / pwrite, batches of 8192 blocks)
+ *     hd7bgzf -G1 -@8 -i in -o out.bgz                    (file to file: N threads pread / pwrite)
+ *     hd7bgzf -G1 -g8 -i in -o out.bgz                    (-g N: the batches are dealt round robin to N devices -- the entries
+ *                                                          of HIPDEFLATE_DEVICES if set, else devices 0..N-1; the reference's
+ *                                                          analogue is -@ N worker threads, applet/7bgzf.c:155-217)
  *
  * What changed, and why: the reference reads one <=64 KiB block, compresses it on
  * a fresh pthread and writes it (applet/7bgzf.c:159-277); a GPU needs thousands
@@ -84,7 +87,12 @@ static int index_write(void)
 /* compress: the reader thread fills pinned batches straight from stdin and submits
  * them, the main thread takes the finished batches (one contiguous run of members
  * each) in order and writes them; three batches are in flight on the device side */
-static hipdeflate_pipe *g_pipe;
+/* -g N: one pipe per entry of the device list; batch j goes to pipe j % N, the results are fetched in the same order,
+ * so the one reader and the one in-order writer of the single-device host drive N cards and the output is byte for
+ * byte that of -g 1 (blocks are independent) */
+#define HD_MAX_G 32
+static hipdeflate_pipe *g_pipes[HD_MAX_G];
+static int g_npipe = 1;
 static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
 static int g_submitted, g_reader_done, g_reader_err;
@@ -92,7 +100,8 @@ static int g_submitted, g_reader_done, g_reader_err;
 static void *reader_main(void *arg)
 {
 	(void)arg;
-	for (;;) {
+	for (int j = 0;; j++) {
+		hipdeflate_pipe *g_pipe = g_pipes[j % g_npipe];
 		size_t cap = 0, got = 0;
 		unsigned char *buf = hipdeflate_pipe_input(g_pipe, &cap);
 		int err = buf == NULL;
@@ -136,13 +145,26 @@ static int write_all(const unsigned char *p, size_t n)
 	return 0;
 }
 
+static int open_pipes(int level, uint32_t per, int depth)
+{
+	const int ndev = hipdeflate_device_count();
+	for (int k = 0; k < g_npipe; k++) {
+		g_pipes[k] = hipdeflate_pipe_open_on(k % (ndev > 0 ? ndev : 1), level, g_frame, (uint32_t)g_block, per, depth);
+		if (!g_pipes[k]) {
+			fprintf(stderr, "hip_deflate: cannot open the device pipeline\n");
+			return 1;
+		}
+	}
+	return 0;
+}
+
 static int do_compress(int level)
 {
-	g_pipe = hipdeflate_pipe_open(level, g_frame, (uint32_t)g_block, g_frame == HD_FRAME_MIGZ ? (uint32_t)((HD_PIPE_BATCH * (size_t)0xff00 + g_block - 1) / g_block) : HD_PIPE_BATCH, 4);
-	if (!g_pipe) {
-		fprintf(stderr, "hip_deflate: cannot open the device pipeline\n");
+	size_t per = g_frame == HD_FRAME_MIGZ ? (HD_PIPE_BATCH * (size_t)0xff00 + g_block - 1) / g_block : HD_PIPE_BATCH;
+	if (getenv("HD7BGZF_BATCH") && atol(getenv("HD7BGZF_BATCH")) > 0)
+		per = (size_t)atol(getenv("HD7BGZF_BATCH"));
+	if (open_pipes(level, (uint32_t)per, g_npipe > 1 ? 3 : 4))
 		return 1;
-	}
 	pthread_t rd;
 	pthread_create(&rd, NULL, reader_main, NULL);
 	int total_blocks = 0, chk = 64, fetched = 0, ret = 0;
@@ -163,6 +185,7 @@ static int do_compress(int level)
 		const uint8_t *data;
 		size_t nbytes;
 		uint32_t nb;
+		hipdeflate_pipe *g_pipe = g_pipes[fetched % g_npipe];
 		int r = hipdeflate_pipe_result(g_pipe, &data, &nbytes, &nb);
 		if (r) {
 			fprintf(stderr, "hip_deflate %d\n", r);                      /* applet/7bgzf.c:228-254 */
@@ -197,7 +220,8 @@ static int do_compress(int level)
 	if (ret)
 		_exit(1);                                         /* the reader may sit in read(): do not join it */
 	pthread_join(rd, NULL);
-	hipdeflate_pipe_close(g_pipe);
+	for (int k = 0; k < g_npipe; k++)
+		hipdeflate_pipe_close(g_pipes[k]);
 	if (g_frame == HD_FRAME_BGZF && write_all(eof_member, 28))            /* applet/7bgzf.c:283-289 */
 		return 1;
 	if (g_index_path && index_write()) {
@@ -303,7 +327,9 @@ static double now_s(void)
 static void *file_reader_main(void *arg)
 {
 	(void)arg;
-	for (off_t pos = 0;;) {
+	int j = 0;
+	for (off_t pos = 0;; j++) {
+		hipdeflate_pipe *g_pipe = g_pipes[j % g_npipe];
 		size_t cap = 0;
 		double t0 = now_s();
 		unsigned char *buf = hipdeflate_pipe_input(g_pipe, &cap);
@@ -345,21 +371,23 @@ static void *fallocate_main(void *arg)
 static int do_compress_files(int level, int nthreads)
 {
 	const size_t nblocks = (size_t)((g_in_size + (off_t)g_block - 1) / (off_t)g_block);
-	/* batches as large as the device likes them (8192 blocks), smaller for small files so that three are in flight */
-	size_t per = nblocks / 3 + 1;
-	if (per > 8192)
-		per = 8192;
+	/* Batches of 2048 blocks (128 MiB): this path is bound by the host's reads, writes and by pinning memory (~0.3 ms per
+	 * MiB, paid when a slot is first used), not by the kernels, so a batch only needs to be large enough for the copies and
+	 * launches to overlap -- 8192-block batches (rounds 2-3) pinned 3 GiB before the first byte moved.  Smaller for small
+	 * files so that a few are in flight per device.  HD7BGZF_BATCH overrides. */
+	size_t per = nblocks / (size_t)(4 * g_npipe) + 1;
+	if (per > 2048)
+		per = 2048;
+	if (getenv("HD7BGZF_BATCH") && atol(getenv("HD7BGZF_BATCH")) > 0)
+		per = (size_t)atol(getenv("HD7BGZF_BATCH"));
 	if (g_frame == HD_FRAME_MIGZ && per * g_block > ((size_t)512 << 20))
 		per = ((size_t)512 << 20) / g_block;
 	if (per < 64)
 		per = 64;
 	double t0 = now_s();
-	g_pipe = hipdeflate_pipe_open(level, g_frame, (uint32_t)g_block, (uint32_t)per, 3);
-	g_t_open = now_s() - t0;
-	if (!g_pipe) {
-		fprintf(stderr, "hip_deflate: cannot open the device pipeline\n");
+	if (open_pipes(level, (uint32_t)per, g_npipe > 1 ? 3 : 4))
 		return 1;
-	}
+	g_t_open = now_s() - t0;
 	/* -@ N: N readers and N writers.  The output's pages are allocated ahead of the writers by a helper thread
 	 * (fallocate of what the data is likely to need, in 256 MiB steps: a first write into a fresh page-cache or tmpfs
 	 * page costs several times a memcpy -- measured 5 GB/s for 8 writers without it) */
@@ -390,6 +418,7 @@ static int do_compress_files(int level, int nthreads)
 		size_t nbytes;
 		uint32_t nb;
 		t0 = now_s();
+		hipdeflate_pipe *g_pipe = g_pipes[fetched % g_npipe];
 		const int r = hipdeflate_pipe_result(g_pipe, &data, &nbytes, &nb);
 		g_t_result += now_s() - t0;
 		if (r) {
@@ -437,7 +466,8 @@ static int do_compress_files(int level, int nthreads)
 	if (!fstat(g_fd_out, &so) && S_ISREG(so.st_mode) && ftruncate(g_fd_out, written + (g_frame == HD_FRAME_BGZF ? 28 : 0)))
 		return 1;
 	free(io);
-	hipdeflate_pipe_close(g_pipe);
+	for (int k = 0; k < g_npipe; k++)
+		hipdeflate_pipe_close(g_pipes[k]);
 	if (g_frame == HD_FRAME_BGZF && pwrite(g_fd_out, eof_member, 28, written) != 28)        /* applet/7bgzf.c:283-289 */
 		return 1;
 	if (g_index_path && index_write()) {
@@ -497,7 +527,7 @@ static int member_len(const unsigned char *p, size_t avail, size_t *hdr, size_t 
  * finished batch -- one contiguous run of output -- in order */
 #define UNP_IN_CAP  ((size_t)16 << 20)
 #define UNP_OUT_CAP ((size_t)96 << 20)
-static hipdeflate_unpipe *g_unpipe;
+static hipdeflate_unpipe *g_unpipes[HD_MAX_G];
 static int g_members;
 
 static void reader_fail(int code)
@@ -517,7 +547,8 @@ static void *unreader_main(void *arg)
 	unsigned char *carry = NULL;
 	size_t carry_len = 0, carry_cap = 0;
 	int eof = 0;
-	while (!eof || carry_len) {
+	for (int j = 0; !eof || carry_len; j++) {
+		hipdeflate_unpipe *g_unpipe = g_unpipes[j % g_npipe];
 		size_t cap = 0;
 		unsigned char *buf = hipdeflate_unpipe_input(g_unpipe, &cap);
 		if (!buf || carry_len > cap) {
@@ -606,10 +637,13 @@ static void *unreader_main(void *arg)
 
 static int do_decompress(void)
 {
-	g_unpipe = hipdeflate_unpipe_open(HD_BATCH, UNP_IN_CAP, UNP_OUT_CAP, 3);
-	if (!g_unpipe) {
-		fprintf(stderr, "inflate: cannot open the device pipeline\n");
-		return 1;
+	const int ndev = hipdeflate_device_count();
+	for (int k = 0; k < g_npipe; k++) {
+		g_unpipes[k] = hipdeflate_unpipe_open_on(k % (ndev > 0 ? ndev : 1), HD_BATCH, UNP_IN_CAP, UNP_OUT_CAP, 3);
+		if (!g_unpipes[k]) {
+			fprintf(stderr, "inflate: cannot open the device pipeline\n");
+			return 1;
+		}
 	}
 	pthread_t rd;
 	pthread_create(&rd, NULL, unreader_main, NULL);
@@ -629,7 +663,7 @@ static int do_decompress(void)
 		}
 		const uint8_t *data;
 		size_t nbytes;
-		int r = hipdeflate_unpipe_result(g_unpipe, &data, &nbytes);
+		int r = hipdeflate_unpipe_result(g_unpipes[fetched % g_npipe], &data, &nbytes);
 		if (r) {
 			fprintf(stderr, "inflate %d\n", r);                          /* applet/7bgzf.c:350-353 */
 			ret = 1;
@@ -645,7 +679,8 @@ static int do_decompress(void)
 	if (ret)
 		_exit(ret < 0 ? 255 : 1);
 	pthread_join(rd, NULL);
-	hipdeflate_unpipe_close(g_unpipe);
+	for (int k = 0; k < g_npipe; k++)
+		hipdeflate_unpipe_close(g_unpipes[k]);
 	fprintf(stderr, "%d done.\n", g_members);
 	return 0;
 }
@@ -674,6 +709,8 @@ int main(int argc, char **argv)
 			out_path = argv[++i];
 		else if (!strncmp(a, "-@", 2))
 			nthreads = a[2] ? atoi(a + 2) : 8;              /* I/O threads of the file-to-file path */
+		else if (!strncmp(a, "-g", 2) && a[2] >= '0' && a[2] <= '9')
+			g_npipe = atoi(a + 2);                          /* devices */
 		else if (!strcmp(a, "-c"))
 			;                                               /* accepted and ignored, as the reference's -c */
 		else {
@@ -690,8 +727,19 @@ int main(int argc, char **argv)
 		g_block = (size_t)bsize * 1024;
 	}
 	g_timing = getenv("HD7BGZF_TIMING") != NULL;
-	if (hipdeflate_init(-1))
+	if (g_npipe < 1 || g_npipe > HD_MAX_G) {
+		fprintf(stderr, "-g: 1..%d devices\n", HD_MAX_G);
 		return 1;
+	}
+	if (g_npipe > 1 && !(getenv("HIPDEFLATE_DEVICES") && *getenv("HIPDEFLATE_DEVICES"))) {
+		int list[HD_MAX_G];                                   /* -g N without a list: devices 0 .. N-1 */
+		for (int k = 0; k < g_npipe; k++)
+			list[k] = k;
+		if (hipdeflate_init_devices(list, g_npipe))
+			return 1;
+	} else if (hipdeflate_init(-1)) {
+		return 1;
+	}
 	struct timeval t0, t1;
 	gettimeofday(&t0, NULL);
 	int ret;

@@ -89,9 +89,10 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
 
 constexpr uint32_t INF_LT_BITS = 9;      // litlen direct table (8 VGPRs once loaded)
 constexpr uint32_t INF_DT_BITS = 8;      // offset direct table
-constexpr uint32_t INF_RING    = 2048;   // LDS output ring: small on purpose, occupancy beats window
+constexpr uint32_t INF_RING    = 2048;   // LDS output ring of the throughput kernel: small on purpose, occupancy beats window
                                          // (8 KiB: 36 GB/s, 2 KiB: 49 GB/s on the libdeflate-6 stream)
-constexpr uint32_t INF_NEAR    = INF_RING - 258 - 64; // dist <= this: source is in the ring
+constexpr uint32_t INF_RING_LAT = 65536; // ... of the latency kernel (k_inflate_lat: a few streams on an empty chip, hip_inflate):
+                                         // every match source of a block is in LDS, nothing waits for flushed output
 
 // table entry: [31:16] value (literal / length base / offset base)
 //              [9:8] kind  [7:4] extra-bit count  [3:0] codeword length
@@ -134,15 +135,16 @@ __device__ __forceinline__ uint32_t offset_entry(uint32_t sym, uint32_t len)
 //     (decompress_template.h:171), dead once the lengths are in;
 //   - cl / pre_lens share the union with the window decoder's dump slots and stream copy; the dump
 //     slots follow the ring directly, ring[INF_RING + lane] addresses them.
-struct InfLds {
+template <uint32_t RING>
+struct InfLdsT {
 	uint32_t lit[1u << INF_LT_BITS];
 	uint32_t off[1u << INF_DT_BITS];
 	uint16_t lit_sorted[288];
 	uint16_t off_sorted[32];
 	uint16_t lit_count[16], off_count[16];
 	union {
-		__attribute__((aligned(16))) uint8_t ring[INF_RING];
-		uint32_t ring32[INF_RING / 4];
+		__attribute__((aligned(16))) uint8_t ring[RING];
+		uint32_t ring32[RING / 4];
 	};
 	union {
 		struct {
@@ -155,6 +157,7 @@ struct InfLds {
 		};
 	};
 };
+using InfLds = InfLdsT<INF_RING>;
 static_assert(sizeof(InfLds) == 6400, "InfLds must stay within five LDS allocation units");
 constexpr uint32_t INF_T_SCRATCH = 320;      // byte offset in cl of { u32 cnt[16]; u16 first[16]; u16 offs[16]; }
 
@@ -163,7 +166,6 @@ constexpr uint32_t INF_T_SCRATCH = 320;      // byte offset in cl of { u32 cnt[1
 //   nsyms <= 288; tbits = direct table bits; kind 0 litlen / 1 offset / 2 precode
 // Per-length counters live in LDS (one lane per code length), not in registers:
 // sixteen-element uniform arrays would cost 64 SGPRs and spill the symbol loop.
-struct InfLds;
 template <int KIND>
 __device__ __noinline__ uint32_t build_table(const uint8_t *lens, uint32_t nsyms, uint32_t *table, uint32_t tbits,
 					  uint16_t *sorted, uint16_t *count_out, uint8_t *scratch, uint32_t lane)
@@ -277,9 +279,11 @@ __device__ __noinline__ uint32_t slow_decode(uint64_t bb, const uint16_t *count,
 	return (uint32_t)sorted[readlane(offs + d, len)] | (len << 16);
 }
 
-__global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
+// the decoder, for an output ring of RING bytes (one wavefront; L is the workgroup's LDS)
+template <uint32_t RING>
+__device__ __forceinline__ void inflate_stream(const InflateArgs &a, InfLdsT<RING> &L)
 {
-	__shared__ InfLds L;
+	constexpr uint32_t INF_NEAR = RING - 258 - 64;       // dist <= this: source is in the ring
 	const uint32_t lane = threadIdx.x;
 	const uint32_t b = blockIdx.x;
 	if (b >= a.nblocks)
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	crc.init(lane, 0xffffffffu);          // length unknown yet; lane 0 seeds, fixed in finish
 	auto flush_pieces = [&]() {
 		while (pos - flushed >= HD_PIECE) {
-			const uint4 v = *(const uint4 *)&L.ring[(flushed & (INF_RING - 1)) + 16 * lane];
+			const uint4 v = *(const uint4 *)&L.ring[(flushed & (RING - 1)) + 16 * lane];
 			if (dst_aligned) {
 				*(uint4 *)(dst + flushed + 16 * lane) = v;
 			} else {
@@ -398,8 +402,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	// some room in the output (the window's budget), less than a piece waiting for the flush.
 	// Returns 0 = fall back to the scalar loop for one token, 1 = end of block
 	// consumed, 2 = error (st set).  Reader state is the scalar one on both sides.
-	// output budget of one window: pending <= 1023 + 704 = 1727 <= INF_RING - 64 - 257, so a source is
-	// either wholly in the ring (wend - src <= INF_RING - 64) or wholly flushed to HBM
+	// output budget of one window: pending <= 1023 + 704 = 1727 <= RING - 64 - 257, so a source is
+	// either wholly in the ring (wend - src <= RING - 64) or wholly flushed to HBM
 	constexpr uint32_t WIN_OUT_BUDGET = 704;
 	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
 	uint32_t lds_p0 = 0xfffffff0u;                // pieces lds_p0, lds_p0 + 1 are in L.comp
@@ -548,8 +552,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
 			const uint64_t lit0 = real0 & s0.is_lit, lit1 = real1 & s1.is_lit;
 			auto store_literals = [&]() {
-				L.ring[sel(lit0, opos0 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s0.e >> 16);
-				L.ring[sel(lit1, opos1 & (INF_RING - 1), INF_RING + lane)] = (uint8_t)(s1.e >> 16);
+				L.ring[sel(lit0, opos0 & (RING - 1), RING + lane)] = (uint8_t)(s0.e >> 16);
+				L.ring[sel(lit1, opos1 & (RING - 1), RING + lane)] = (uint8_t)(s1.e >> 16);
 			};
 			if (!HD_INF_OWNER)
 				store_literals();
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// "simple": source wholly in the ring and wholly in front of this window's output,
 			// at most 64 bytes.  Nothing in the window feeds them, so they go first and in any order;
 			// whatever else there is follows in stream order.
-			const uint64_t inr0 = __ballot(wend - srcl0 <= INF_RING - 64), inr1 = __ballot(wend - srcl1 <= INF_RING - 64);
+			const uint64_t inr0 = __ballot(wend - srcl0 <= RING - 64), inr1 = __ballot(wend - srcl1 <= RING - 64);
 			const uint64_t le0 = __ballot(s0.length <= 64), le1 = __ballot(s1.length <= 64);
 			const uint64_t simple0 = match0 & inr0 & __ballot(s0.offset >= rel0 + s0.length) & le0;
 			const uint64_t simple1 = match1 & inr1 & __ballot(s1.offset >= rel1 + s1.length) & le1;
@@ -601,8 +605,8 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			// the lane groups took ~36 per pass (INSTS_VALU 209 -> 199 per 64 bytes with the groups; this kernel is
 			// bound by vector issue).  Not for: a destination run that wraps the ring (one scalar test per window),
 			// a ring source whose five dwords would, a far source when the output is not 4-byte aligned.
-			const bool ring_room = (pos & (INF_RING - 1)) + cum + 16 <= INF_RING;
-			const uint64_t sw0 = __ballot((srcl0 & (INF_RING - 1)) <= INF_RING - 20), sw1 = __ballot((srcl1 & (INF_RING - 1)) <= INF_RING - 20);
+			const bool ring_room = (pos & (RING - 1)) + cum + 16 <= RING;
+			const uint64_t sw0 = __ballot((srcl0 & (RING - 1)) <= RING - 20), sw1 = __ballot((srcl1 & (RING - 1)) <= RING - 20);
 			const uint64_t vfar0 = dst_al4 ? hbm0 : 0ull, vfar1 = dst_al4 ? hbm1 : 0ull;
 			const uint64_t vec0 = ring_room ? ((simple0 & sw0) | vfar0) & l16_0 : 0ull;
 			const uint64_t vec1 = ring_room ? ((simple1 & sw1) | vfar1) & l16_1 : 0ull;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			auto far_store = [&]() {
 #pragma unroll
 				for (int k = 0; k < FARK; k++)
-					L.ring[lane < fml[k] ? ((fP[k] + lane) & (INF_RING - 1)) : INF_RING + lane] = (uint8_t)fv[k];
+					L.ring[lane < fml[k] ? ((fP[k] + lane) & (RING - 1)) : RING + lane] = (uint8_t)fv[k];
 			};
 			const bool anyfar = (hbm0 | hbm1) != 0;
 			if (anyfar)
@@ -660,10 +664,10 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 							const uint32_t *g = (const uint32_t *)(dst + al);
 							w0 = g[0]; w1 = g[1]; w2 = g[2]; w3 = g[3]; w4 = g[4];
 						} else {
-							const uint32_t ri = (al & (INF_RING - 1)) >> 2;
+							const uint32_t ri = (al & (RING - 1)) >> 2;
 							w0 = L.ring32[ri]; w1 = L.ring32[ri + 1]; w2 = L.ring32[ri + 2]; w3 = L.ring32[ri + 3]; w4 = L.ring32[ri + 4];
 						}
-						const uint32_t da = ring_lds + (oposv & (INF_RING - 1));
+						const uint32_t da = ring_lds + (oposv & (RING - 1));
 						if ((longm >> lane) & 1) {
 							const uint32_t b2 = __builtin_amdgcn_alignbyte(w3, w2, sh), b3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
 							asm volatile("ds_write_b8_d16_hi %0, %4 offset:15\n\t"
@@ -723,11 +727,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 						const uint32_t dp = pos + (w & 1023) + sub, sp = dp - (w >> 15);
 						const bool act = sub < ml;
 						// (the whole source in the ring or the whole source flushed: the same test as inr above)
-						const bool ringsrc = wend - (sp - sub) <= INF_RING - 64;
-						uint32_t v = L.ring[sp & (INF_RING - 1)];
+						const bool ringsrc = wend - (sp - sub) <= RING - 64;
+						uint32_t v = L.ring[sp & (RING - 1)];
 						if (act && !ringsrc)
 							v = dst[sp];
-						const uint32_t di = act ? (dp & (INF_RING - 1)) : INF_RING + lane;
+						const uint32_t di = act ? (dp & (RING - 1)) : RING + lane;
 						if (HD_INF_DEFER && !pend) {
 							pend = true;
 							pend_idx = di;
@@ -779,26 +783,26 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s0.outlen, m), P = readlane(opos0, m), srcp = readlane(srcl0, m);
-				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
-				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
+				const uint8_t v = L.ring[(srcp + lane) & (RING - 1)];
+				L.ring[lane < mlen ? ((P + lane) & (RING - 1)) : RING + lane] = v;
 			}
 			for (uint64_t sm = simple1 & ~done1; sm;) {
 				const uint32_t m = (uint32_t)__ffsll((unsigned long long)sm) - 1;
 				asm("s_bitset0_b64 %0, %1" : "+s"(sm) : "s"(m));       // (sm &= sm - 1 is three scalar instructions)
 				const uint32_t mlen = readlane(s1.outlen, m), P = readlane(opos1, m), srcp = readlane(srcl1, m);
-				const uint8_t v = L.ring[(srcp + lane) & (INF_RING - 1)];
-				L.ring[lane < mlen ? ((P + lane) & (INF_RING - 1)) : INF_RING + lane] = v;
+				const uint8_t v = L.ring[(srcp + lane) & (RING - 1)];
+				L.ring[lane < mlen ? ((P + lane) & (RING - 1)) : RING + lane] = v;
 			}
 			if (pend)
 				L.ring[pend_idx] = (uint8_t)pend_v;
 			auto copy_general = [&](uint32_t mlen, uint32_t P, uint32_t srcp) {
 				const uint32_t moff = P - srcp;
-				if (wend - srcp <= INF_RING - 64) {
+				if (wend - srcp <= RING - 64) {
 					// source still in the ring (the literals and the simple matches of the whole
 					// window are already in)
 					if (moff >= mlen) {
 						for (uint32_t i = lane; i < mlen; i += 64)
-							L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + i) & (INF_RING - 1)];
+							L.ring[(P + i) & (RING - 1)] = L.ring[(srcp + i) & (RING - 1)];
 					} else {
 						const float rcp = 1.0f / (float)moff;
 						for (uint32_t i = lane; i < mlen; i += 64) {
@@ -806,14 +810,14 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 							uint32_t r = i - q * moff;
 							r = (int32_t)r < 0 ? r + moff : r;
 							r = r >= moff ? r - moff : r;
-							L.ring[(P + i) & (INF_RING - 1)] = L.ring[(srcp + r) & (INF_RING - 1)];
+							L.ring[(P + i) & (RING - 1)] = L.ring[(srcp + r) & (RING - 1)];
 						}
 					}
 				} else {
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
 					for (uint32_t i = lane; i < mlen; i += 64)
-						L.ring[(P + i) & (INF_RING - 1)] = dst[srcp + i];
+						L.ring[(P + i) & (RING - 1)] = dst[srcp + i];
 				}
 			};
 			if (scalar_far) {
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			for (uint32_t done = 0; done < len;) {
 				const uint32_t step = len - done < 64 ? len - done : 64;
 				if (lane < step)
-					L.ring[(pos + lane) & (INF_RING - 1)] = src[ip + done + lane];
+					L.ring[(pos + lane) & (RING - 1)] = src[ip + done + lane];
 				pos += step;
 				done += step;
 				if (pos - flushed >= HD_PIECE)
@@ -1015,7 +1019,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 				if (kind == K_LIT) {
 					if (pos == cap) { st = HD_INSUFFICIENT_SPACE; break; }
 					// every lane stores the same byte to the same address: no exec juggling
-					L.ring[pos & (INF_RING - 1)] = (uint8_t)(e >> 16);
+					L.ring[pos & (RING - 1)] = (uint8_t)(e >> 16);
 					pos++;
 					INF_T1(2, t_tok);
 					continue;
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					if (offset >= length) {
 						// disjoint: the common case, one pass per 64 bytes
 						for (uint32_t i = lane; i < length; i += 64)
-							L.ring[(pos + i) & (INF_RING - 1)] = L.ring[(pos - offset + i) & (INF_RING - 1)];
+							L.ring[(pos + i) & (RING - 1)] = L.ring[(pos - offset + i) & (RING - 1)];
 					} else {
 						// overlapping (run of period `offset`): source index i mod offset,
 						// by a uniform reciprocal; all sources lie before pos
@@ -1061,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 							uint32_t r = i - q * offset;
 							r = (int32_t)r < 0 ? r + offset : r;
 							r = r >= offset ? r - offset : r;
-							L.ring[(pos + i) & (INF_RING - 1)] = L.ring[(pos - offset + r) & (INF_RING - 1)];
+							L.ring[(pos + i) & (RING - 1)] = L.ring[(pos - offset + r) & (RING - 1)];
 						}
 					}
 				} else {
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
 					for (uint32_t i = lane; i < length; i += 64)
-						L.ring[(pos + i) & (INF_RING - 1)] = dst[pos - offset + i];
+						L.ring[(pos + i) & (RING - 1)] = dst[pos - offset + i];
 				}
 				pos += length;
 				INF_T1(2, t_tok);
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	if (st == HD_OK) {
 		// tail: bytes [flushed, pos) leave the ring byte-wise
 		for (uint32_t i = flushed + lane; i < pos; i += 64)
-			dst[i] = L.ring[i & (INF_RING - 1)];
+			dst[i] = L.ring[i & (RING - 1)];
 		if (want_crc) {
 			// full 16-byte slots of the tail piece, then the < 16 byte remainder
 			const uint32_t piece = flushed / HD_PIECE;
@@ -1098,11 +1102,11 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 			const bool full = o + 16 <= pos;
 			uint4 v = make_uint4(0, 0, 0, 0);
 			if (full)
-				v = *(const uint4 *)&L.ring[o & (INF_RING - 1)];
+				v = *(const uint4 *)&L.ring[o & (RING - 1)];
 			if (pos < 16)
 				crc.s = 0;                       // no full slot at all: finish() reseeds
 			crc.fold(ct, piece, full, v);
-			crcv = crc.finish(ct, lane, pos, &L.ring[(pos & ~15u) & (INF_RING - 1)]);
+			crcv = crc.finish(ct, lane, pos, &L.ring[(pos & ~15u) & (RING - 1)]);
 		}
 	}
 	if (lane == 0) {
@@ -1112,6 +1116,22 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	}
 	INF_T1(3, t_kernel);
 	INF_CYC_FLUSH;
+}
+
+// throughput form: thousands of streams per launch, 25 workgroups' worth of LDS per CU
+__global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
+{
+	__shared__ InfLds L;
+	inflate_stream<INF_RING>(a, L);
+}
+
+// latency form (hip_inflate / hip_inflate_flush: a handful of streams, callers waiting): the same decoder with the whole
+// DEFLATE window -- a whole BGZF block -- in LDS.  One wavefront alone on its CU cannot hide a load of flushed output
+// behind other waves; here it never issues one (a match reaches back 32 KiB at most, the ring holds 64).
+__global__ __launch_bounds__(64) void k_inflate_lat(InflateArgs a)
+{
+	__shared__ InfLdsT<INF_RING_LAT> L;
+	inflate_stream<INF_RING_LAT>(a, L);
 }
 
 } // namespace hd

@@ -64,10 +64,23 @@ extern "C" {
 
 /* ---- lifetime ---------------------------------------------------------- */
 
-/* Select the device (-1: HIPDEFLATE_DEVICE env, else LOCAL_RANK env, else 0) and
- * create the context.  Idempotent; every other entry point calls it lazily. */
+/* The device list (SURVEY.md 8(b) `hipdeflate_init(devices...)`; the reference's analogue is -@ N worker threads,
+ * applet/7bgzf.c:155-217).  The library keeps one context -- stream, tables, scratch -- per ENTRY of the list; an entry
+ * is a HIP device ordinal and an ordinal may be listed twice (two independent contexts on one card: how the
+ * multi-device hosts are rehearsed on a one-GPU box).  The list is fixed by the first of:
+ *   hipdeflate_init_devices(list, n)            an explicit list (n <= 32);
+ *   hipdeflate_init(device)                     a list of one; device -1 = HIPDEFLATE_DEVICE, else LOCAL_RANK, else 0
+ *                                               (a torch.distributed / RCCL rank owns one card);
+ *   any other entry point, lazily               HIPDEFLATE_DEVICES=0,1,2,... if set, else as hipdeflate_init(-1).
+ * Contexts are created on first use.  A thread's calls run on entry 0 unless it chose another with
+ * hipdeflate_use_device(index) (thread-local, like hipSetDevice); pipes and latency contexts stay on the entry they
+ * were opened on whatever thread calls them; the LD_PRELOAD hook and the per-block codecs spread their batch contexts
+ * over the whole list.  Idempotent; hipdeflate_init_devices with a list other than the one in force is HD_E_ARG. */
 int  hipdeflate_init(int device);
-void hipdeflate_shutdown(void);
+int  hipdeflate_init_devices(const int *devices, int n);
+int  hipdeflate_device_count(void);          /* entries of the list (configures it from the environment if need be) */
+int  hipdeflate_use_device(int index);       /* 0, or HD_E_ARG / HD_E_NODEVICE; index = position in the list */
+void hipdeflate_shutdown(void);              /* every context; the next call configures the list afresh */
 /* 0 if a usable device is present and the kernels loaded, else HD_E_NODEVICE */
 int  hipdeflate_available(void);
 /* human-readable build/device description, never NULL */
@@ -84,7 +97,11 @@ int hip_deflate(unsigned char *dest, size_t *destLen,
 /* zlibutil_code_dec (lib/zlibutil.h:46).  Stops at BFINAL, ignores trailing
  * source bytes (applet/7bgzf.c:328 passes payload + 8-byte trailer).  Returns
  * enum libdeflate_result values 0/1/3 like libdeflate_inflate
- * (lib/zlibutil.c:194-204). */
+ * (lib/zlibutil.c:194-204).  Re-entrant and thread-safe, and built for the way the reference calls it -- a thread
+ * per block, -@ N at once (applet/7bgzf.c:330-345): concurrent calls are coalesced into one launch (one wavefront
+ * per stream, the whole window in LDS) on pinned batch memory, no process-wide lock; the batches are spread over the
+ * device list.  HIPDEFLATE_INFLATE_WINDOW_US (100) / _LINGER_US (15) bound how long a batch's first caller waits
+ * for the others. */
 int hip_inflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen);
 
@@ -222,6 +239,10 @@ int hipdeflate_pipe_members(hipdeflate_pipe *p, const uint32_t **out_len, const 
 /* BAM / tabix virtual file offset of byte `uoffset` of the block whose member starts at `coffset` */
 #define HIPDEFLATE_VOFFSET(coffset, uoffset) (((uint64_t)(coffset) << 16) | (uint64_t)((uoffset) & 0xffff))
 void hipdeflate_pipe_close(hipdeflate_pipe *p);
+/* the same pipe on entry `index` of the device list: one pipe per device and batches dealt round robin is how
+ * hd7bgzf -g N drives N cards from one in-order reader and one in-order writer */
+hipdeflate_pipe *hipdeflate_pipe_open_on(int index, int level, int frame, uint32_t block_bytes,
+					 uint32_t blocks_per_batch, int depth);
 
 /* ---- streaming decoder: the same pipeline in the other direction -----------------
  * Role of the read / inflate / write loop of applet/7bgzf.c:295-365.  The caller reads
@@ -240,6 +261,7 @@ int hipdeflate_unpipe_submit(hipdeflate_unpipe *p, const uint64_t *in_off, const
  * (1 bad data / 3 does not fit, also used when a member is shorter than out_size), or HD_E_* */
 int hipdeflate_unpipe_result(hipdeflate_unpipe *p, const uint8_t **data, size_t *nbytes);
 void hipdeflate_unpipe_close(hipdeflate_unpipe *p);
+hipdeflate_unpipe *hipdeflate_unpipe_open_on(int index, uint32_t max_members, size_t in_cap, size_t out_cap, int depth);
 
 /* ---- latency contexts: small synchronous batches ----------------------------------
  * For callers that hold a FEW blocks and wait for them: the LD_PRELOAD hook (htslib's worker threads hand over
@@ -258,6 +280,7 @@ int hipdeflate_lat_run(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n);
 /* member i of the last run: its bytes (pinned, valid until the next run), size, CRC-32 of the input, status */
 const uint8_t *hipdeflate_lat_output(hipdeflate_lat *c, uint32_t i, uint32_t *out_len, uint32_t *crc32, int32_t *status);
 void hipdeflate_lat_close(hipdeflate_lat *c);
+hipdeflate_lat *hipdeflate_lat_open_on(int index, int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes);
 
 /* scratch bytes batch_deflate_dev needs per launch for `level` (0 for level <= 1): the token slabs of the
  * fused kernel plus, for blocks up to 256 KiB (max_block = the slot stride), the tokens and histograms of one
@@ -266,13 +289,16 @@ void hipdeflate_lat_close(hipdeflate_lat *c);
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level);
 
 /* ---- LD_PRELOAD hook ----------------------------------------------------- */
-/* Same signature and return values as bgzf_compress.c:39: 0 ok; -1 if
- * *dlen < 26 (28 for the EOF block) or no coder; 1 on codec error.  slen == 0
- * yields the canned 28-byte EOF block.  BGZF_METHOD=hip<level> (default level
- * 1) is the only method this library serves; any other BGZF_METHOD value makes
- * the call fail with -1 ("coder missing"), it never falls back to a CPU codec.
- * Calls from concurrent htslib worker threads are micro-batched into one
- * launch (HIPDEFLATE_BATCH_US, default 200 us window). */
+/* Same signature and return values as bgzf_compress.c:39: 0 ok; -1 if *dlen < 26 (28 for the EOF block) or the
+ * device is missing; 1 on codec error.  slen == 0 yields the canned 28-byte EOF block.  BGZF_METHOD (parsed once,
+ * bgzf_compress.c:53-113: name + trailing digits = level): `hip<level>` is this library's coder (`hip` alone =
+ * level 1); UNSET means level 6, as the reference's unset means its zlib at 6 (bgzf_compress.c:54,:102); a name of
+ * the reference's table (zlib, libdeflate, igzip, ...) or an unknown one is served by the hip coder at the level
+ * the reference would have used for it, with one line on stderr -- a BGZF_METHOD=libdeflate6 left in the
+ * environment keeps writing.  There is no CPU codec behind any name.  Calls from concurrent htslib worker threads
+ * are micro-batched into latency-mode launches on pinned memory: a batch closes when every caller inside the hook
+ * has joined, when nobody has joined for HIPDEFLATE_LINGER_US (8), or after HIPDEFLATE_BATCH_US (60); at most
+ * HIPDEFLATE_INFLIGHT (2) batches are on a device at once; batch contexts are spread over the device list. */
 int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
 
 /* device self-test of the wave primitives (scan, CRC folding); 0 = pass */

@@ -506,3 +506,26 @@ void hipdeflate_unpipe_close(hipdeflate_unpipe *p)
 	}
 	free(p);
 }
+
+/* the device list of the real library: the stub answers for HIPDEFLATE_DEVICES-many "devices" (default one), all the
+ * same CPU code -- enough for hd7bgzf -g N to deal its batches round robin under the sanitizers */
+static int stub_ndev(void)
+{
+	const char *s = getenv("HIPDEFLATE_DEVICES");
+	int n = 1;
+	for (; s && *s; s++)
+		n += *s == ',';
+	return n;
+}
+static int g_stub_ndev;
+int hipdeflate_device_count(void) { return g_stub_ndev ? g_stub_ndev : stub_ndev(); }
+int hipdeflate_init_devices(const int *devices, int n) { (void)devices; g_stub_ndev = n; return n >= 1 ? 0 : HD_E_ARG; }
+int hipdeflate_use_device(int index) { return index >= 0 && index < hipdeflate_device_count() ? 0 : HD_E_ARG; }
+hipdeflate_pipe *hipdeflate_pipe_open_on(int index, int level, int frame, uint32_t block_bytes, uint32_t blocks_per_batch, int depth)
+{
+	return index >= 0 && index < hipdeflate_device_count() ? hipdeflate_pipe_open(level, frame, block_bytes, blocks_per_batch, depth) : NULL;
+}
+hipdeflate_unpipe *hipdeflate_unpipe_open_on(int index, uint32_t max_members, size_t in_cap, size_t out_cap, int depth)
+{
+	return index >= 0 && index < hipdeflate_device_count() ? hipdeflate_unpipe_open(max_members, in_cap, out_cap, depth) : NULL;
+}

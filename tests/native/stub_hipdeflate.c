@@ -166,3 +166,10 @@ int hip_deflate_flush(unsigned char *dest, size_t *destLen, const unsigned char 
 	*destLen += 5;
 	return 0;
 }
+
+/* the device list of the real library: the stub has one "device" */
+int hipdeflate_device_count(void) { return 1; }
+hipdeflate_lat *hipdeflate_lat_open_on(int index, int level, int frame, uint32_t max_blocks, uint32_t max_block_bytes)
+{
+	return index == 0 ? hipdeflate_lat_open(level, frame, max_blocks, max_block_bytes) : NULL;
+}
