@@ -10,6 +10,7 @@
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <unistd.h>
+#include <sched.h>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -1671,8 +1672,14 @@ std::mutex g_inf_mu;
 std::condition_variable g_inf_free;
 int g_inf_open = -1;                                          // the collecting batch
 int g_inf_active = 0, g_inf_running = 0;                      // callers inside inflate_one / in batches that are closed
-long g_inf_window_ns = 100000, g_inf_linger_ns = 15000;       // HIPDEFLATE_INFLATE_WINDOW_US / _LINGER_US
+int g_inf_inflight = 0, g_inf_max_inflight = 2;               // closed batches not yet done / HIPDEFLATE_INFLATE_INFLIGHT
+long g_inf_window_ns = 400000, g_inf_linger_ns = 60000;       // HIPDEFLATE_INFLATE_WINDOW_US / _LINGER_US
 int g_inf_failed = 0;
+// A batch is ~1.5 ms on the device whatever it holds (one wavefront per stream, the chip is empty), and the device runs two
+// launches side by side but hardly a third (measured on the latency contexts, DESIGN "Hook": 152 us alone, 173 us each for
+// two, 266+ for three): so at most two batches are out, and while they are the collecting batch stays open and grows.
+// Sixteen callers settle into two groups of eight that alternate; without the cap they drifted apart into batches of one
+// to four that queued behind one another (3.0 ms per call where the kernel takes 1.55).
 
 static void infb_sleep(uint32_t *w, uint32_t seen) { syscall(SYS_futex, w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
 static void infb_wake_all(uint32_t *w) { syscall(SYS_futex, w, FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0); }
@@ -1691,6 +1698,9 @@ static int infb_create(InfBatch &b, int k)
 			g_inf_window_ns = atol(w) * 1000;
 		if (const char *w = getenv("HIPDEFLATE_INFLATE_LINGER_US"))
 			g_inf_linger_ns = atol(w) * 1000;
+		if (const char *w = getenv("HIPDEFLATE_INFLATE_INFLIGHT"))
+			if (atoi(w) >= 1)
+				g_inf_max_inflight = atoi(w);
 		return true;
 	}();
 	(void)env_once;
@@ -1776,6 +1786,7 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 			// it cannot take this stream: closed as it stands (its leader finds it so), a new one is opened
 			__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
 			g_inf_running += b->n;
+			g_inf_inflight++;
 			g_inf_open = -1;
 		}
 		int k;
@@ -1812,9 +1823,10 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	b->out_used += out_need;
 	__atomic_store_n(&b->n, idx + 1, __ATOMIC_RELAXED);
 	// everybody who could join has: the callers inside that are not in a closed batch are all here (or the batch is full)
-	if (b->n >= (int)INFB_SLOTS || b->n >= g_inf_active - g_inf_running) {
+	if (b->n >= (int)INFB_SLOTS || (b->n >= g_inf_active - g_inf_running && g_inf_inflight < g_inf_max_inflight)) {
 		__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
 		g_inf_running += b->n;
+		g_inf_inflight++;
 		g_inf_open = -1;
 	}
 	lk.unlock();
@@ -1826,10 +1838,10 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	if (leader) {
 		// others join while the window is open; whoever completes the batch (above) closes it, or the leader does when
 		// nobody has joined for the linger time although callers are missing, or when the window is over
-		if (g_inf_window_ns > 0) {
-			const int64_t t0 = infb_now(), deadline = t0 + g_inf_window_ns;
+		{
+			const int64_t t0 = infb_now(), deadline = t0 + g_inf_window_ns, hard = t0 + 20000000;
 			int64_t t_last = t0;
-			int seen = 1;
+			int seen = 1, spins = 0;
 			while (__atomic_load_n(&b->state, __ATOMIC_ACQUIRE) == 1) {
 				const int64_t t = infb_now();
 				const int now_n = __atomic_load_n(&b->n, __ATOMIC_RELAXED);
@@ -1837,15 +1849,23 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 					seen = now_n;
 					t_last = t;
 				}
-				if (t >= deadline || t - t_last >= g_inf_linger_ns)
+				const bool slot = __atomic_load_n(&g_inf_inflight, __ATOMIC_RELAXED) < g_inf_max_inflight;
+				// complete (every caller that is inside and not on the device has joined), or nobody came for the linger
+				// time, or the window is over -- and a launch slot is free (20 ms at most, should a batch hang)
+				const bool complete = now_n >= __atomic_load_n(&g_inf_active, __ATOMIC_RELAXED) - __atomic_load_n(&g_inf_running, __ATOMIC_RELAXED);
+				if (((complete || t >= deadline || t - t_last >= g_inf_linger_ns) && slot) || t >= hard)
 					break;
-				__builtin_ia32_pause();
+				if (!slot && (++spins & 15) == 0)
+					sched_yield();                       // two batches are out for a millisecond yet: leave the CPU to their callers
+				else
+					__builtin_ia32_pause();
 			}
 		}
 		lk.lock();
 		if (__atomic_load_n(&b->state, __ATOMIC_RELAXED) == 1) {
 			__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
 			g_inf_running += b->n;
+			g_inf_inflight++;
 			g_inf_open = -1;
 		}
 		const int n = b->n;
@@ -1879,6 +1899,7 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 		b->rc = rc;
 		lk.lock();
 		g_inf_running -= n;
+		g_inf_inflight--;
 		lk.unlock();
 		(void)__atomic_exchange_n(&b->state, 3u, __ATOMIC_SEQ_CST);   /* (a full fence: the load of `sleepers` must not pass it) */
 		if (__atomic_load_n(&b->sleepers, __ATOMIC_SEQ_CST))

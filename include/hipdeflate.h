@@ -100,8 +100,9 @@ int hip_deflate(unsigned char *dest, size_t *destLen,
  * (lib/zlibutil.c:194-204).  Re-entrant and thread-safe, and built for the way the reference calls it -- a thread
  * per block, -@ N at once (applet/7bgzf.c:330-345): concurrent calls are coalesced into one launch (one wavefront
  * per stream, the whole window in LDS) on pinned batch memory, no process-wide lock; the batches are spread over the
- * device list.  HIPDEFLATE_INFLATE_WINDOW_US (100) / _LINGER_US (15) bound how long a batch's first caller waits
- * for the others. */
+ * device list.  At most HIPDEFLATE_INFLATE_INFLIGHT (2) batches are on the device, the collecting one grows meanwhile;
+ * HIPDEFLATE_INFLATE_WINDOW_US (400) / _LINGER_US (60) bound how long a batch's first caller waits for the others
+ * once a launch slot is free (a lone caller never waits). */
 int hip_inflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen);
 

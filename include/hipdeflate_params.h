@@ -117,6 +117,35 @@
 #define HD_TABLE_58(win_bits, hash_bits)      ((win_bits) == 13 && (hash_bits) == 12)
 #define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? (3u << ((hash_bits) - 2)) : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
 
+/* WORKGROUP LEVELS (6..9 in the throughput form; the latency form of these levels keeps the two-way tables above): ONE
+ * WORKGROUP of HD_WG_WAVES wavefronts per block shares one window and one table in LDS (hd_deflate_wg.hpp) -- the role of
+ * hc_matchfinder (lib/libdeflate/hc_matchfinder.h:183-338) and of deflate_compress_lazy_generic (deflate_compress.c:2606-2809)
+ * with what a whole CU's LDS holds instead of one wavefront's share of it:
+ *   window   DEFLATE's 32 KiB, in a 64 KiB ring (positions are ring offsets; table entries (p + 1) mod 2^16, 0 = empty);
+ *   table    HD_WG_BUCKETS buckets of HD_WG_WAYS positions, newest first, six-byte key (HD_HASH_SLOT6).  A step's lanes read
+ *            their buckets as the steps before left them; of the lanes of a step that share a bucket the highest stores
+ *            { itself, the three newest before the step };
+ *   verify   every candidate -- the byte before the position, if the lane has one in its step (runs), then the four of the
+ *            bucket -- over HD_WG_VCAP bytes; the longest wins, the nearer on a tie; a match of HD_WG_VCAP bytes is extended to
+ *            its full length (<= 258); minimum length HD_WG_MIN_LEN;
+ *   lazy     libdeflate's rule (deflate_compress.c:2723-2726) on the lane to the right, with the lengths capped at HD_WG_VCAP:
+ *            a match steps aside when 4 (len' - len) + log2(dist) - log2(dist') > 2 for its neighbour's match;
+ *   blocks   a DEFLATE block ends at a step boundary once it holds HD_DYN_BLOCK_TOKENS tokens, or when the token mix has
+ *            shifted: libdeflate's observation test (deflate_compress.c:2141-2218) over three classes -- literal, match
+ *            below 9 bytes, longer match --, checked every HD_WG_SPLIT_OBS tokens, blocks of at least HD_WG_SPLIT_MIN bytes;
+ *   long blocks (MiGz members) are ONE stream with the window sliding through them: no segments.
+ * tools/mf_explore.c is the CPU model this geometry was chosen with. */
+#define HD_WG_LEVEL        6
+#define HD_WG_BUCKETS      8192u
+#define HD_WG_WAYS         4
+#define HD_WG_WINDOW       32768u
+#define HD_WG_RING         65536u
+#define HD_WG_VCAP         16u
+#define HD_WG_MIN_LEN      5u
+#define HD_WG_SPLIT_OBS    512u
+#define HD_WG_SPLIT_MIN    5000u
+#define HD_WG_WAVES        16
+
 /* Besides the hash table, which only knows earlier steps, a lane takes the lane just before it as its
  * candidate when that one holds the same four bytes (a run of five equal bytes): the latest occurrence,
  * and on DNA-like data, whose quality strings are full of runs, worth 9 % of the output (0.454 -> 0.415

@@ -726,6 +726,178 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	return ret;
 }
 
+
+/* ---- levels >= HD_WG_LEVEL, throughput form: the workgroup parse (include/hipdeflate_params.h "WORKGROUP LEVELS") ------
+ * The serial statement of hd_deflate_wg.hpp.  Roles: hc_matchfinder_longest_match (lib/libdeflate/hc_matchfinder.h:183-338)
+ * -> the bucket's four positions + the run candidate, verified over HD_WG_VCAP bytes; the lazy rule and the token choice of
+ * deflate_compress_lazy_generic (deflate_compress.c:2606-2809) -> steps 5..7 below; should_end_block (:2141-2218) -> split. */
+typedef struct {
+	uint32_t obs[3], nobs[3], n, nn;        /* literal / match of < 9 bytes / longer match: merged, and since the last check */
+} wg_split_t;
+
+static int wg_split_check(wg_split_t *s, uint32_t block_len)
+{
+	if (s->n > 0) {
+		/* sum of absolute differences of the class probabilities, times n * nn (do_end_block_check,
+		 * deflate_compress.c:2143-2196), in 32-bit arithmetic: counts are below 2^17, nn below 2^10 */
+		uint32_t total = 0;
+		for (int i = 0; i < 3; i++) {
+			const uint32_t e = s->obs[i] * s->nn, a = s->nobs[i] * s->n;
+			total += a > e ? a - e : e - a;
+		}
+		const uint32_t items = s->n + s->nn;
+		uint32_t cutoff = s->nn * 200u / 512u * s->n;
+		if (block_len < 10000 && items < 8192)
+			cutoff += (cutoff >> 13) * (8192u - items);
+		if (total + (block_len / 4096u) * s->n >= cutoff)
+			return 1;
+	}
+	for (int i = 0; i < 3; i++) {
+		s->obs[i] += s->nobs[i];
+		s->nobs[i] = 0;
+	}
+	s->n += s->nn;
+	s->nn = 0;
+	return 0;
+}
+
+static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n, int flush)
+{
+	const size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
+	const size_t stored = HD_STORED_SIZE(n);
+	const size_t limit = cap < stored - 1 ? cap : stored - 1;
+	uint8_t *tmp = calloc(1, limit + 64 + 8);
+	uint16_t *bk = calloc((size_t)HD_WG_BUCKETS * HD_WG_WAYS, 2);
+	dynblk_t b;
+	bw_t w = { tmp, 0 };
+	wg_split_t sp;
+	int alive = 1;
+	uint32_t clen[HD_WAVE], flen[HD_WAVE], dist[HD_WAVE];
+	uint16_t pre[HD_WAVE][HD_WG_WAYS];
+	size_t E = 0, block_begin = 0;
+
+	memset(&b, 0, sizeof(b));
+	memset(&sp, 0, sizeof(sp));
+	b.tok = malloc((n + 64) * 4);
+	for (size_t S = 0; S < n && alive; S += HD_WAVE) {
+		const unsigned lanes = n - S < HD_WAVE ? (unsigned)(n - S) : HD_WAVE;
+		/* 1. every lane with six bytes left reads its bucket as the steps before left it */
+		for (unsigned l = 0; l < lanes; l++) {
+			const size_t p = S + l;
+			memset(pre[l], 0, sizeof(pre[l]));
+			if (p + HD_LAZY_KEY_BYTES <= n)
+				memcpy(pre[l], bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), HD_WG_BUCKETS) * HD_WG_WAYS,
+				       sizeof(pre[l]));
+		}
+		/* 2. ... and stores { itself, the three newest before the step }: in lane order, so the highest lane's store stays */
+		for (unsigned l = 0; l < lanes; l++) {
+			const size_t p = S + l;
+			if (p + HD_LAZY_KEY_BYTES > n)
+				continue;
+			uint16_t *e = bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), HD_WG_BUCKETS) * HD_WG_WAYS;
+			e[0] = (uint16_t)(p + 1);
+			for (unsigned k = 1; k < HD_WG_WAYS; k++)
+				e[k] = pre[l][k - 1];
+		}
+		/* 3. verify: the byte before (runs; only inside the step), then the bucket, newest first; longest wins, nearest on a tie */
+		for (unsigned l = 0; l < lanes; l++) {
+			const size_t p = S + l;
+			const unsigned room = n - p < HD_WG_VCAP ? (unsigned)(n - p) : HD_WG_VCAP;
+			unsigned best = 0;
+			uint32_t bd = 0;
+			clen[l] = flen[l] = dist[l] = 0;
+			if (p + HD_LAZY_KEY_BYTES > n)
+				continue;
+			for (unsigned k = 0; k <= HD_WG_WAYS; k++) {
+				uint32_t back;
+				if (k == 0) {
+					if (l == 0)
+						continue;
+					back = 1;
+				} else {
+					const uint32_t e = pre[l][k - 1];
+					back = (uint32_t)(p + 1 - e) & 0xffffu;
+					if (e == 0 || back == 0 || back > HD_WG_WINDOW || back > p)
+						continue;
+				}
+				unsigned m = 0;
+				while (m < room && in[p + m] == in[p - back + m])
+					m++;
+				if (m > best) {
+					best = m;
+					bd = back;
+				}
+			}
+			if (best < HD_WG_MIN_LEN)
+				continue;
+			clen[l] = best;
+			dist[l] = bd;
+			/* 4. a match of the whole verified span is extended to its full length */
+			unsigned len = best;
+			if (best == HD_WG_VCAP) {
+				const unsigned maxlen = n - p < HD_MAX_MATCH ? (unsigned)(n - p) : HD_MAX_MATCH;
+				while (len < maxlen && in[p + len] == in[p + len - bd])
+					len++;
+			}
+			flen[l] = len;
+		}
+		/* 5. the lazy rule on the right-hand neighbour, 6. the path from E, 7. tokens */
+		for (unsigned l = 0; l < lanes; l++) {
+			const size_t p = S + l;
+			if (p < E)
+				continue;
+			int take = clen[l] != 0;
+			if (take && l + 1 < lanes && clen[l + 1] >= clen[l] && clen[l + 1] &&
+			    4 * ((int)clen[l + 1] - (int)clen[l]) + ((int)ilog2(dist[l]) - (int)ilog2(dist[l + 1])) > 2)
+				take = 0;
+			if (take) {
+				unsigned sym, eb, ev;
+				b.tok[b.ntok++] = HD_TOKEN_MATCH | ((uint32_t)(flen[l] - 3) << 16) | (dist[l] - 1);
+				len_slot(flen[l], &sym, &eb, &ev);
+				b.lf[sym]++;
+				off_slot(dist[l], &sym, &eb, &ev);
+				b.df[sym]++;
+				E = p + flen[l];
+				sp.nobs[flen[l] >= 9 ? 2 : 1]++;
+			} else {
+				b.tok[b.ntok++] = in[p];
+				b.lf[in[p]]++;
+				E = p + 1;
+				sp.nobs[0]++;
+			}
+			sp.nn++;
+		}
+		/* a DEFLATE block may end behind any step but the last */
+		const size_t here = S + lanes;
+		if (here < n) {
+			int end = b.ntok >= HD_DYN_BLOCK_TOKENS;
+			if (!end && sp.nn >= HD_WG_SPLIT_OBS && here - block_begin >= HD_WG_SPLIT_MIN && n - here >= HD_WG_SPLIT_MIN)
+				end = wg_split_check(&sp, (uint32_t)(here - block_begin));
+			if (end) {
+				alive = flush_dyn_block(&w, &b, 0, 8 * (uint64_t)limit);
+				memset(&sp, 0, sizeof(sp));
+				block_begin = here;
+			}
+		}
+	}
+	if (alive)
+		alive = flush_dyn_block(&w, &b, !flush, 8 * (uint64_t)limit);
+	int ret;
+	if (alive) {
+		if (flush)
+			put_flush_suffix(&w);
+		*destLen = (size_t)((w.bitpos + 7) >> 3);
+		memcpy(dest, tmp, *destLen);
+		ret = 0;
+	} else {
+		ret = write_stored(dest, destLen, in, n, flush);
+	}
+	free(b.tok);
+	free(bk);
+	free(tmp);
+	return ret;
+}
+
 /* test hook: the code lengths build_code() gives a frequency vector (tests/test_oracle_golden.py checks
  * Kraft equality and the length limit on adversarial distributions) */
 void hdo_build_lengths(const uint32_t *freq, unsigned nsyms, unsigned maxbits, uint8_t *lens_out)
@@ -775,6 +947,9 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level >= 1 && lat && sourceLen > HD_LAT_SEG_BYTES(level) &&
 	    *destLen >= HD_SEGN_WORST((uint64_t)sourceLen, HD_LAT_SEG_BYTES(level), flush))
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_LAT_SEG_BYTES(level));
+	if (level >= HD_WG_LEVEL && !part)      /* the workgroup levels take a block of any length as one stream (a latency
+	                                         * segment parsed in parts keeps the two-way tables of its part wavefronts) */
+		return deflate_wg(dest, destLen, source, sourceLen, flush);
 	if (level >= 1 && sourceLen > HD_SEG_LIMIT)
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_SEG_BYTES);
 	if (level <= 0)

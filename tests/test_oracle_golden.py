@@ -266,9 +266,9 @@ def test_twin_flush_form_is_full_flush_of_twin(level):
         assert r4 != 0, name
 
 
-@pytest.mark.parametrize("level", [1, 2, 6])
+@pytest.mark.parametrize("level", [1, 2, 5])
 def test_twin_codes_long_blocks_in_flushed_segments(level):
-    """Levels >= 1, blocks longer than HD_SEG_LIMIT (320 KiB): independent 0xff00-byte segments, each the
+    """Levels 1..5, blocks longer than HD_SEG_LIMIT (320 KiB): independent 0xff00-byte segments, each the
     twin's own flush form, 03 00 behind the last (include/hipdeflate_params.h).  One byte less and the block
     is coded whole.  The room must cover every segment's worst case; zlib reads the result."""
     import zlib
@@ -291,6 +291,33 @@ def test_twin_codes_long_blocks_in_flushed_segments(level):
     assert r == 0 and zlib.decompress(z, -15) == whole and not z.endswith(b"\x00\x00\xff\xff\x03\x00")
     r, z = hdtest.oracle_twin(data[:limit + 1], level)
     assert r == 0 and zlib.decompress(z, -15) == data[:limit + 1] and z.endswith(b"\x00\x00\xff\xff\x03\x00")
+
+
+@pytest.mark.parametrize("level", [6, 9])
+def test_twin_workgroup_levels_take_long_blocks_as_one_stream(level):
+    """Levels >= 6 (include/hipdeflate_params.h "WORKGROUP LEVELS"): a block of any length is ONE stream with the 32 KiB
+    window sliding through it -- no flushed segments, matches across every 0xff00 boundary, more than one DEFLATE block
+    (the split test fires where the data changes kind) --, smaller than the segments' sum; the room rule is the stored
+    form's, as for a short block."""
+    import zlib
+    s = hdtest.synth()
+    data = bytes(s.text_like(400000, seed=91)) + bytes(s.random_bytes(70000)) + bytes(s.fastq_like(300000, seed=92))
+    r, z = hdtest.oracle_twin(data, level)
+    assert r == 0 and zlib.decompress(z, -15) == data
+    assert b"\x00\x00\xff\xff\x03\x00" != z[-6:]
+    segs = sum(len(hdtest.oracle_twin_flush(data[o:o + 0xff00], 5)[1]) for o in range(0, len(data), 0xff00))
+    assert len(z) < 0.97 * segs
+    # DEFLATE blocks of the stream (zlib's Z_BLOCK walk is not in the python module: count BFINAL = 0 dynamic headers by
+    # re-inflating with the oracle, which reports the consumed bits -- here simply: the noise in the middle must not have
+    # been coded with the text's code, i.e. the stream is shorter than one-code-for-all would be)
+    r, zf = hdtest.oracle_twin_flush(data, level)
+    assert r == 0 and zlib.decompressobj(-15).decompress(zf + b"\x03\x00") == data
+    assert hdtest.oracle_twin(data, level, cap=len(z))[0] == 0
+    assert hdtest.oracle_twin(data, level, cap=len(z) - 1)[0] != 0
+    # incompressible: the stored form, which needs its 5 bytes per 65535
+    noise = bytes(s.random_bytes(200000))
+    r, zn = hdtest.oracle_twin(noise, level)
+    assert r == 0 and len(zn) == len(noise) + 5 * 4 and zlib.decompress(zn, -15) == noise
 
 
 def test_zlib_gzip_frames_match_reference_wrappers():
@@ -380,13 +407,15 @@ def test_twin_ratio_envelope(level, refkey):
         assert got <= hdtest.RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))
 
 
-@pytest.mark.parametrize("level,bound", [(1, 1.02), (2, 1.035), (6, 1.033)])
+@pytest.mark.parametrize("level,bound", [(1, 1.02), (2, 1.035), (6, 1.065)])
 def test_twin_latency_form_ratio_envelope(level, bound):
     """Latency mode (the hook's and the per-block codecs' form: 4080 / 8160-byte segments, four parse parts per segment at
     the dynamic levels) against the ordinary form of the same level, on the 0xff00-byte FASTQ-like set: with every segment
     and part primed by the 512 bytes before it (HD_LAT_PRIME) the segments cost 1.2 % at level 1, 2.5 % at level 2 (eight
     Huffman headers per block instead of one) and 2.4 % at level 6; with unprimed segments the 16 GiB runs measured 6.4 %, 4.5 %
-    and 3.7 % (round 3).  A change that drops the priming, or parses parts cold, fails here."""
+    and 3.7 % (round 3).  A change that drops the priming, or parses parts cold, fails here.  (Round 4: the ordinary form of
+    level 6 is the workgroup parse and 3.4 % smaller than it was; the latency form is what it was -- 2 KiB parts cannot use a
+    32 KiB window -- so the same bytes now read 5.9 % against it.)"""
     for name, e, data in hdtest.ratio_sets():
         if name != "fastq/65280":
             continue
