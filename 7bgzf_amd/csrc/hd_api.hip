@@ -19,6 +19,7 @@
 #include "../../include/hipdeflate.h"
 #include "hd_deflate_static.hpp"
 #include "hd_deflate_dynamic.hpp"
+#include "hd_deflate_wg.hpp"
 #include "hd_inflate.hpp"
 #include "hd_compact.hpp"
 #include "hd_segment.hpp"
@@ -487,7 +488,7 @@ static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level, bool lat
 {
 	if (level >= 1 && latency && cap > HD_LAT_SEG_BYTES(level))
 		return hd::segmented_scratch_bytes(nblocks, cap, level, HD_LAT_SEG_BYTES(level));
-	if (level >= 1 && cap > HD_SEG_LIMIT)
+	if (level >= 1 && level < HD_WG_LEVEL && cap > HD_SEG_LIMIT)       // (the workgroup levels take a block of any length whole)
 		return hd::segmented_scratch_bytes(nblocks, cap, level);
 	return level < 2 ? 0 : hd::dynamic_scratch_bytes(nblocks, cap, level);
 }
@@ -544,7 +545,7 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	// mode): such blocks are coded in segments, the ordinary coding leaves them alone
 	const uint32_t seg_lim = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	a.seg_bytes = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
-	a.seg_limit = (level >= 1 && a.split_max > seg_lim) ? seg_lim : 0;
+	a.seg_limit = (level >= 1 && (latency || level < HD_WG_LEVEL) && a.split_max > seg_lim) ? seg_lim : 0;
 	a.hint = 0;
 	a.host_seg_off = nullptr;
 	a.host_seg_len = nullptr;
@@ -1365,7 +1366,7 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 		c->slot = 65536;
 	const uint32_t seg_lim = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	c->seg = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
-	c->seg_limit = (level >= 1 && c->slot > seg_lim) ? seg_lim : 0;
+	c->seg_limit = (level >= 1 && (c->latency || level < HD_WG_LEVEL) && c->slot > seg_lim) ? seg_lim : 0;
 	c->S = c->seg_limit ? hd::seg_slots_per_block(c->slot, c->seg) : 0;
 	// [ in_off u64 | in_len, out_len, crc, status u32 | seg_off u64 [max_blocks * S] | seg_len u32 [max_blocks * S] ]
 	c->meta_seg = (((size_t)max_blocks * (8 + 4 + 4 + 4 + 4)) + 15) & ~(size_t)15;

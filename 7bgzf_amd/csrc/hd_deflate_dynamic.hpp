@@ -26,7 +26,35 @@
 
 namespace hd {
 
+constexpr uint64_t SPLIT_SCRATCH_BUDGET_WG = (uint64_t)12672 << 20;
 constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
+
+// the records of the workgroup parse (levels >= HD_WG_LEVEL, hd_deflate_wg.hpp): one token per byte at most (no other path
+// stands behind that one), a DEFLATE block per HD_WG_SPLIT_MIN bytes or HD_DYN_BLOCK_TOKENS tokens at most
+__host__ __device__ inline SplitLayout wg_layout(uint32_t max_block)
+{
+	SplitLayout l;
+	l.cap_tok = (max_block + 64 + 15) & ~15u;
+	l.max_db = max_block / HD_WG_SPLIT_MIN + l.cap_tok / HD_DYN_BLOCK_TOKENS + 3;
+	l.off_rec = (uint64_t)l.cap_tok * 4;
+	l.off_ntok = l.off_rec + 16;
+	l.off_hist = (l.off_ntok + (uint64_t)l.max_db * 4 + 15) & ~(uint64_t)15;
+	l.bytes = l.off_hist + (uint64_t)l.max_db * 320 * 4;
+	return l;
+}
+inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
+{
+	uint64_t sub = SPLIT_SCRATCH_BUDGET_WG / wg_layout(split_max).bytes;
+	if (sub > 65536)
+		sub = 65536;
+	if (sub < 1)
+		sub = 1;
+	return sub < nblocks ? (uint32_t)sub : nblocks;
+}
+inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max)
+{
+	return (((uint64_t)nblocks * 4 + 15) & ~(uint64_t)15) + (uint64_t)wg_sub_batch(nblocks, split_max) * wg_layout(split_max).bytes + 16;
+}
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
 {
@@ -102,6 +130,8 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int 
 {
 	if (level < 2)
 		return 0;
+	if (level >= HD_WG_LEVEL && !parts)
+		return wg_scratch_bytes(nblocks, split_max);
 	if (parts)
 		return fused_scratch_bytes(nblocks, level) + (uint64_t)nblocks * 4 +
 		       (uint64_t)part_sub_batch(nblocks, parts) * parts * part_layout().bytes + 16;
@@ -1094,12 +1124,16 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				crcv = uniform(L.misc[4]);              // (the second wavefront's, behind the barriers of flush_block)
 			} else {
 			// the parse has been done: one flush per recorded DEFLATE block
-			const SplitLayout lay = split_layout(a.split_max);
-			const uint8_t *rec = split_block(a.scratch, a.split_max, bi);
+			const SplitLayout lay = a.wg ? wg_layout(a.split_max) : split_layout(a.split_max);
+			const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
 			const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
 			const uint32_t *nt = (const uint32_t *)(rec + lay.off_ntok);
-			const uint32_t ndb = m[0];
+			uint32_t ndb = m[0];
 			crcv = m[1];
+			if (ndb == 0xffffffffu) {                    // (the workgroup parse gave the block up: stored)
+				alive = false;
+				ndb = 0;
+			}
 			uint32_t t0 = 0;
 			for (uint32_t k = 0; k < ndb && alive; k++) {
 				const uint32_t *h = (const uint32_t *)(rec + lay.off_hist) + k * 320;
@@ -1188,8 +1222,14 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA, DEEP>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }
 
+void launch_wg(const DeflateArgs &a, hipStream_t st);       // hd_deflate_wg.hpp
+
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
+	if (level >= HD_WG_LEVEL && !a.parts) {              // the workgroup levels: one workgroup per block, then the emit-only kernel
+		launch_wg(a, st);
+		return 0;
+	}
 	if (level == 2)
 		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	else if (level == 3)
@@ -1198,14 +1238,8 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
 	else if (level < HD_DEEP_LEVEL)
 		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 0>(a, level, st);
-	else if (level <= 6)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
-	else if (level <= 7)
-		launch_level<HD_L7_WIN_BITS, HD_L7_HASH_BITS, HD_L7_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
-	else if (level == 8)
-		launch_level<HD_L8_WIN_BITS, HD_L8_HASH_BITS, HD_L8_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
-	else
-		launch_level<HD_L9_WIN_BITS, HD_L9_HASH_BITS, HD_L9_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, level, st);
+	else            // levels 6..9, latency segments parsed in parts: the two-way tables in the 8 KiB geometry (a part is 2 KiB)
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, 6, st);
 	return 0;
 }
 

@@ -72,6 +72,9 @@ struct DeflateArgs {
 	// instead of going through hipStreamSynchronize.  done_count: a device word the workgroups count themselves off on
 	uint32_t *done_flag = nullptr, *done_count = nullptr;
 	uint32_t done_epoch = 0;
+	// != 0: the records in `scratch` are the workgroup parse's (hd_deflate_wg.hpp wg_layout: a token per byte, a DEFLATE
+	// block per HD_WG_SPLIT_MIN bytes); the emit-only kernel reads them so
+	uint32_t wg = 0;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)

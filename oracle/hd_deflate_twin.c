@@ -965,17 +965,10 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level == 4)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
 				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0, part, prime);
-	if (level <= 6)         /* level 5: the one-way table; level 6: the same geometry with the lazy levels' two-way buckets */
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-				       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part, prime);
-	if (level <= 7)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L7_WIN_BITS, HD_L7_HASH_BITS,
-				       HD_L7_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part, prime);
-	if (level == 8)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L8_WIN_BITS, HD_L8_HASH_BITS,
-				       HD_L8_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part, prime);
-	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L9_WIN_BITS, HD_L9_HASH_BITS,
-			       HD_L9_MIN_LEN, 1, HD_INTRA_DIST, flush, 1, part, prime);
+	/* level 5: the one-way table; levels 6..9 (latency segments parsed in parts; every other form of these levels is the
+	 * workgroup parse above): the same geometry with the two-way buckets */
+	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
+			       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part, prime);
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,
