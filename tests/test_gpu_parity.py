@@ -404,7 +404,9 @@ def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, l
         assert (st[i] == 0) == (r == 0), i
         if r == 0:
             assert members[i] == twin
-    assert st[0] != 0 and st[3] == 0
+    # (the workgroup levels code a long block as ONE stream, not as segments: the rule above does not bind them -- the
+    # block goes through whenever its stream fits, as the twin's does)
+    assert (st[0] != 0 or level >= pkg.WG_LEVEL) and st[3] == 0
     r, z = pkg.hip_deflate(big, level)                   # one block per call: the latency form
     assert r == 0 and z == hdtest.codec_twin(big, level)[1]
     outs, dcrc, dst = pkg.batch_inflate([z], [len(big)])
