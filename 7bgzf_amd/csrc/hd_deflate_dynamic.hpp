@@ -29,17 +29,18 @@ namespace hd {
 constexpr uint64_t SPLIT_SCRATCH_BUDGET_WG = (uint64_t)12672 << 20;
 constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 
-// the records of the workgroup parse (levels >= HD_WG_LEVEL, hd_deflate_wg.hpp): one token per byte at most (no other path
-// stands behind that one), a DEFLATE block per HD_WG_SPLIT_MIN bytes or HD_DYN_BLOCK_TOKENS tokens at most
+// the records of the workgroup parse (levels >= HD_WG_LEVEL, hd_deflate_wg.hpp): piece k's tokens from token k * HD_WG_CUT on
+// (one per byte at most), then { status, CRC-32 }, then one { tokens, literals, short matches, long matches } per piece
+//   [ tokens: cap_tok x u32 | status, crc, pad, pad | piece[max_db] x uint4 ]
 __host__ __device__ inline SplitLayout wg_layout(uint32_t max_block)
 {
 	SplitLayout l;
-	l.cap_tok = (max_block + 64 + 15) & ~15u;
-	l.max_db = max_block / HD_WG_SPLIT_MIN + l.cap_tok / HD_DYN_BLOCK_TOKENS + 3;
+	l.max_db = (max_block + HD_WG_CUT - 1) / HD_WG_CUT + 1;                // pieces
+	l.cap_tok = l.max_db * HD_WG_CUT;
 	l.off_rec = (uint64_t)l.cap_tok * 4;
-	l.off_ntok = l.off_rec + 16;
-	l.off_hist = (l.off_ntok + (uint64_t)l.max_db * 4 + 15) & ~(uint64_t)15;
-	l.bytes = l.off_hist + (uint64_t)l.max_db * 320 * 4;
+	l.off_ntok = l.off_rec + 16;                                           // the pieces' records
+	l.off_hist = l.off_ntok + (uint64_t)l.max_db * 16;
+	l.bytes = l.off_hist;
 	return l;
 }
 inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
@@ -658,6 +659,60 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 			return q;
 		};
 
+		// ---- the workgroup parse's records (a.wg; hd_deflate_wg.hpp): the DEFLATE block being closed is the pieces
+		// [wg_k0, wg_k1) of the block; piece k's tokens start at token k * HD_WG_CUT of the record ------------------------
+		uint32_t wg_k0 = 0, wg_k1 = 0, wg_base = 0xffffff00u, wg_np = 0;
+		const uint4 *wg_pieces = nullptr;
+		uint4 wg_pv = make_uint4(0, 0, 0, 0);            // lane i: the record of piece wg_base + i
+		auto wg_piece_load = [&](uint32_t k) {
+			if (k - wg_base >= 64) {
+				wg_base = k & ~63u;
+				wg_pv = wg_base + lane < wg_np ? wg_pieces[wg_base + lane] : make_uint4(0, 0, 0, 0);
+			}
+		};
+		auto wg_piece_tokens = [&](uint32_t k) -> uint32_t {
+			wg_piece_load(k);
+			return readlane(wg_pv.x, k - wg_base);
+		};
+		// f(token of lane i, tokens in the group) for every group of up to 64 tokens of the DEFLATE block, in order; the
+		// loads run a batch of eight groups ahead of their use (see the note at the emit-only kernel's token loop)
+		auto wg_for_tokens = [&](auto &&f) {
+			constexpr uint32_t PF = 8;
+			uint32_t k = wg_k0, base = 0, c = wg_k0 < wg_k1 ? wg_piece_tokens(wg_k0) : 0u;
+			uint32_t cur[PF], nxt[PF], ncur[PF], nnxt[PF];
+			auto fetch = [&](uint32_t &v, uint32_t &nv) {
+				nv = 0;
+				v = 0;
+				if (k < wg_k1) {
+					nv = c - base < 64 ? c - base : 64;
+					v = lane < nv ? tok[k * HD_WG_CUT + base + lane] : 0u;
+					base += 64;
+					if (base >= c) {
+						k++;
+						base = 0;
+						c = k < wg_k1 ? wg_piece_tokens(k) : 0u;
+					}
+				}
+			};
+#pragma unroll
+			for (uint32_t j = 0; j < PF; j++)
+				fetch(nxt[j], nnxt[j]);
+			while (nnxt[0]) {
+#pragma unroll
+				for (uint32_t j = 0; j < PF; j++) {
+					cur[j] = nxt[j];
+					ncur[j] = nnxt[j];
+				}
+#pragma unroll
+				for (uint32_t j = 0; j < PF; j++)
+					fetch(nxt[j], nnxt[j]);
+#pragma unroll
+				for (uint32_t j = 0; j < PF; j++)
+					if (ncur[j])
+						f(cur[j], ncur[j]);
+			}
+		};
+
 		// Close the open DEFLATE block: build codes, pick dynamic vs static, emit.
 		// Returns false if the member would exceed `limit` (-> stored fallback).
 		auto flush_block = [&](bool final) -> bool {
@@ -829,8 +884,8 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 			// straight-line: both forms are computed and one is selected; a token's two fields
 			// (litlen code + extra bits, offset code + extra bits: <= 20 + 28 bits) go out as
 			// one 64-bit OR over up to three dwords
-			auto put_tokens = [&](uint32_t tk, uint32_t base) {
-				const bool valid = base + lane < ntok_slab;
+			auto put_tokens_n = [&](uint32_t tk, uint32_t nvalid) {
+				const bool valid = lane < nvalid;
 				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
 				uint32_t ls, leb, lev, ds, deb, dev;
 				len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
@@ -854,8 +909,11 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				bitpos += readlane(incl, 63);
 				flush_ready();
 			};
+			auto put_tokens = [&](uint32_t tk, uint32_t base) { put_tokens_n(tk, ntok_slab - base); };
 			EMIT_T(2);
-			if (EMIT) {
+			if (EMIT && !PARTS && a.wg) {
+				wg_for_tokens(put_tokens_n);
+			} else if (EMIT) {
 				// The emit-only kernel reads its tokens from HBM: one dependent load per 64 tokens left the
 				// wave waiting for memory most of the time (~0.5 us per iteration).  Tokens come in groups of
 				// eight loads issued back to back, and the next group is requested before the current one is
@@ -1122,18 +1180,90 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				ntok_slab = total;
 				alive = flush_block(true);
 				crcv = uniform(L.misc[4]);              // (the second wavefront's, behind the barriers of flush_block)
+			} else if (a.wg) {
+				// the workgroup parse has left the pieces' tokens and counts: the DEFLATE blocks are cut here -- at a piece
+				// boundary once a block holds HD_DYN_BLOCK_TOKENS tokens or when the token mix has shifted (the twin's
+				// wg_split_check; deflate_compress.c:2141-2218) --, their symbols counted, and each is closed as ever
+				const SplitLayout lay = wg_layout(a.split_max);
+				const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
+				const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
+				wg_pieces = (const uint4 *)(rec + lay.off_ntok);
+				wg_np = (n + HD_WG_CUT - 1) / HD_WG_CUT;
+				wg_base = 0xffffff00u;
+				tok = (uint32_t *)rec;
+				crcv = m[1];
+				if (m[0] != 0)                               // (the workgroup parse gave the block up: stored)
+					alive = false;
+				for (uint32_t i = lane; i < 288; i += 64)
+					L.lf[i] = 0;
+				if (lane < 32)
+					L.df[lane] = 0;
+				uint32_t k = 0, block_begin = 0;
+				do {
+					uint32_t obs0 = 0, obs1 = 0, obs2 = 0, sn = 0, no0 = 0, no1 = 0, no2 = 0, snn = 0, blk_tok = 0;
+					bool end = false;
+					wg_k0 = k;
+					while (k < wg_np && !end) {
+						wg_piece_load(k);
+						const uint32_t li = k - wg_base;
+						blk_tok += readlane(wg_pv.x, li);
+						snn += readlane(wg_pv.x, li);
+						no0 += readlane(wg_pv.y, li);
+						no1 += readlane(wg_pv.z, li);
+						no2 += readlane(wg_pv.w, li);
+						k++;
+						const uint32_t here = k * HD_WG_CUT;             // (< n unless this was the last piece)
+						if (k < wg_np) {
+							end = blk_tok >= HD_DYN_BLOCK_TOKENS;
+							if (!end && snn >= HD_WG_SPLIT_OBS && here - block_begin >= HD_WG_SPLIT_MIN && n - here >= HD_WG_SPLIT_MIN) {
+								if (sn > 0) {
+									const uint32_t e0 = obs0 * snn, a0 = no0 * sn, e1 = obs1 * snn, a1 = no1 * sn, e2 = obs2 * snn, a2 = no2 * sn;
+									const uint32_t total = (a0 > e0 ? a0 - e0 : e0 - a0) + (a1 > e1 ? a1 - e1 : e1 - a1) + (a2 > e2 ? a2 - e2 : e2 - a2);
+									const uint32_t items = sn + snn, blen = here - block_begin;
+									uint32_t cutoff = snn * 200u / 512u * sn;
+									if (blen < 10000 && items < 8192)
+										cutoff += (cutoff >> 13) * (8192u - items);
+									end = total + (blen / 4096u) * sn >= cutoff;
+								}
+								if (!end) {
+									obs0 += no0;
+									obs1 += no1;
+									obs2 += no2;
+									sn += snn;
+									no0 = no1 = no2 = snn = 0;
+								}
+							}
+						}
+					}
+					wg_k1 = k;
+					block_begin = k * HD_WG_CUT;
+					if (!alive)
+						break;
+					// the block's symbols
+					wg_for_tokens([&](uint32_t tk, uint32_t nv) {
+						if (lane < nv) {
+							if (tk & HD_TOKEN_MATCH) {
+								uint32_t ls, ds, eb, ev;
+								len_slot(((tk >> 16) & 0xff) + 3, ls, eb, ev);
+								off_slot((tk & 0xffff) + 1, ds, eb, ev);
+								atomicAdd(&L.lf[257 + ls], 1u);
+								atomicAdd(&L.df[ds], 1u);
+							} else {
+								atomicAdd(&L.lf[tk & 0xff], 1u);
+							}
+						}
+					});
+					ntok_slab = blk_tok;
+					alive = flush_block(k == wg_np);
+				} while (alive && k < wg_np);
 			} else {
 			// the parse has been done: one flush per recorded DEFLATE block
-			const SplitLayout lay = a.wg ? wg_layout(a.split_max) : split_layout(a.split_max);
+			const SplitLayout lay = split_layout(a.split_max);
 			const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
 			const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
 			const uint32_t *nt = (const uint32_t *)(rec + lay.off_ntok);
 			uint32_t ndb = m[0];
 			crcv = m[1];
-			if (ndb == 0xffffffffu) {                    // (the workgroup parse gave the block up: stored)
-				alive = false;
-				ndb = 0;
-			}
 			uint32_t t0 = 0;
 			for (uint32_t k = 0; k < ndb && alive; k++) {
 				const uint32_t *h = (const uint32_t *)(rec + lay.off_hist) + k * 320;

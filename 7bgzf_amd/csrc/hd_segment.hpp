@@ -335,9 +335,10 @@ inline int launch_deflate_segmented(const DeflateArgs &a, int level, hipStream_t
 		if ((r = code(s)))
 			return r;
 		if (S <= 64) {
+			SegArgs gr = g;                                        // (a copy per round: only the last round's launch tells the host)
 			if (first + rb < a.nblocks)
-				g.a.done_flag = nullptr;                       // (only the last round's launch tells the host)
-			hipLaunchKernelGGL(k_seg_finish, dim3(ns), dim3(64), 0, st, g, (const uint8_t *)slots, stride);
+				gr.a.done_flag = nullptr;
+			hipLaunchKernelGGL(k_seg_finish, dim3(ns), dim3(64), 0, st, gr, (const uint8_t *)slots, stride);
 		} else {
 			hipLaunchKernelGGL(k_seg_stitch, dim3(g.count), dim3(64), 0, st, g);
 			hipLaunchKernelGGL(k_compact, dim3(ns), dim3(64), 0, st, (const uint8_t *)slots, (uint64_t)stride,

@@ -233,15 +233,26 @@ def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
                 p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=120)
                 return json.loads(p.stdout.strip().split("\n")[-1])["GBps_in"] if p.returncode == 0 else None
             try:
+                # the comparator is libdeflate with ONE REUSED compressor per thread (the reference's
+                # adapter allocates one per call, lib/zlibutil.c:186-188; that figure is kept beside it)
+                r_all = run(threads, "libdeflate_reused:%d" % level)
+                r_one = run(1, "libdeflate_reused:%d" % level)
                 c_all = run(threads, "libdeflate_deflate:%d" % level)
                 c_one = run(1, "libdeflate_deflate:%d" % level)
                 hook = run(threads, None, "libdeflate%d" % level) if block <= 0xff00 else None
-                if c_all:
-                    out.update({"value": round(c_all, 4), "unit": "GB/s", "cores": threads, "kind": kind,
-                                "one_core": round(c_one or 0, 4),
-                                "sample": "libdeflate 1.23 via libdeflate_deflate (lib/zlibutil.c:179), one call per %d-byte "
-                                          "block of the same workload from %d pthreads for 2 s = %d core-seconds "
-                                          "(tools/hook_bench.c against oracle/_ref/libref.so)" % (block, threads, 2 * threads)})
+                if r_all:
+                    out.update({"value": round(r_all, 4), "unit": "GB/s", "cores": threads, "kind": kind,
+                                "one_core": round(r_one or 0, 4),
+                                "sample": "libdeflate 1.23 libdeflate_deflate_compress level %d, one reused compressor per "
+                                          "thread, one call per %d-byte block of the same workload from %d pthreads for 2 s = "
+                                          "%d core-seconds (tools/hook_bench.c against oracle/_ref/libref.so)"
+                                          % (level, block, threads, 2 * threads)})
+                    out["reused_compressor"] = {"one_core": round(r_one or 0, 4), "all_cores": round(r_all, 4),
+                                                "what": "the same figure (cpu_baseline.value), kept under its old key"}
+                    if c_all:
+                        out["per_call_adapter"] = {"all_cores": round(c_all, 4), "one_core": round(c_one or 0, 4),
+                                                   "what": "libdeflate_deflate (lib/zlibutil.c:179-192): compressor allocated "
+                                                           "and freed in every call, as the reference's applets run it"}
                     done = True
                 if hook:
                     out["reference_hook"] = {"all_cores": round(hook, 4), "what": "bgzf_compress (bgzf_compress.c:39) with "
@@ -255,7 +266,7 @@ def cpu_baseline(tile, level, mode, block, sample_budget_s=12.0):
                     "sample": "%s; %d blocks (%.2f GB) of the same workload over %d python threads, %.1f s CPU work"
                               % (what, threads * n_all, threads * n_all * block / 1e9, threads, wall * threads)})
     if mode == "encode":
-        if have_ref:
+        if have_ref and "reused_compressor" not in out:
             one, allc, _, _ = measure(reused_work, 0.15)
             out["reused_compressor"] = {"one_core": round(one, 4), "all_cores": round(allc, 4),
                                         "what": "libdeflate_deflate_compress level %d, one compressor per thread" % level}
@@ -439,6 +450,36 @@ class Bench:
                    off=off, ln=ln, enc=enc, packed=packed, hdr=20 if migz else 18, dist=dict(state))
         return res
 
+    def verify_encode(self, res, data, block):
+        """UNTIMED, after the timed region: the whole packed stream of the last pass is inflated on the device and compared
+        with the input byte for byte, every member's CRC-32 with the one its trailer carries (the encoder's own)."""
+        torch, dev = self.torch, self.dev
+        enc, packed = res["enc"], res["packed"]
+        off, ln = res["off"], res["ln"]
+        nb = off.numel()
+        in_off = enc.dst_off - res["dist"]["base"] + res["hdr"]
+        in_len = (enc.out_len - res["hdr"]).to(torch.int32)       # payload + trailer: the inflater stops at BFINAL
+        out = torch.empty_like(data)
+        out_len = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        st = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        dev.device_inflate(packed, in_off, in_len, out, off, ln, out_len, crc, st)
+        torch.cuda.synchronize()
+        ok = (int(st.abs().sum()) == 0 and torch.equal(out_len, ln) and torch.equal(out, data) and torch.equal(crc, enc.crc))
+        # the CRC-32 / ISIZE fields of every member's trailer, read back from the packed stream
+        end = (enc.dst_off - res["dist"]["base"] + enc.out_len.to(torch.int64))
+        idx = (end[:, None] - 8 + torch.arange(8, device="cuda")[None, :]).reshape(-1)
+        trl = packed[idx].reshape(nb, 8).to(torch.int64)
+        t_crc = trl[:, 0] | (trl[:, 1] << 8) | (trl[:, 2] << 16) | (trl[:, 3] << 24)
+        t_isz = trl[:, 4] | (trl[:, 5] << 8) | (trl[:, 6] << 16) | (trl[:, 7] << 24)
+        ok = ok and torch.equal(t_crc, enc.crc.to(torch.int64) & 0xffffffff) and torch.equal(t_isz, ln.to(torch.int64))
+        del out
+        if not ok:
+            raise AssertionError("full-size verification failed: the packed stream does not inflate back to the input")
+        return {"bytes": int(data.numel()), "members": int(nb),
+                "how": "untimed: device inflate of the whole packed stream == input (torch.equal), per-member CRC-32 == "
+                       "encoder's == trailer field, ISIZE == block length"}
+
     def decode(self, data, packed, in_off, in_len, want_crc, block, steps, warmup):
         torch, dev = self.torch, self.dev
         total = data.numel()
@@ -502,8 +543,7 @@ class Bench:
 
 def level_name(level):
     return ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else \
-        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy (6-byte key, two-way buckets, 32 KiB window)" if level >= 9 else
-                                                   "lazy (6-byte key, two-way buckets)" if level >= 6 else
+        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy (workgroup-shared 32 KiB window, 8192 x 4-way table, block splitting)" if level >= 6 else
                                                    "lazy (one-way)" if level == 5 else "greedy")) if level >= 2 \
         else "level 0: stored"
 
@@ -515,7 +555,7 @@ def summary(res, steps, world=1, mode="encode"):
     ach = algo / res["k_avg_s"] / 1e9
     return {"value": round(res["total"] * world * steps / res["elapsed"] / 1e9, 3), "unit": "GB/s", "steps": steps,
             "ms_per_step": round(res["elapsed"] / steps * 1e3, 3), "kernel_ms_avg": round(res["k_avg_s"] * 1e3, 3),
-            "ratio": round(res["comp_total"] / res["total"], 4), "blocks": res["nb"],
+            "ratio": round(res["comp_total"] / res["total"], 4), "blocks": res["nb"], "input_bytes": int(res["total"]),
             "algorithmic_bytes_per_launch": algo, "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
 
 
@@ -560,6 +600,8 @@ def main():
         B.free()
         res = B.decode(data, packed, in_off, in_len, want_crc, block, args.steps, args.warmup)
     s = summary(res, args.steps, world, args.mode)
+    verified = B.verify_encode(res, data, block) if args.mode == "encode" else {
+        "how": "every pass: status, lengths, per-block CRC-32 against the reference stream's; first and last blocks byte for byte"}
 
     # HBM bytes per launch from the PMC counters: NOT measured in this run (counters need rocprofv3 around the
     # process); the tracked file holds the figure of the same command under `rocprofv3 --pmc` (tools/prof_round.sh)
@@ -598,7 +640,7 @@ def main():
                                        total / 2 ** 30, {"fastq": "FASTQ-like", "text": "enwik-like text",
                                                          "random": "random bytes"}[args.data],
                                        args.tile_mib, reps, res["nb"], shard_txt),
-                       "blocks_per_gpu": res["nb"], "ratio": s["ratio"], "parallelism": "block-range shard x%d" % world,
+                       "blocks_per_gpu": res["nb"], "input_bytes_per_gpu": int(total), "ratio": s["ratio"], "parallelism": "block-range shard x%d" % world,
                        "step": ("encode kernel + size scan + %sgather into the contiguous stream; passes are "
                                 "software-pipelined as a stream of batches is: scan and gather of pass k run on a second "
                                 "HIP stream beside the encode kernel of pass k + 1 (two sets of buffers), the last gather "
@@ -607,12 +649,14 @@ def main():
                        if args.mode == "encode" else "inflate kernel",
                        "stream": args.stream if args.mode == "decode" else None},
             "roofline": {"bound": "hbm", "kernel": "k_deflate_static" if args.mode == "encode" and level <= 1
-                         else ("k_deflate_static<TOK> (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" else "k_inflate"),
+                         else ("k_parse_wg (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" and level >= 6 else
+                               "k_deflate_static<TOK> (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" else "k_inflate"),
                          "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": s["frac"], "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": s["algorithmic_bytes_per_launch"],
                          "kernel_ms_avg": s["kernel_ms_avg"]},
         }
+        line["verified"] = verified
         line["ranks_seen"] = len(B.rank_elapsed)
         line["value_per_rank"] = [round(total * args.steps / e / 1e9, 3) for e in B.rank_elapsed]
         if B.use_dist and args.mode == "encode":
@@ -621,6 +665,10 @@ def main():
             line["config"]["stream_offsets"] = {"totals": d["totals"], "bases": d["bases"], "stream_bytes": d["grand"],
                                                 "first_member_offset": d["first_member_offset"]}
             line["config"]["collective"] = "all_gather of one int64 per rank, backend %s" % B.backend
+            try:
+                line["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if B.backend == "nccl" else None
+            except Exception:
+                line["config"]["rccl_version"] = None
 
     # ---- the other GPU configs of BASELINE.json, same run (default invocation, one GPU) ----------
     default_run = (args.mode == "encode" and level == 1 and args.data == "fastq" and not args.block_kib
@@ -639,6 +687,8 @@ def main():
                 tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
                 if os.path.exists(tf) and "error" not in configs[name]:
                     tj = json.load(open(tf))
+                if os.path.exists(tf) and "error" not in configs[name] and tj.get("input_bytes") == configs[name].get("input_bytes"):
+                    # (a counter run over another input size is another workload's traffic: left out)
                     configs[name]["traffic"] = tj.get("hbm_bytes_per_launch")
                     configs[name]["traffic_source"] = ("profiles/traffic_%s.json: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes over this config "
                                                        "in an earlier run (all kernels of a step; see its `reading`); not measured by this process" % name)
@@ -646,13 +696,34 @@ def main():
                 configs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             B.free()
 
-        def encode_l2():
-            r = B.encode(data, block, 2, False, xs, xw)
-            out = summary(r, xs)
-            out["workload"] = "BGZF encode, 0xff00-byte blocks, %s, same %.2f GiB FASTQ-like data" % (
-                level_name(2), total / 2 ** 30)
+        def encode_lv(lv):
+            def run():
+                r = B.encode(data, block, lv, False, xs, xw)
+                out = summary(r, xs)
+                out["verified"] = B.verify_encode(r, data, block)["how"]
+                out["workload"] = "BGZF encode, 0xff00-byte blocks, %s, same %.2f GiB FASTQ-like data" % (
+                    level_name(lv), total / 2 ** 30)
+                return out
+            return run
+        note("encode_l2", encode_lv(2))
+        note("encode_l6", encode_lv(6))
+
+        def decode_own_l1():
+            # a decode of THIS product's output: the level-1 stream of the headline data
+            e = B.encode(data, block, 1, False, 1, 0)
+            enc = e["enc"]
+            packed = e["packed"][: e["comp_total"] + 16].clone()
+            in_off = (enc.dst_off - e["dist"]["base"] + e["hdr"]).clone()
+            in_len = (enc.out_len - e["hdr"]).to(torch.int32)
+            want_crc = enc.crc.clone()
+            del enc, e
+            B.free()
+            r = B.decode(data, packed, in_off, in_len, want_crc, block, xs, xw)
+            out = summary(r, xs, mode="decode")
+            out["workload"] = ("BGZF decode (inflate), 0xff00-byte blocks, %.2f GiB out, stream from this encoder at level 1; "
+                               "output and per-block CRC-32 checked" % (total / 2 ** 30))
             return out
-        note("encode_l2", encode_l2)
+        note("decode_own_l1", decode_own_l1)
 
         def decode_ref(which, who):
             def run():
@@ -682,6 +753,7 @@ def main():
                 _, tdata, _ = B.make_data("text", mb, whole_blocks=False)
                 r = B.encode(tdata, mb, lv, True, xs, xw)
                 out = summary(r, xs)
+                out["verified"] = B.verify_encode(r, tdata, mb)["how"]
                 out["workload"] = "MiGz encode, 1 MiB blocks, %s, %.2f GiB enwik-like text" % (
                     level_name(lv), tdata.numel() / 2 ** 30)
                 return out

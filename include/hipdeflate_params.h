@@ -121,16 +121,19 @@
  * WORKGROUP of HD_WG_WAVES wavefronts per block shares one window and one table in LDS (hd_deflate_wg.hpp) -- the role of
  * hc_matchfinder (lib/libdeflate/hc_matchfinder.h:183-338) and of deflate_compress_lazy_generic (deflate_compress.c:2606-2809)
  * with what a whole CU's LDS holds instead of one wavefront's share of it:
- *   window   DEFLATE's 32 KiB, in a 64 KiB ring (positions are ring offsets; table entries (p + 1) mod 2^16, 0 = empty);
+ *   window   DEFLATE's 32 KiB, in a 64 KiB ring (positions are ring offsets; a table entry is p mod 2^16 -- no entry is
+ *            "empty": a zeroed or stale one names some position 1..32768 bytes back or is out of range, and the bytes there decide);
  *   table    HD_WG_BUCKETS buckets of HD_WG_WAYS positions, newest first, six-byte key (HD_HASH_SLOT6).  A step's lanes read
  *            their buckets as the steps before left them; of the lanes of a step that share a bucket the highest stores
  *            { itself, the three newest before the step };
  *   verify   every candidate -- the byte before the position, if the lane has one in its step (runs), then the four of the
  *            bucket -- over HD_WG_VCAP bytes; the longest wins, the nearer on a tie; a match of HD_WG_VCAP bytes is extended to
- *            its full length (<= 258); minimum length HD_WG_MIN_LEN;
+ *            its full length (<= 258); minimum length HD_WG_MIN_LEN; NO MATCH CROSSES A MULTIPLE OF HD_WG_CUT (a "piece"):
+ *            the parse of a piece depends on nothing but the table, so the pieces of a block are parsed side by side, one
+ *            wavefront each, and only the table accesses take turns (cut = 1024 costs 0.2 % of the output, tools/mf_explore.c);
  *   lazy     libdeflate's rule (deflate_compress.c:2723-2726) on the lane to the right, with the lengths capped at HD_WG_VCAP:
  *            a match steps aside when 4 (len' - len) + log2(dist) - log2(dist') > 2 for its neighbour's match;
- *   blocks   a DEFLATE block ends at a step boundary once it holds HD_DYN_BLOCK_TOKENS tokens, or when the token mix has
+ *   blocks   a DEFLATE block ends at a piece boundary once it holds HD_DYN_BLOCK_TOKENS tokens, or when the token mix has
  *            shifted: libdeflate's observation test (deflate_compress.c:2141-2218) over three classes -- literal, match
  *            below 9 bytes, longer match --, checked every HD_WG_SPLIT_OBS tokens, blocks of at least HD_WG_SPLIT_MIN bytes;
  *   long blocks (MiGz members) are ONE stream with the window sliding through them: no segments.
@@ -144,6 +147,7 @@
 #define HD_WG_MIN_LEN      5u
 #define HD_WG_SPLIT_OBS    512u
 #define HD_WG_SPLIT_MIN    5000u
+#define HD_WG_CUT          1024u
 #define HD_WG_WAVES        16
 
 /* Besides the hash table, which only knows earlier steps, a lane takes the lane just before it as its

@@ -795,14 +795,19 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			if (p + HD_LAZY_KEY_BYTES > n)
 				continue;
 			uint16_t *e = bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), HD_WG_BUCKETS) * HD_WG_WAYS;
-			e[0] = (uint16_t)(p + 1);
+			e[0] = (uint16_t)p;             /* the position mod 2^16 = its offset in the 64 KiB ring; nothing marks an entry
+			                                 * empty: whatever it holds names a position, and the bytes there decide */
 			for (unsigned k = 1; k < HD_WG_WAYS; k++)
 				e[k] = pre[l][k - 1];
 		}
 		/* 3. verify: the byte before (runs; only inside the step), then the bucket, newest first; longest wins, nearest on a tie */
 		for (unsigned l = 0; l < lanes; l++) {
 			const size_t p = S + l;
-			const unsigned room = n - p < HD_WG_VCAP ? (unsigned)(n - p) : HD_WG_VCAP;
+			/* no match crosses a multiple of HD_WG_CUT: the parse of one HD_WG_CUT-byte piece never depends on another's */
+			const unsigned to_cut = HD_WG_CUT - (unsigned)(p % HD_WG_CUT);
+			unsigned room = n - p < HD_WG_VCAP ? (unsigned)(n - p) : HD_WG_VCAP;
+			if (to_cut < room)
+				room = to_cut;
 			unsigned best = 0;
 			uint32_t bd = 0;
 			clen[l] = flen[l] = dist[l] = 0;
@@ -816,8 +821,8 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 					back = 1;
 				} else {
 					const uint32_t e = pre[l][k - 1];
-					back = (uint32_t)(p + 1 - e) & 0xffffu;
-					if (e == 0 || back == 0 || back > HD_WG_WINDOW || back > p)
+					back = (uint32_t)(p - e) & 0xffffu;
+					if (back == 0 || back > HD_WG_WINDOW || back > p)
 						continue;
 				}
 				unsigned m = 0;
@@ -835,7 +840,9 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			/* 4. a match of the whole verified span is extended to its full length */
 			unsigned len = best;
 			if (best == HD_WG_VCAP) {
-				const unsigned maxlen = n - p < HD_MAX_MATCH ? (unsigned)(n - p) : HD_MAX_MATCH;
+				unsigned maxlen = n - p < HD_MAX_MATCH ? (unsigned)(n - p) : HD_MAX_MATCH;
+				if (to_cut < maxlen)
+					maxlen = to_cut;
 				while (len < maxlen && in[p + len] == in[p + len - bd])
 					len++;
 			}
@@ -867,9 +874,9 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			}
 			sp.nn++;
 		}
-		/* a DEFLATE block may end behind any step but the last */
+		/* a DEFLATE block may end behind any piece of HD_WG_CUT bytes but the last */
 		const size_t here = S + lanes;
-		if (here < n) {
+		if (here < n && here % HD_WG_CUT == 0) {
 			int end = b.ntok >= HD_DYN_BLOCK_TOKENS;
 			if (!end && sp.nn >= HD_WG_SPLIT_OBS && here - block_begin >= HD_WG_SPLIT_MIN && n - here >= HD_WG_SPLIT_MIN)
 				end = wg_split_check(&sp, (uint32_t)(here - block_begin));

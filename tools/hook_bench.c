@@ -7,7 +7,9 @@
  * With a fifth argument the threads call that zlibutil codec (lib/zlibutil.h:47, e.g. libdeflate_deflate:1 or
  * hip_deflate:1, looked up with dlsym) instead of the hook: the per-block function alone, a fresh 1.5 x block
  * destination per call as zlibutil_buffer_allocate gives it -- bench.py's cpu_baseline runs the reference's
- * libdeflate_deflate this way, on real pthreads rather than through Python.
+ * libdeflate_deflate this way, on real pthreads rather than through Python.  The name libdeflate_reused:<level> stands
+ * for libdeflate_deflate_compress with ONE compressor per thread, allocated before the clock starts (SURVEY.md 8(d)(i):
+ * the reference without lib/zlibutil.c:186-188's alloc/free per call).
  *
  * Links against whatever provides bgzf_compress: libhipdeflate.so (BGZF_METHOD=hip1) or the reference's
  * own hook built from bgzf_compress.c (oracle/_ref/libref.so, BGZF_METHOD=libdeflate1) -- the same binary
@@ -30,6 +32,19 @@ int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int lev
 typedef int (*codec_fn)(unsigned char *, size_t *, const unsigned char *, size_t, int);
 static codec_fn g_codec;
 static int g_codec_level = 1;
+/* libdeflate_reused: the library's own entry points, looked up in whatever the binary is linked against */
+static void *(*g_ld_alloc)(int);
+static size_t (*g_ld_compress)(void *, const void *, size_t, void *, size_t);
+static void (*g_ld_free)(void *);
+static __thread void *t_comp;
+static int reused_codec(unsigned char *dst, size_t *dlen, const unsigned char *src, size_t slen, int level)
+{
+	if (!t_comp && !(t_comp = g_ld_alloc(level)))
+		return 2;
+	const size_t n = g_ld_compress(t_comp, src, slen, dst, *dlen);
+	*dlen = n;
+	return n == 0;
+}
 static unsigned char *g_data;
 static size_t g_size, g_block = 0xff00;
 static volatile int g_stop;
@@ -55,7 +70,9 @@ static void *run(void *arg)
 	unsigned char *dst = (unsigned char *)malloc(g_block + g_block / 2 + 0x10000);
 	const size_t nblk = g_size / g_block;
 	size_t k = (size_t)w->id * 7919u % nblk;
-	while (!g_stop) {
+	if (g_codec == reused_codec && !(t_comp = g_ld_alloc(g_codec_level)))
+		w->err = 2;
+	while (!g_stop && !w->err) {
 		size_t dlen = g_codec ? g_block + g_block / 2 : 0x10000;
 		int r = g_codec ? g_codec(dst, &dlen, g_data + k * g_block, g_block, g_codec_level)
 				: bgzf_compress(dst, &dlen, g_data + k * g_block, g_block, -1);
@@ -67,6 +84,10 @@ static void *run(void *arg)
 		w->out_bytes += dlen;
 		w->calls++;
 		k = (k + (size_t)w->nthreads) % nblk;
+	}
+	if (t_comp) {
+		g_ld_free(t_comp);
+		t_comp = NULL;
 	}
 	free(dst);
 	return NULL;
@@ -123,7 +144,14 @@ int main(int argc, char **argv)
 			*c = 0;
 			g_codec_level = atoi(c + 1);
 		}
-		g_codec = (codec_fn)dlsym(RTLD_DEFAULT, name);
+		if (!strcmp(name, "libdeflate_reused")) {
+			g_ld_alloc = (void *(*)(int))dlsym(RTLD_DEFAULT, "libdeflate_alloc_compressor");
+			g_ld_compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(RTLD_DEFAULT, "libdeflate_deflate_compress");
+			g_ld_free = (void (*)(void *))dlsym(RTLD_DEFAULT, "libdeflate_free_compressor");
+			g_codec = g_ld_alloc && g_ld_compress && g_ld_free ? reused_codec : NULL;
+		} else {
+			g_codec = (codec_fn)dlsym(RTLD_DEFAULT, name);
+		}
 		if (!g_codec) {
 			fprintf(stderr, "no such codec: %s\n", name);
 			return 2;
@@ -210,6 +238,10 @@ int main(int argc, char **argv)
 		if (r) {
 			fprintf(stderr, "bgzf_compress failed: %d\n", r);
 			return 1;
+		}
+		if (t_comp) {
+			g_ld_free(t_comp);
+			t_comp = NULL;
 		}
 		free(dst);
 	}

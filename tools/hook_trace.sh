@@ -16,6 +16,7 @@ M=${1:-hip2}; T=${2:-8}
 export BGZF_METHOD=$M HIPDEFLATE_HOOK_STATS=1
 ROOT=$PWD
 ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 > $OUT/${M}_T${T}_plain.txt 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ht_$M_$T -o ht -- $ROOT/7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 > $OUT/${M}_T${T}_rocprof.log 2>&1) || tail -5 $OUT/${M}_T${T}_rocprof.log
-cp "$(find /tmp/ht_$M_$T -name "*kernel_stats.csv" | head -1)" $OUT/${M}_T${T}_kernel_stats.csv
+rm -rf /tmp/ht_${M}_$T
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ht_${M}_$T -o ht -- $ROOT/7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 > $OUT/${M}_T${T}_rocprof.log 2>&1) || tail -5 $OUT/${M}_T${T}_rocprof.log
+cp "$(find /tmp/ht_${M}_$T -name "*kernel_stats.csv" | head -1)" $OUT/${M}_T${T}_kernel_stats.csv
 cut -c1-400 $OUT/${M}_T${T}_plain.txt; grep -h "hook\|GBps" $OUT/${M}_T${T}_rocprof.log | cut -c1-400; cut -c1-160 $OUT/${M}_T${T}_kernel_stats.csv

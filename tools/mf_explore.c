@@ -15,7 +15,7 @@
 #include <stdio.h>
 
 typedef struct {
-	unsigned win_bits, buckets, ways, key, G, intra, vcap, minlen, lazy, adapt, split, seg, prime, toks, h3, far5, ins_all, k2, b2, lazyd;
+	unsigned win_bits, buckets, ways, key, G, intra, vcap, minlen, lazy, adapt, split, seg, prime, toks, h3, far5, ins_all, k2, b2, lazyd, cut, splitg;
 } cfg_t;
 
 static uint32_t hash_key(const uint8_t *p, unsigned key, unsigned buckets)
@@ -102,7 +102,9 @@ static int code_segment(bw_t *w, const uint8_t *in, size_t n, size_t prime, cons
 			cand_dist[l] = 0;
 			if (p + c->key > tot)
 				continue;
-			const unsigned room = tot - p < c->vcap ? (unsigned)(tot - p) : c->vcap;
+			unsigned room = tot - p < c->vcap ? (unsigned)(tot - p) : c->vcap;
+			if (c->cut && c->cut - (unsigned)(p % c->cut) < room)   /* no match crosses a cut boundary */
+				room = c->cut - (unsigned)(p % c->cut);
 			unsigned best = 0;
 			uint32_t bd = 0;
 			const uint32_t *e = bk + (size_t)hash_key(base + p, c->key, B) * W;
@@ -192,7 +194,9 @@ static int code_segment(bw_t *w, const uint8_t *in, size_t n, size_t prime, cons
 			}
 			if (take) {
 				unsigned len = cand_len[l], sym, eb, ev;
-				const unsigned maxlen = tot - p < 258 ? (unsigned)(tot - p) : 258;
+				unsigned maxlen = tot - p < 258 ? (unsigned)(tot - p) : 258;
+				if (c->cut && c->cut - (unsigned)(p % c->cut) < maxlen)
+					maxlen = c->cut - (unsigned)(p % c->cut);
 				while (len < maxlen && base[p + len] == base[p + len - cand_dist[l]])
 					len++;
 				b.tok[b.ntok++] = HD_TOKEN_MATCH | ((uint32_t)(len - 3) << 16) | (cand_dist[l] - 1);
@@ -226,7 +230,7 @@ static int code_segment(bw_t *w, const uint8_t *in, size_t n, size_t prime, cons
 			next_recalc += here - block_begin < tot - next_recalc ? here - block_begin : tot - next_recalc;
 		}
 		int end = 0;
-		if (here < tot) {
+		if (here < tot && !(c->splitg && here % c->splitg)) {      /* splitg: blocks end at multiples of it only */
 			if (b.ntok >= c->toks)
 				end = 1;
 			else if (c->split && sp.nn >= 512 && here - block_begin >= 5000 && tot - here >= 5000)
@@ -303,7 +307,7 @@ int main(int argc, char **argv)
 #define KEY(name, field) if (!strcmp(k, name)) c.field = v
 		KEY("win", win_bits); KEY("buckets", buckets); KEY("ways", ways); KEY("key", key); KEY("G", G); KEY("intra", intra);
 		KEY("vcap", vcap); KEY("minlen", minlen); KEY("lazy", lazy); KEY("adapt", adapt); KEY("split", split); KEY("seg", seg);
-		KEY("prime", prime); KEY("toks", toks); KEY("h3", h3); KEY("far5", far5); KEY("ins_all", ins_all); KEY("k2", k2); KEY("b2", b2); KEY("lazyd", lazyd);
+		KEY("prime", prime); KEY("toks", toks); KEY("h3", h3); KEY("far5", far5); KEY("ins_all", ins_all); KEY("k2", k2); KEY("b2", b2); KEY("lazyd", lazyd); KEY("cut", cut); KEY("splitg", splitg);
 	}
 	FILE *f = fopen(argv[1], "rb");
 	if (!f)

@@ -30,7 +30,7 @@ line = json.loads([l for l in open("%s/%s_FETCH_SIZE.log" % (out, name)).read().
 kern = {k: {"launches": calls[k], "FETCH_SIZE_KiB": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KiB": v.get("WRITE_SIZE", 0.0)} for k, v in acc.items()}
 fetch = sum(v["FETCH_SIZE_KiB"] for v in kern.values()) * 1024
 write = sum(v["WRITE_SIZE_KiB"] for v in kern.values()) * 1024
-res = {"config": name, "bench_args": args, "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
+res = {"config": name, "bench_args": args, "input_bytes": line["config"].get("input_bytes_per_gpu"), "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
        "fetch_bytes_raw": fetch, "fetch_bytes_doubled": 2 * fetch, "write_bytes": write,
        "hbm_bytes_per_launch": 2 * fetch + write, "kernels": kern,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over one bench.py step (--steps 1 --warmup 0); KiB units; "
