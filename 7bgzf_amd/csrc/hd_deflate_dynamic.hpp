@@ -26,7 +26,9 @@
 
 namespace hd {
 
-constexpr uint64_t SPLIT_SCRATCH_BUDGET_WG = (uint64_t)12672 << 20;
+// (4096 one-MiB members -- sixteen emit wavefronts per CU, which the emit kernel needs: one wavefront writes a member -- or
+// 64 Ki BGZF blocks per round)
+constexpr uint64_t SPLIT_SCRATCH_BUDGET_WG = (uint64_t)17408 << 20;
 constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 
 // the records of the workgroup parse (levels >= HD_WG_LEVEL, hd_deflate_wg.hpp): piece k's tokens from token k * HD_WG_CUT on
@@ -35,7 +37,7 @@ constexpr uint32_t DYN_SLAB_TOKENS = HD_DYN_BLOCK_TOKENS + 64;
 __host__ __device__ inline SplitLayout wg_layout(uint32_t max_block)
 {
 	SplitLayout l;
-	l.max_db = (max_block + HD_WG_CUT - 1) / HD_WG_CUT + 1;                // pieces
+	l.max_db = (max_block + HD_WG_CUT - 1) / HD_WG_CUT;                    // pieces
 	l.cap_tok = l.max_db * HD_WG_CUT;
 	l.off_rec = (uint64_t)l.cap_tok * 4;
 	l.off_ntok = l.off_rec + 16;                                           // the pieces' records

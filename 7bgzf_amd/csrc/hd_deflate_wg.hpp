@@ -34,7 +34,9 @@ namespace hd {
 constexpr uint32_t WG_NW = HD_WG_WAVES;
 constexpr uint32_t WG_NP = WG_NW - 1;            // parsers
 constexpr uint32_t WG_STEPS = HD_WG_CUT / 64;
-constexpr uint32_t WG_AHEAD = 8;                 // pieces the ring is filled ahead of the table turn
+constexpr uint32_t WG_AHEAD = 24;                // pieces the ring is filled ahead of the oldest piece in work (or of the table
+                                                 // turn, whichever is older): piece k takes the place of piece k - 64 and a
+                                                 // parser reads up to 32 pieces behind its own, so anything below 32 is safe
 constexpr uint32_t WG_SPIN_LIMIT = 1u << 20;     // a turn that does not come: the block is given up (stored), never a hang
 static_assert(HD_WG_CUT == HD_PIECE && WG_STEPS == 16, "a piece of the parse is a piece of the ring");
 static_assert(HD_WG_RING == 65536 && HD_WG_WINDOW == 32768 && HD_WG_WAYS == 4 && HD_WG_VCAP == 16, "the kernel is written for this geometry");
@@ -45,6 +47,8 @@ struct WgLds {
 	uint32_t turn;                         // the piece whose table accesses may run
 	uint32_t filled;                       // pieces in the ring
 	uint32_t fail;
+	uint32_t next;                         // the next piece to hand out
+	uint32_t cur[WG_NW];                   // the piece wavefront w is working on (0xffffffff: none)
 };
 #define WG_BARRIER() asm volatile("" ::: "memory")
 // LDS words that other wavefronts write are read and written through address-space-3 pointers (ds_read / ds_write, never
@@ -72,18 +76,30 @@ __device__ __forceinline__ bool wg_wait(wg_word_p word, uint32_t want, wg_word_p
 	}
 }
 
-// first byte at which two 16-byte strings differ, given the XOR of their dwords: 0..16
-__device__ __forceinline__ uint32_t wg_common16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+// first BIT at which two 16-byte strings differ, given the XOR of their dwords, capped at `cap_bits` (<= 128): v_ffbl_b32 of
+// an equal dword is 0xffffffff and stays there through the saturating add, so the minimum is the first differing dword's.
+// Nine instructions, pinned: the compiler's own form of "first set bit or the next dword's" is a compare and a select per dword.
+__device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t cap_bits, uint32_t k96)
 {
-	// (v_ffbl_b32 of 0 is 0xffffffff: the min takes the other side)
-	uint32_t t = min(x3 ? (uint32_t)__builtin_ctz(x3) : 0xffffffffu, 32u);
-	t = min(x2 ? (uint32_t)__builtin_ctz(x2) : 0xffffffffu, t + 32u);
-	t = min(x1 ? (uint32_t)__builtin_ctz(x1) : 0xffffffffu, t + 32u);
-	t = min(x0 ? (uint32_t)__builtin_ctz(x0) : 0xffffffffu, t + 32u);
-	return t >> 3;
+	uint32_t g0, g1, g2, g3, t;
+	asm("v_ffbl_b32 %0, %1" : "=v"(g0) : "v"(x0));
+	asm("v_ffbl_b32 %0, %1" : "=v"(g1) : "v"(x1));
+	asm("v_ffbl_b32 %0, %1" : "=v"(g2) : "v"(x2));
+	asm("v_ffbl_b32 %0, %1" : "=v"(g3) : "v"(x3));
+	asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(g1) : "v"(g1));
+	asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(g2) : "v"(g2));
+	asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(g3) : "v"(g3), "s"(k96));
+	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(g0), "v"(g1), "v"(g2));
+	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(g3), "v"(cap_bits));
+	return t;
 }
 
 typedef uint32_t wg_u32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint64_t wg_uniform64(uint64_t v)
+{
+	return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
+}
 
 __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 {
@@ -99,14 +115,17 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	uint32_t *const tok = (uint32_t *)rec;
 	uint4 *const rec_piece = (uint4 *)(rec + lay.off_ntok);
 	WG_LDS WgLds *const Lp = (WG_LDS WgLds *)&L;
-	const wg_word_p vturn = (wg_word_p)&Lp->turn, vfilled = (wg_word_p)&Lp->filled, vfail = (wg_word_p)&Lp->fail;
+	const wg_word_p vturn = (wg_word_p)&Lp->turn, vfilled = (wg_word_p)&Lp->filled, vfail = (wg_word_p)&Lp->fail,
+			vcur = (wg_word_p)Lp->cur;
 	const uint32_t npieces = (n + HD_WG_CUT - 1) / HD_WG_CUT;
 
 	// ---- LDS: the table zero, the words ------------------------------------------------------------------------------
 	for (uint32_t i = threadIdx.x; i < HD_WG_BUCKETS * HD_WG_WAYS / 8; i += 64 * WG_NW)
 		((uint4 *)L.table)[i] = make_uint4(0, 0, 0, 0);
+	if (threadIdx.x < WG_NW)
+		L.cur[threadIdx.x] = 0xffffffffu;
 	if (threadIdx.x == 0) {
-		L.turn = L.filled = L.fail = 0;
+		L.turn = L.filled = L.fail = L.next = 0;
 		L.table[HD_WG_BUCKETS * HD_WG_WAYS / 2] = L.table[HD_WG_BUCKETS * HD_WG_WAYS / 2 + 1] = 0;
 	}
 	__syncthreads();
@@ -120,9 +139,31 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		if (npieces)
 			pend = load_slot(src, n, 0, lane, aligned);
 		for (uint32_t k = 0; k < npieces; k++) {
-			// piece k takes the place of piece k - 64; the oldest piece a parser may still read is 14 + 32 behind the turn
-			if (k > WG_AHEAD && !wg_wait(vturn, k - WG_AHEAD, vfail))
-				break;
+			// piece k takes the place of piece k - 64, and a parser reads up to 32 pieces behind its own: k stays within
+			// WG_AHEAD of the oldest piece still in work (the table turn counts as one: its holder is about to start)
+			if (k > WG_AHEAD) {
+				bool ok = true;
+				for (uint32_t spins = 0;; spins++) {
+					uint32_t v = lane < WG_NW ? vcur[lane] : 0xffffffffu;
+					const uint32_t tn = uniform(*vturn);
+					WG_BARRIER();
+					v = min(v, (uint32_t)__shfl_xor((int)v, 8, 64));
+					v = min(v, (uint32_t)__shfl_xor((int)v, 4, 64));
+					v = min(v, (uint32_t)__shfl_xor((int)v, 2, 64));
+					v = min(v, (uint32_t)__shfl_xor((int)v, 1, 64));
+					const uint32_t oldest = min(uniform(v), tn);
+					if (oldest + WG_AHEAD >= k)
+						break;
+					if (uniform(*vfail) || spins > WG_SPIN_LIMIT) {
+						*vfail = 1;
+						ok = false;
+						break;
+					}
+					__builtin_amdgcn_s_sleep(8);
+				}
+				if (!ok)
+					break;
+			}
 			const uint4 v = pend;
 			if (k + 1 < npieces)
 				pend = load_slot(src, n, k + 1, lane, aligned);
@@ -143,8 +184,28 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		hk.init(2 * HD_WG_BUCKETS);                // byte offset of an 8-byte bucket: 4 * (2 * slot)
 		hk.m = 0xfff8u;
 		WG_LDS uint8_t *const tab8 = (WG_LDS uint8_t *)Lp->table;
+		uint32_t k96;
+		asm volatile("s_movk_i32 %0, 96" : "=s"(k96));            // (an SGPR on purpose: VOP3 takes no literal)
 		const uint8_t *const ring8 = (const uint8_t *)L.ring32;
-		for (uint32_t j = w; j < npieces; j += WG_NP) {
+		// Pieces are handed out by a counter, not dealt round robin: three SIMDs carry four parsers and one carries three and
+		// the filler, and a parser that gets a larger share of its SIMD takes more pieces.  Whoever holds the lowest piece in
+		// work never waits for a higher one, so the hand-out cannot lock up.
+		uint32_t deal_round = 0;
+		(void)deal_round;
+		for (;;) {
+			uint32_t j = 0;
+#ifdef HD_WG_EXP_STATIC_DEAL                        /* experiment (tools/exp_wg_variants.sh): pieces dealt round robin */
+			j = w + WG_NP * deal_round++;
+#else
+			if (lane == 0)
+				j = __hip_atomic_fetch_add((WG_LDS uint32_t *)&Lp->next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			j = uniform(j);
+#endif
+			if (lane == 0)
+				vcur[w] = j < npieces ? j : 0xffffffffu;
+			WG_BARRIER();
+			if (j >= npieces)
+				break;
 			const uint32_t P0 = j * HD_WG_CUT;
 			const uint32_t pend = n - P0 < HD_WG_CUT ? n : P0 + HD_WG_CUT;         // the piece's end
 			const uint32_t nst = (pend - P0 + 63) >> 6;
@@ -159,7 +220,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				const uint32_t p = P0 + 64 * t + lane;
 				const uint32_t *q = L.ring32 + ((p & (HD_WG_RING - 1)) >> 2);
 				const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-				const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, p & 3), vh = __builtin_amdgcn_alignbyte(d2, d1, p & 3);
+				const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, p), vh = __builtin_amdgcn_alignbyte(d2, d1, p);   // (v_alignbyte_b32 reads bits [1:0] of its shift: tools/isa_probe.hip)
 				ha[t] = hash_slot_addr6(v, vh, hk);
 			}
 			// ---- the turn: 16 steps of buckets, in order --------------------------------------------------------------
@@ -213,18 +274,18 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				// own 16 bytes
 				const uint32_t *q = L.ring32 + ((p & (HD_WG_RING - 1)) >> 2);
 				const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-				const uint32_t sh = p & 3;
+				const uint32_t sh = p;                           // (v_alignbyte_b32 reads bits [1:0] only)
 				const uint32_t o0 = __builtin_amdgcn_alignbyte(d1, d0, sh), o1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
 					       o2 = __builtin_amdgcn_alignbyte(d3, d2, sh), o3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
 				const uint64_t keyed = __ballot(p + HD_LAZY_KEY_BYTES <= n);
-				const uint32_t room = min(pend - p, (uint32_t)HD_WG_VCAP);        // (keyed lanes: p < pend)
+				const uint32_t room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;  // in bits (keyed lanes: p < pend)
 				const uint32_t lim = min(p, (uint32_t)HD_WG_WINDOW);
 				// the byte before (runs; only inside the step): as long as the own bytes repeat it
 				uint32_t best, dist = 1;
 				{
 					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 					const uint32_t sp = __builtin_amdgcn_perm(prev, prev, 0u);      // its first byte, four times
-					const uint32_t m = min(wg_common16(o0 ^ sp, o1 ^ sp, o2 ^ sp, o3 ^ sp), room);
+					const uint32_t m = wg_common_bits(o0 ^ sp, o1 ^ sp, o2 ^ sp, o3 ^ sp, room8, k96) >> 3;
 					best = sel(keyed & ~1ull, m, 0u);
 				}
 				// the bucket, newest first: the longest wins, the nearer on a tie
@@ -236,10 +297,10 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 					const uint64_t ok = __ballot(back - 1 < lim) & keyed;
 					const uint32_t *c = L.ring32 + (e >> 2);
 					const uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
-					const uint32_t cs = e & 3;
+					const uint32_t cs = e;
 					const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, cs) ^ o0, x1 = __builtin_amdgcn_alignbyte(c2, c1, cs) ^ o1,
 						       x2 = __builtin_amdgcn_alignbyte(c3, c2, cs) ^ o2, x3 = __builtin_amdgcn_alignbyte(c4, c3, cs) ^ o3;
-					const uint32_t m = min(wg_common16(x0, x1, x2, x3), room);
+					const uint32_t m = wg_common_bits(x0, x1, x2, x3, room8, k96) >> 3;
 					const uint64_t better = __ballot(m > best) & ok;
 					best = sel(better, m, best);
 					dist = sel(better, back, dist);
@@ -252,45 +313,86 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				const int gain = 4 * ((int)clen_r - (int)clen) + ((int)__clz(dist_r | 1) - (int)__clz(dist | 1));
 				const uint64_t defer = __ballot(clen_r >= clen) & __ballot(gain > 2) & candm & (lanem >> 1);
 				const uint64_t take = candm & ~defer;
-				const uint64_t capm = __ballot(best == HD_WG_VCAP);         // matches of the whole verified span: extended when taken
-				uint32_t flen = clen;
-				// ---- the walk from E: literal runs in one hop, a lane read per match -----------------------------------
+				// matches of the whole verified span are extended when the walk takes them
+				uint64_t capt = __ballot(best == HD_WG_VCAP) & take;
+				uint32_t jmp = sel(take, clen, 1u);             // where the parse goes from a lane that starts a token
+				// ---- the walk from E: a hop per match (a bit set, a lane read, an add) and one per run of literals (a mask), in
+				// ISA -- the compiler's form of this loop was ~27 scalar instructions per hop, and the scalar pipe is as full as
+				// the vector one here -----
 				uint64_t starts = 0;
 				uint32_t bb = E > S ? E - S : 0u;
+				if (take == 0 && bb < lanes) {                   // (nothing but literals: random data)
+					starts = lanem & ~((1ull << bb) - 1);
+					bb = lanes;
+				}
 				while (bb < lanes) {
-					const uint64_t tk = take >> bb;
-					if (tk == 0) {
-						starts |= lanem & ~((1ull << bb) - 1);
-						bb = lanes;
+					uint32_t hop;
+					capt = wg_uniform64(capt);
+					const uint64_t take_u = wg_uniform64(take);
+					starts = wg_uniform64(starts);
+					bb = uniform(bb);
+					uint64_t tk;
+					uint32_t z;
+					asm volatile("Lhd_wg_walk_%=:\n\t"
+						     "s_bitcmp1_b64 %[take], %[b]\n\t"
+						     "s_cbranch_scc0 Lhd_wg_lit_%=\n"
+						     "Lhd_wg_match_%=:\n\t"
+						     "s_bitcmp1_b64 %[capt], %[b]\n\t"
+						     "s_cbranch_scc1 Lhd_wg_walk_out_%=\n\t"
+						     "s_bitset1_b64 %[st], %[b]\n\t"
+						     "v_readlane_b32 %[hop], %[jmp], %[b]\n\t"
+						     "s_add_u32 %[b], %[b], %[hop]\n\t"
+						     "s_cmp_lt_u32 %[b], %[lanes]\n\t"
+						     "s_cbranch_scc1 Lhd_wg_walk_%=\n\t"
+						     "s_branch Lhd_wg_walk_out_%=\n"
+						     "Lhd_wg_lit_%=:\n\t"                      // a run of literals: up to the next match or the step's end
+						     "s_lshr_b64 %[tk], %[take], %[b]\n\t"
+						     "s_ff1_i32_b64 %[z], %[tk]\n\t"           // (-1: no match behind)
+						     "s_sub_u32 %[hop], %[lanes], %[b]\n\t"
+						     "s_min_u32 %[z], %[z], %[hop]\n\t"        // (< 64: a whole step of literals never comes here)
+						     "s_bfm_b64 %[tk], %[z], %[b]\n\t"
+						     "s_or_b64 %[st], %[st], %[tk]\n\t"
+						     "s_add_u32 %[b], %[b], %[z]\n\t"
+						     "s_cmp_lt_u32 %[b], %[lanes]\n\t"
+						     "s_cbranch_scc1 Lhd_wg_match_%=\n"
+						     "Lhd_wg_walk_out_%=:"
+						     : [b] "+s"(bb), [st] "+s"(starts), [hop] "=&s"(hop), [tk] "=&s"(tk), [z] "=&s"(z)
+						     : [capt] "s"(capt), [jmp] "v"(jmp), [lanes] "s"(lanes), [take] "s"(take_u)
+						     : "scc");
+					// (what an asm statement returns counts as divergent for the compiler: pinned)
+					bb = uniform(bb);
+					starts = wg_uniform64(starts);
+					if (bb >= lanes)
 						break;
+					// lane bb: a match of the whole verified span, taken: to its full length, 64 bytes per pass by all lanes
+					const uint32_t k = bb;
+					uint32_t len = HD_WG_VCAP;
+					const uint32_t D = readlane(dist, k), at = S + k;
+					const uint32_t maxlen = pend - at < HD_MAX_MATCH ? pend - at : HD_MAX_MATCH;
+					while (len < maxlen) {
+						const uint32_t x = at + len + lane;
+						const uint64_t ne = __ballot(ring8[x & (HD_WG_RING - 1)] != ring8[(x - D) & (HD_WG_RING - 1)]);
+						const uint32_t adv = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
+						len = len + adv < maxlen ? len + adv : maxlen;
+						if (ne)
+							break;
 					}
-					const uint32_t k = bb + (uint32_t)__builtin_ctzll(tk);
-					starts |= ((2ull << k) - 1) & ~((1ull << bb) - 1);            // literals bb .. k - 1, the match at k
-					uint32_t len = readlane(flen, k);
-					if ((capm >> k) & 1) {
-						// a match of the whole verified span, taken: to its full length, 64 bytes per pass by all lanes
-						const uint32_t D = readlane(dist, k), at = S + k;
-						const uint32_t maxlen = pend - at < HD_MAX_MATCH ? pend - at : HD_MAX_MATCH;
-						while (len < maxlen) {
-							const uint32_t x = at + len + lane;
-							const uint64_t ne = __ballot(ring8[x & (HD_WG_RING - 1)] != ring8[(x - D) & (HD_WG_RING - 1)]);
-							const uint32_t adv = ne ? (uint32_t)__builtin_ctzll(ne) : 64u;
-							len = len + adv < maxlen ? len + adv : maxlen;
-							if (ne)
-								break;
-						}
-						// (v_writelane_b32 with the lane select in M0: the one form that may name two scalar operands)
-						asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(flen) : "s"(len), "s"(k));
-					}
-					bb = k + len;
+					// (v_writelane_b32 with the lane select in M0: the one form that may name two scalar operands)
+					asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(jmp) : "s"(len), "s"(k));
+					capt &= ~(1ull << k);
 				}
 				E = S + bb;
+				const uint32_t flen = jmp;                       // (a token's length on the lanes of `take`)
 				// ---- the step's tokens ------------------------------------------------------------------------------
 				const uint64_t long9 = __ballot(flen >= 9);
 				const uint32_t tw = sel(take, (flen << 16) + dist + (HD_TOKEN_MATCH - (3u << 16) - 1u), o0 & 0xffu);
-				if ((starts >> lane) & 1) {
+				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
-					ptok[cnt + rank] = tw;
+					uint32_t *const at = ptok + cnt + rank;
+					// (the store under exec = starts: the mask goes to exec as it is, not through a compare per lane)
+					uint64_t saved;
+					asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0"
+						     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
 				}
 				cnt += (uint32_t)__popcll(starts);
 				c_lit += (uint32_t)__popcll(starts & ~take);
