@@ -886,16 +886,45 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 			// straight-line: both forms are computed and one is selected; a token's two fields
 			// (litlen code + extra bits, offset code + extra bits: <= 20 + 28 bits) go out as
 			// one 64-bit OR over up to three dwords
+			// The emit-only kernels code the litlen half of a token with ONE lookup: after the header is out (the code
+			// construction's scratch is dead from there on) the block's code goes into a 512-entry table -- a literal's
+			// codeword, or a length's with its extra bits behind it, and the bit count in the top byte -- as the level-1
+			// kernel has it for the static code (CrcTables::SL).  Slot arithmetic + two selects per token before: ~17 of
+			// the pass's ~75 vector instructions.
+			uint32_t *const litlen_lut = Bd.hs.freq;             // 512 dwords: freq[288] and the first 224 of nf
+			static_assert(offsetof(HuffScratch, nf) == sizeof(uint32_t) * 288, "the table runs from freq into nf");
+			if (EMIT) {
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) {
+					const uint32_t i = 64 * q + lane;                // literal i, length 3 + i
+					const uint32_t lc = Bd.lcode[i];
+					litlen_lut[i] = (lc & 0xffff) | (lc >> 16 << 24);
+					uint32_t ls, leb, lev;
+					len_slot(i + 3, ls, leb, lev);
+					const uint32_t mc = Bd.lcode[257 + ls];
+					litlen_lut[256 + i] = (mc & 0xffff) | (lev << (mc >> 16)) | (((mc >> 16) + leb) << 24);
+				}
+			}
 			auto put_tokens_n = [&](uint32_t tk, uint32_t nvalid) {
 				const bool valid = lane < nvalid;
 				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
-				uint32_t ls, leb, lev, ds, deb, dev;
-				len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
+				uint32_t ca, na;
+				if (EMIT) {
+					// (the workgroup parse's tokens carry the table index in bits 16..24; the others a literal in the low byte)
+					const uint32_t idx = (!PARTS && a.wg) ? (tk >> 16) & 0x1ffu : is_match ? 256u + ((tk >> 16) & 0xffu) : tk & 0xffu;
+					const uint32_t le = litlen_lut[idx];
+					ca = le & 0xffffffu;
+					na = le >> 24;
+				} else {
+					uint32_t ls, leb, lev;
+					len_slot(((tk >> 16) & 0xff) + 3, ls, leb, lev);
+					const uint32_t lc = Bd.lcode[is_match ? 257 + ls : (tk & 0xff)];
+					ca = (lc & 0xffff) | (is_match ? lev << (lc >> 16) : 0u);
+					na = (lc >> 16) + (is_match ? leb : 0u);
+				}
+				uint32_t ds, deb, dev;
 				off_slot((tk & 0xffff) + 1, ds, deb, dev);
-				const uint32_t lc = Bd.lcode[is_match ? 257 + ls : (tk & 0xff)];
 				const uint32_t dc = Bd.dcode[ds];
-				const uint32_t ca = (lc & 0xffff) | (is_match ? lev << (lc >> 16) : 0u);
-				const uint32_t na = (lc >> 16) + (is_match ? leb : 0u);
 				const uint32_t cb = (dc & 0xffff) | (dev << (dc >> 16));
 				const uint32_t nb = is_match ? (dc >> 16) + deb : 0u;
 				const uint32_t nbits = valid ? na + nb : 0u;
@@ -1205,6 +1234,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 					uint32_t obs0 = 0, obs1 = 0, obs2 = 0, sn = 0, no0 = 0, no1 = 0, no2 = 0, snn = 0, blk_tok = 0;
 					bool end = false;
 					wg_k0 = k;
+					EMIT_T0();
 					while (k < wg_np && !end) {
 						wg_piece_load(k);
 						const uint32_t li = k - wg_base;
@@ -1239,24 +1269,38 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 					}
 					wg_k1 = k;
 					block_begin = k * HD_WG_CUT;
+					EMIT_T(4);
 					if (!alive)
 						break;
-					// the block's symbols
+					// the block's symbols: the litlen symbol of a token is one lookup (length symbols from a 256-byte table that
+				// is set up here, in scratch the code construction overwrites), the offset symbol slot arithmetic
+				{
+					uint8_t *const lsym = (uint8_t *)&Bd.hs.nf[256];
+					uint32_t w = 0;
+#pragma unroll
+					for (uint32_t q = 0; q < 4; q++) {
+						uint32_t ls, eb, ev;
+						len_slot(4 * lane + q + 3, ls, eb, ev);
+						w |= ls << (8 * q);
+					}
+					((uint32_t *)lsym)[lane] = w;
 					wg_for_tokens([&](uint32_t tk, uint32_t nv) {
+						const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
+						const uint32_t idx = (tk >> 16) & 0x1ffu;                // literal, or 256 + (length - 3)
+						const uint32_t sym = is_match ? 257u + lsym[idx & 0xffu] : idx;
+						uint32_t ds, eb, ev;
+						off_slot((tk & 0xffff) + 1, ds, eb, ev);
 						if (lane < nv) {
-							if (tk & HD_TOKEN_MATCH) {
-								uint32_t ls, ds, eb, ev;
-								len_slot(((tk >> 16) & 0xff) + 3, ls, eb, ev);
-								off_slot((tk & 0xffff) + 1, ds, eb, ev);
-								atomicAdd(&L.lf[257 + ls], 1u);
+							atomicAdd(&L.lf[sym], 1u);
+							if (is_match)
 								atomicAdd(&L.df[ds], 1u);
-							} else {
-								atomicAdd(&L.lf[tk & 0xff], 1u);
-							}
 						}
 					});
+				}
+					EMIT_T(5);
 					ntok_slab = blk_tok;
 					alive = flush_block(k == wg_np);
+					EMIT_T(6);
 				} while (alive && k < wg_np);
 			} else {
 			// the parse has been done: one flush per recorded DEFLATE block

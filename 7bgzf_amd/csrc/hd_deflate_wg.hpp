@@ -184,8 +184,9 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		hk.init(2 * HD_WG_BUCKETS);                // byte offset of an 8-byte bucket: 4 * (2 * slot)
 		hk.m = 0xfff8u;
 		WG_LDS uint8_t *const tab8 = (WG_LDS uint8_t *)Lp->table;
-		uint32_t k96;
+		uint32_t k96, kfffc;
 		asm volatile("s_movk_i32 %0, 96" : "=s"(k96));            // (an SGPR on purpose: VOP3 takes no literal)
+		asm volatile("v_mov_b32 %0, 0xfffc" : "=v"(kfffc));        // (a VGPR on purpose: SDWA takes no literal)
 		const uint8_t *const ring8 = (const uint8_t *)L.ring32;
 		// Pieces are handed out by a counter, not dealt round robin: three SIMDs carry four parsers and one carries three and
 		// the filler, and a parser that gets a larger share of its SIMD takes more pieces.  Whoever holds the lowest piece in
@@ -281,30 +282,41 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				const uint32_t room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;  // in bits (keyed lanes: p < pend)
 				const uint32_t lim = min(p, (uint32_t)HD_WG_WINDOW);
 				// the byte before (runs; only inside the step): as long as the own bytes repeat it
-				uint32_t best, dist = 1;
+				uint32_t best, dm1 = 0;                         // the best candidate's length, its distance - 1
 				{
 					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 					const uint32_t sp = __builtin_amdgcn_perm(prev, prev, 0u);      // its first byte, four times
 					const uint32_t m = wg_common_bits(o0 ^ sp, o1 ^ sp, o2 ^ sp, o3 ^ sp, room8, k96) >> 3;
 					best = sel(keyed & ~1ull, m, 0u);
 				}
-				// the bucket, newest first: the longest wins, the nearer on a tie
+				// the bucket, newest first: the longest wins, the nearer on a tie.  An entry e is a ring offset; its distance
+				// - 1 = (p - 1 - e) mod 2^16 in ONE 16-bit subtract with the entry's half picked by SDWA, and the entry is in
+				// range when that is below min(p, 32768) (distance 0 wraps to 65535)
 				const uint32_t cxt = cx[t], cyt = cy[t];
+				const uint32_t pm1 = p - 1;
 #pragma unroll
 				for (int k = 0; k < HD_WG_WAYS; k++) {
-					const uint32_t e = k == 0 ? (cxt & 0xffffu) : k == 1 ? (cxt >> 16) : k == 2 ? (cyt & 0xffffu) : (cyt >> 16);
-					const uint32_t back = (p - e) & 0xffffu;
-					const uint64_t ok = __ballot(back - 1 < lim) & keyed;
-					const uint32_t *c = L.ring32 + (e >> 2);
+					const uint32_t cw = k < 2 ? cxt : cyt;
+					uint32_t bm1, ea;
+					if (k & 1) {
+						asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(bm1) : "v"(pm1), "v"(cw));
+						asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(ea) : "v"(cw), "v"(kfffc));
+					} else {
+						asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(bm1) : "v"(pm1), "v"(cw));
+						asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(ea) : "v"(cw), "v"(kfffc));
+					}
+					const uint64_t ok = __ballot(bm1 < lim) & keyed;
+					const uint32_t *c = (const uint32_t *)((const uint8_t *)L.ring32 + ea);
 					const uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
-					const uint32_t cs = e;
+					const uint32_t cs = (k & 1) ? cw >> 16 : cw;          // (v_alignbyte_b32 reads bits [1:0] of its shift)
 					const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, cs) ^ o0, x1 = __builtin_amdgcn_alignbyte(c2, c1, cs) ^ o1,
 						       x2 = __builtin_amdgcn_alignbyte(c3, c2, cs) ^ o2, x3 = __builtin_amdgcn_alignbyte(c4, c3, cs) ^ o3;
 					const uint32_t m = wg_common_bits(x0, x1, x2, x3, room8, k96) >> 3;
 					const uint64_t better = __ballot(m > best) & ok;
 					best = sel(better, m, best);
-					dist = sel(better, back, dist);
+					dm1 = sel(better, bm1, dm1);
 				}
+				const uint32_t dist = dm1 + 1;
 				const uint64_t candm = __ballot(best >= HD_WG_MIN_LEN) & lanem;
 				const uint32_t clen = sel(candm, best, 0u);
 				// ---- the lazy rule on the lane to the right (deflate_compress.c:2723-2726, lengths capped at 16) ------
@@ -385,7 +397,11 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				const uint32_t flen = jmp;                       // (a token's length on the lanes of `take`)
 				// ---- the step's tokens ------------------------------------------------------------------------------
 				const uint64_t long9 = __ballot(flen >= 9);
-				const uint32_t tw = sel(take, (flen << 16) + dist + (HD_TOKEN_MATCH - (3u << 16) - 1u), o0 & 0xffu);
+				// token words: bits 16..24 are the index into the emit kernel's litlen table -- a literal's byte, or
+				// 256 + (length - 3) (HD_TOKEN_MATCH_TAG) -- and a match carries its distance - 1 below
+				uint32_t litw;
+				asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(litw) : "v"(16u), "v"(o0));
+				const uint32_t tw = sel(take, (flen << 16) + dm1 + (HD_TOKEN_MATCH_TAG - (3u << 16)), litw);
 				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
 					uint32_t *const at = ptok + cnt + rank;

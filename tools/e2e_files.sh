@@ -26,6 +26,24 @@ for T in 4 8 16; do
     python3 -c "print('hd7bgzf -G$L -@$T file-to-file: %.3f s  %.2f GB/s in' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
   done
 done
+# decode, file to file (the level-1 file of the last run above is level 6's: make the level-1 one again)
+run_files 1 8
+for T in 4 16; do
+  t0=$(date +%s.%N); ./7bgzf_amd/hd7bgzf -d -@$T -i $D/out.bgz -o $D/back.bin 2>> $OUT/e2e_stderr.txt; t1=$(date +%s.%N)
+  python3 -c "print('hd7bgzf -d -@$T file-to-file: %.3f s  %.2f GB/s out' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
+done
+cmp $D/back.bin $D/in.bin && echo "decode output == input" >> $OUT/e2e_files.txt
+rm -f $D/back.bin
+# a 256 MiB file: what the start-up costs (context, pinning)
+head -c $((256<<20)) $D/in.bin > $D/in256.bin
+for L in 1 6; do
+  t0=$(date +%s.%N); ./7bgzf_amd/hd7bgzf -G$L -@8 -i $D/in256.bin -o $D/out256.bgz 2>> $OUT/e2e_stderr.txt; t1=$(date +%s.%N)
+  python3 -c "print('hd7bgzf -G$L -@8 256 MiB file-to-file: %.3f s  %.2f GB/s in' % ($t1-$t0, (256<<20)/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
+done
+t0=$(date +%s.%N); ./7bgzf_amd/hd7bgzf -d -@8 -i $D/out256.bgz -o $D/back256.bin 2>> $OUT/e2e_stderr.txt; t1=$(date +%s.%N)
+python3 -c "print('hd7bgzf -d -@8 256 MiB file-to-file: %.3f s  %.2f GB/s out' % ($t1-$t0, (256<<20)/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
+cmp $D/back256.bin $D/in256.bin && echo "256 MiB decode output == input" >> $OUT/e2e_files.txt
+rm -f $D/in256.bin $D/out256.bgz $D/back256.bin
 t0=$(date +%s.%N); run_filter; t1=$(date +%s.%N)
 python3 -c "print('hd7bgzf -G1 filter (stdin/stdout): %.3f s  %.2f GB/s in' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
 run_files 1 8; cmp $D/out.bgz $D/out2.bgz && echo "file-to-file output == filter output" >> $OUT/e2e_files.txt

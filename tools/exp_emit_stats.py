@@ -3,7 +3,7 @@ make -C 7bgzf_amd/csrc EXTRA=-DHD_EMIT_STATS.  usage: python tools/exp_emit_stat
 import ctypes, importlib, sys, runpy
 sys.path.insert(0, '.')
 extra = sys.argv[1:]
-sys.argv = ["bench.py", "--no-cpu", "--gib", "2", "--steps", "1", "--warmup", "0", "--level", "2"] + extra
+sys.argv = ["bench.py", "--no-cpu", "--no-extra", "--gib", "2", "--steps", "1", "--warmup", "0", "--level", "2"] + extra
 try:
     runpy.run_path("bench.py", run_name="__main__")
 except SystemExit:
@@ -15,3 +15,6 @@ names = ["build litlen+offset codes", "lens copy + RLE (lane 0)", "precode, cost
 v = [int(x) for x in out]
 # marks 1..3 are cumulative from the same start (EMIT_T0 after the code construction)
 print({"build_codes": v[0], "rle_lane0": v[1], "precode_costs_header": v[2] - v[1], "tokens": v[3] - v[2]})
+# the workgroup records (levels >= 6): marks 4..6 are cumulative from the start of a DEFLATE block
+if v[6]:
+    print({"wg_cut_scan": v[4], "wg_symbol_count_pass": v[5] - v[4], "wg_flush_block": v[6] - v[5], "wg_total": v[6]})

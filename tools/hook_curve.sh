@@ -25,6 +25,12 @@ if [ -x oracle/_ref/hook_bench_ref ] && [ "$2" != quick ]; then
     BGZF_METHOD=libdeflate1 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin $T 2 >> $OUT/hook_curve.jsonl
   done
   BGZF_METHOD=libdeflate6 ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin 16 2 >> $OUT/hook_curve.jsonl
+  # the reference's DEFAULT (BGZF_METHOD unset = its zlib at level 6, bgzf_compress.c:54,102): what an unset variable replaces;
+  # beside it ours with the variable unset (hip level 6)
+  for T in 8 16 64; do
+    env -u BGZF_METHOD ./oracle/_ref/hook_bench_ref /tmp/hook_fq.bin $T 2 | sed 's/"method": ""/"method": "(unset: reference zlib6)"/' >> $OUT/hook_curve.jsonl
+    env -u BGZF_METHOD ./7bgzf_amd/hook_bench /tmp/hook_fq.bin $T 2 | sed 's/"method": ""/"method": "(unset: hip6)"/' >> $OUT/hook_curve.jsonl
+  done
 fi
 cat $OUT/hook_curve.jsonl
 cat $OUT/hook_stats.txt

@@ -22,6 +22,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if "hd::" not in r["Kernel_Name"]:
                 continue
+            if "--mode decode" not in args and "k_inflate" in r["Kernel_Name"]:
+                continue                      # bench.py's untimed full-size verification of an encode run, not the step
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if c == "FETCH_SIZE":
@@ -32,7 +34,7 @@ fetch = sum(v["FETCH_SIZE_KiB"] for v in kern.values()) * 1024
 write = sum(v["WRITE_SIZE_KiB"] for v in kern.values()) * 1024
 res = {"config": name, "bench_args": args, "input_bytes": line["config"].get("input_bytes_per_gpu"), "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
        "fetch_bytes_raw": fetch, "fetch_bytes_doubled": 2 * fetch, "write_bytes": write,
-       "hbm_bytes_per_launch": 2 * fetch + write, "kernels": kern,
+       "hbm_bytes_per_launch": 2 * fetch + write, "hbm_bytes_per_launch_fetch_as_counted": fetch + write, "kernels": kern,
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over one bench.py step (--steps 1 --warmup 0); KiB units; "
                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (exact for 16-B-per-lane streaming reads; dword reads -- token slabs, far-match "
                  "sources -- are uncalibrated and over-counted by the doubling); WRITE_SIZE as is"}
