@@ -1398,12 +1398,12 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA, DEEP>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
 }
 
-void launch_wg(const DeflateArgs &a, hipStream_t st);       // hd_deflate_wg.hpp
+void launch_wg(const DeflateArgs &a, int level, hipStream_t st);       // hd_deflate_wg.hpp
 
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
 	if (level >= HD_WG_LEVEL && !a.parts) {              // the workgroup levels: one workgroup per block, then the emit-only kernel
-		launch_wg(a, st);
+		launch_wg(a, level, st);
 		return 0;
 	}
 	if (level == 2)

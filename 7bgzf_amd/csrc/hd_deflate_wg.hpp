@@ -39,11 +39,12 @@ constexpr uint32_t WG_AHEAD = 24;                // pieces the ring is filled ah
                                                  // parser reads up to 32 pieces behind its own, so anything below 32 is safe
 constexpr uint32_t WG_SPIN_LIMIT = 1u << 20;     // a turn that does not come: the block is given up (stored), never a hang
 static_assert(HD_WG_CUT == HD_PIECE && WG_STEPS == 16, "a piece of the parse is a piece of the ring");
-static_assert(HD_WG_RING == 65536 && HD_WG_WINDOW == 32768 && HD_WG_WAYS == 4 && HD_WG_VCAP == 16, "the kernel is written for this geometry");
+static_assert(HD_WG_RING == 65536 && HD_WG_WINDOW == 32768 && HD_WG_VCAP == 16, "the kernel is written for this geometry");
+constexpr uint32_t WG_TABLE_BYTES = 65536;      // ways x buckets x 2 at every level
 
 struct WgLds {
 	__attribute__((aligned(16))) uint32_t ring32[HD_WG_RING / 4 + 8];      // + 32 bytes that mirror the start: unaligned reads never wrap
-	__attribute__((aligned(16))) uint32_t table[HD_WG_BUCKETS * HD_WG_WAYS / 2 + 2];   // p mod 2^16 x 4 per bucket, newest first (+ a spare bucket)
+	__attribute__((aligned(16))) uint32_t table[WG_TABLE_BYTES / 4 + 2];   // p mod 2^16 x WAYS per bucket, newest first (+ a spare bucket)
 	uint32_t turn;                         // the piece whose table accesses may run
 	uint32_t filled;                       // pieces in the ring
 	uint32_t fail;
@@ -101,8 +102,11 @@ __device__ __forceinline__ uint64_t wg_uniform64(uint64_t v)
 	return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
 }
 
+// WAYS: positions per bucket = candidates verified per position (1, 2 or 4); LAZY: the lazy rule (else greedy)
+template <int WAYS, int LAZY>
 __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 {
+	static_assert(WAYS == 1 || WAYS == 2 || WAYS == 4, "a bucket is 2, 4 or 8 bytes");
 	__shared__ WgLds L;
 	const uint32_t lane = threadIdx.x & 63, w = uniform(threadIdx.x >> 6);      // (the compiler must know that w is one value per wavefront)
 	const uint32_t bi = blockIdx.x, b = a.first + bi;
@@ -120,13 +124,13 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	const uint32_t npieces = (n + HD_WG_CUT - 1) / HD_WG_CUT;
 
 	// ---- LDS: the table zero, the words ------------------------------------------------------------------------------
-	for (uint32_t i = threadIdx.x; i < HD_WG_BUCKETS * HD_WG_WAYS / 8; i += 64 * WG_NW)
+	for (uint32_t i = threadIdx.x; i < WG_TABLE_BYTES / 16; i += 64 * WG_NW)
 		((uint4 *)L.table)[i] = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < WG_NW)
 		L.cur[threadIdx.x] = 0xffffffffu;
 	if (threadIdx.x == 0) {
 		L.turn = L.filled = L.fail = L.next = 0;
-		L.table[HD_WG_BUCKETS * HD_WG_WAYS / 2] = L.table[HD_WG_BUCKETS * HD_WG_WAYS / 2 + 1] = 0;
+		L.table[WG_TABLE_BYTES / 4] = L.table[WG_TABLE_BYTES / 4 + 1] = 0;
 	}
 	__syncthreads();
 
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	} else {
 		// ================= a parser =======================================================================================
 		HashConsts6 hk;
-		hk.init(2 * HD_WG_BUCKETS);                // byte offset of an 8-byte bucket: 4 * (2 * slot)
-		hk.m = 0xfff8u;
+		hk.init(WG_TABLE_BYTES / 4);               // byte offset of a bucket of 2 WAYS bytes: (2 WAYS) * slot, below 64 KiB
+		hk.m = 0x10000u - 2 * WAYS;
 		WG_LDS uint8_t *const tab8 = (WG_LDS uint8_t *)Lp->table;
 		uint32_t k96, kfffc;
 		asm volatile("s_movk_i32 %0, 96" : "=s"(k96));            // (an SGPR on purpose: VOP3 takes no literal)
@@ -229,16 +233,29 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				break;
 			__builtin_amdgcn_s_setprio(3);
 			wg_u32x16 cx, cy;
+			// one step's buckets: read, { itself, the WAYS - 1 newest before } written back; of the lanes of a step that share
+			// a bucket the HIGHEST keeps each store (the LDS-order probe of ctx_init checks ds_write_b16 / b32), so a bucket of
+			// eight bytes is two dword stores, both that lane's
+			auto bucket = [&](uint32_t h, uint32_t p, uint32_t &ox, uint32_t &oy) {
+				if (WAYS == 4) {
+					const unsigned long long o64 = *(WG_LDS const volatile unsigned long long *)(tab8 + h);   // ds_read_b64
+					ox = (uint32_t)o64;
+					oy = (uint32_t)(o64 >> 32);
+					*(wg_word_p)(tab8 + h) = (ox << 16) | (p & 0xffffu);
+					*(wg_word_p)(tab8 + h + 4) = __builtin_amdgcn_alignbit(oy, ox, 16);
+				} else if (WAYS == 2) {
+					ox = *(wg_word_p)(tab8 + h);
+					*(wg_word_p)(tab8 + h) = (ox << 16) | (p & 0xffffu);
+				} else {
+					ox = *(volatile WG_LDS uint16_t *)(tab8 + h);
+					*(volatile WG_LDS uint16_t *)(tab8 + h) = (uint16_t)p;
+				}
+			};
 			if (all_keyed) {
 #pragma unroll
 				for (int t = 0; t < (int)WG_STEPS; t++) {
-					const uint32_t p = P0 + 64 * t + lane;
-					const unsigned long long o64 = *(WG_LDS const volatile unsigned long long *)(tab8 + ha[t]);   // ds_read_b64
-					const uint32_t ox = (uint32_t)o64, oy = (uint32_t)(o64 >> 32);
-					// two dword stores, not one of eight bytes: of the lanes of a step that share a bucket the HIGHEST keeps
-					// each store (the LDS-order probe of ctx_init checks ds_write_b32), so both halves are that lane's
-					*(wg_word_p)(tab8 + ha[t]) = (ox << 16) | (p & 0xffffu);
-					*(wg_word_p)(tab8 + ha[t] + 4) = __builtin_amdgcn_alignbit(oy, ox, 16);
+					uint32_t ox = 0, oy = 0;
+					bucket(ha[t], P0 + 64 * t + lane, ox, oy);
 					cx[t] = ox;
 					cy[t] = oy;
 				}
@@ -247,13 +264,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				for (int t = 0; t < (int)WG_STEPS; t++) {
 					const uint32_t p = P0 + 64 * t + lane;
 					uint32_t ox = 0, oy = 0;
-					if (p + HD_LAZY_KEY_BYTES <= n) {
-						const unsigned long long o64 = *(WG_LDS const volatile unsigned long long *)(tab8 + ha[t]);
-						ox = (uint32_t)o64;
-						oy = (uint32_t)(o64 >> 32);
-						*(wg_word_p)(tab8 + ha[t]) = (ox << 16) | (p & 0xffffu);
-						*(wg_word_p)(tab8 + ha[t] + 4) = __builtin_amdgcn_alignbit(oy, ox, 16);
-					}
+					if (p + HD_LAZY_KEY_BYTES <= n)
+						bucket(ha[t], p, ox, oy);
 					cx[t] = ox;
 					cy[t] = oy;
 				}
@@ -292,10 +304,10 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				// the bucket, newest first: the longest wins, the nearer on a tie.  An entry e is a ring offset; its distance
 				// - 1 = (p - 1 - e) mod 2^16 in ONE 16-bit subtract with the entry's half picked by SDWA, and the entry is in
 				// range when that is below min(p, 32768) (distance 0 wraps to 65535)
-				const uint32_t cxt = cx[t], cyt = cy[t];
+				const uint32_t cxt = cx[t], cyt = WAYS == 4 ? cy[t] : 0u;
 				const uint32_t pm1 = p - 1;
 #pragma unroll
-				for (int k = 0; k < HD_WG_WAYS; k++) {
+				for (int k = 0; k < WAYS; k++) {
 					const uint32_t cw = k < 2 ? cxt : cyt;
 					uint32_t bm1, ea;
 					if (k & 1) {
@@ -320,10 +332,13 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				const uint64_t candm = __ballot(best >= HD_WG_MIN_LEN) & lanem;
 				const uint32_t clen = sel(candm, best, 0u);
 				// ---- the lazy rule on the lane to the right (deflate_compress.c:2723-2726, lengths capped at 16) ------
-				const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-				const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)dist, 0x130, 0xf, 0xf, false);
-				const int gain = 4 * ((int)clen_r - (int)clen) + ((int)__clz(dist_r | 1) - (int)__clz(dist | 1));
-				const uint64_t defer = __ballot(clen_r >= clen) & __ballot(gain > 2) & candm & (lanem >> 1);
+				uint64_t defer = 0;
+				if (LAZY) {
+					const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+					const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)dist, 0x130, 0xf, 0xf, false);
+					const int gain = 4 * ((int)clen_r - (int)clen) + ((int)__clz(dist_r | 1) - (int)__clz(dist | 1));
+					defer = __ballot(clen_r >= clen) & __ballot(gain > 2) & candm & (lanem >> 1);
+				}
 				const uint64_t take = candm & ~defer;
 				// matches of the whole verified span are extended when the walk takes them
 				uint64_t capt = __ballot(best == HD_WG_VCAP) & take;
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 }
 
 // blocks [first, first + count) of a sub-batch: the workgroup parse, then the emit-only kernel over its records
-inline void launch_wg(const DeflateArgs &a, hipStream_t st)
+inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t sub = wg_sub_batch(a.nblocks, a.split_max);
 	DeflateArgs s = a;
@@ -439,7 +454,15 @@ inline void launch_wg(const DeflateArgs &a, hipStream_t st)
 	for (uint32_t first = 0; first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
-		hipLaunchKernelGGL(k_parse_wg, dim3(s.count), dim3(64 * HD_WG_WAVES), 0, st, s);
+		const dim3 grid(s.count), block(64 * HD_WG_WAVES);
+		if (HD_WG_WAYS(level) == 4)
+			hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, 0, st, s);
+		else if (HD_WG_WAYS(level) == 2)
+			hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, 0, st, s);
+		else if (HD_WG_LAZY(level))
+			hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, 0, st, s);
+		else
+			hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, 0, st, s);
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0, st, s);
 	}

@@ -542,10 +542,15 @@ class Bench:
 
 
 def level_name(level):
-    return ("level %d: greedy LZ77 + static Huffman" % level) if level == 1 else \
-        ("level %d: %s LZ77 + dynamic Huffman" % (level, "lazy (workgroup-shared 32 KiB window, 8192 x 4-way table, block splitting)" if level >= 6 else
-                                                   "lazy (one-way)" if level == 5 else "greedy")) if level >= 2 \
-        else "level 0: stored"
+    if level <= 0:
+        return "level 0: stored"
+    if level == 1:
+        return "level 1: greedy LZ77 + static Huffman"
+    if level == 2:
+        return "level 2: greedy LZ77 (one wavefront's 4 KiB window) + dynamic Huffman"
+    ways = 4 if level >= 6 else 2 if level == 5 else 1
+    return "level %d: %s LZ77 (workgroup-shared 32 KiB window, %d x %d-way table, block splitting) + dynamic Huffman" % (
+        level, "lazy" if level >= 4 else "greedy", 32768 // ways, ways)
 
 
 def summary(res, steps, world=1, mode="encode"):
@@ -649,7 +654,7 @@ def main():
                        if args.mode == "encode" else "inflate kernel",
                        "stream": args.stream if args.mode == "decode" else None},
             "roofline": {"bound": "hbm", "kernel": "k_deflate_static" if args.mode == "encode" and level <= 1
-                         else ("k_parse_wg (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" and level >= 6 else
+                         else ("k_parse_wg (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" and level >= 3 else
                                "k_deflate_static<TOK> (parse) + k_deflate_dynamic<EMIT>" if args.mode == "encode" else "k_inflate"),
                          "achieved": s["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": s["frac"], "traffic": traffic, "traffic_source": traffic_source,
@@ -759,10 +764,9 @@ def main():
                 return out
             return run
         note("migz_l6_text", migz(6))
-        # level 5 = the one-way lazy parse (round 2's level 6): the speed end of the same trade; level 9 = the ratio end
-        # (the reference's 32 KiB window)
+        # levels 5 and 3: the same workgroup parse with two ways / one way, greedy (the speed end of the trade)
         note("migz_l5_text", migz(5))
-        note("migz_l9_text", migz(9))
+        note("migz_l3_text", migz(3))
         line["configs"] = configs
 
     if rank == 0:

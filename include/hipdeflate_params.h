@@ -123,24 +123,34 @@
  * with what a whole CU's LDS holds instead of one wavefront's share of it:
  *   window   DEFLATE's 32 KiB, in a 64 KiB ring (positions are ring offsets; a table entry is p mod 2^16 -- no entry is
  *            "empty": a zeroed or stale one names some position 1..32768 bytes back or is out of range, and the bytes there decide);
- *   table    HD_WG_BUCKETS buckets of HD_WG_WAYS positions, newest first, six-byte key (HD_HASH_SLOT6).  A step's lanes read
+ *   table    HD_WG_BUCKETS(level) buckets of HD_WG_WAYS(level) positions, newest first, six-byte key (HD_HASH_SLOT6).  A step's lanes read
  *            their buckets as the steps before left them; of the lanes of a step that share a bucket the highest stores
- *            { itself, the three newest before the step };
- *   verify   every candidate -- the byte before the position, if the lane has one in its step (runs), then the four of the
+ *            { itself, the ways - 1 newest before the step };
+ *   verify   every candidate -- the byte before the position, if the lane has one in its step (runs), then those of the
  *            bucket -- over HD_WG_VCAP bytes; the longest wins, the nearer on a tie; a match of HD_WG_VCAP bytes is extended to
  *            its full length (<= 258); minimum length HD_WG_MIN_LEN; NO MATCH CROSSES A MULTIPLE OF HD_WG_CUT (a "piece"):
  *            the parse of a piece depends on nothing but the table, so the pieces of a block are parsed side by side, one
  *            wavefront each, and only the table accesses take turns (cut = 1024 costs 0.2 % of the output, tools/mf_explore.c);
- *   lazy     libdeflate's rule (deflate_compress.c:2723-2726) on the lane to the right, with the lengths capped at HD_WG_VCAP:
+ *   lazy     (HD_WG_LAZY(level)) libdeflate's rule (deflate_compress.c:2723-2726) on the lane to the right, with the lengths capped at HD_WG_VCAP:
  *            a match steps aside when 4 (len' - len) + log2(dist) - log2(dist') > 2 for its neighbour's match;
  *   blocks   a DEFLATE block ends at a piece boundary once it holds HD_DYN_BLOCK_TOKENS tokens, or when the token mix has
  *            shifted: libdeflate's observation test (deflate_compress.c:2141-2218) over three classes -- literal, match
  *            below 9 bytes, longer match --, checked every HD_WG_SPLIT_OBS tokens, blocks of at least HD_WG_SPLIT_MIN bytes;
  *   long blocks (MiGz members) are ONE stream with the window sliding through them: no segments.
  * tools/mf_explore.c is the CPU model this geometry was chosen with. */
-#define HD_WG_LEVEL        6
-#define HD_WG_BUCKETS      8192u
-#define HD_WG_WAYS         4
+/* The ladder of the workgroup levels is a ladder of WAYS -- candidates verified per position, the kernel's unit of work --
+ * over the same 64 KiB of table (ways x buckets x 2 bytes):
+ *   level 3      1 way  x 32768 buckets, greedy      (libdeflate-2's ratio class on every set; libdeflate-1 beaten)
+ *   level 4      1 way  x 32768 buckets, lazy
+ *   level 5      2 ways x 16384 buckets, lazy
+ *   levels 6..9  4 ways x  8192 buckets, lazy        (1.029 / 1.012 / 1.023 of libdeflate-6)
+ * Rounds 1-3 ran levels 3..5 in one wavefront's share of LDS (4..8 KiB windows, 1536..2560 entries): 1.12 .. 1.19 of
+ * libdeflate-6 on text. */
+#define HD_WG_LEVEL        3
+#define HD_WG_WAYS(level)    ((level) >= 6 ? 4u : (level) == 5 ? 2u : 1u)
+#define HD_WG_BUCKETS(level) (32768u / HD_WG_WAYS(level))
+#define HD_WG_LAZY(level)    ((level) >= 4)
+#define HD_WG_MAX_WAYS     4
 #define HD_WG_WINDOW       32768u
 #define HD_WG_RING         65536u
 #define HD_WG_VCAP         16u

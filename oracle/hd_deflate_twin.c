@@ -761,19 +761,21 @@ static int wg_split_check(wg_split_t *s, uint32_t block_len)
 	return 0;
 }
 
-static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n, int flush)
+static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n, int flush, int level)
 {
+	const unsigned WAYS = HD_WG_WAYS(level), BUCKETS = HD_WG_BUCKETS(level);
+	const int lazy = HD_WG_LAZY(level);
 	const size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	const size_t stored = HD_STORED_SIZE(n);
 	const size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + 64 + 8);
-	uint16_t *bk = calloc((size_t)HD_WG_BUCKETS * HD_WG_WAYS, 2);
+	uint16_t *bk = calloc((size_t)BUCKETS * WAYS, 2);
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
 	wg_split_t sp;
 	int alive = 1;
 	uint32_t clen[HD_WAVE], flen[HD_WAVE], dist[HD_WAVE];
-	uint16_t pre[HD_WAVE][HD_WG_WAYS];
+	uint16_t pre[HD_WAVE][HD_WG_MAX_WAYS];
 	size_t E = 0, block_begin = 0;
 
 	memset(&b, 0, sizeof(b));
@@ -786,18 +788,18 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			const size_t p = S + l;
 			memset(pre[l], 0, sizeof(pre[l]));
 			if (p + HD_LAZY_KEY_BYTES <= n)
-				memcpy(pre[l], bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), HD_WG_BUCKETS) * HD_WG_WAYS,
-				       sizeof(pre[l]));
+				memcpy(pre[l], bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), BUCKETS) * WAYS,
+				       2 * WAYS);
 		}
 		/* 2. ... and stores { itself, the three newest before the step }: in lane order, so the highest lane's store stays */
 		for (unsigned l = 0; l < lanes; l++) {
 			const size_t p = S + l;
 			if (p + HD_LAZY_KEY_BYTES > n)
 				continue;
-			uint16_t *e = bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), HD_WG_BUCKETS) * HD_WG_WAYS;
+			uint16_t *e = bk + (size_t)HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), BUCKETS) * WAYS;
 			e[0] = (uint16_t)p;             /* the position mod 2^16 = its offset in the 64 KiB ring; nothing marks an entry
 			                                 * empty: whatever it holds names a position, and the bytes there decide */
-			for (unsigned k = 1; k < HD_WG_WAYS; k++)
+			for (unsigned k = 1; k < WAYS; k++)
 				e[k] = pre[l][k - 1];
 		}
 		/* 3. verify: the byte before (runs; only inside the step), then the bucket, newest first; longest wins, nearest on a tie */
@@ -813,7 +815,7 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			clen[l] = flen[l] = dist[l] = 0;
 			if (p + HD_LAZY_KEY_BYTES > n)
 				continue;
-			for (unsigned k = 0; k <= HD_WG_WAYS; k++) {
+			for (unsigned k = 0; k <= WAYS; k++) {
 				uint32_t back;
 				if (k == 0) {
 					if (l == 0)
@@ -854,7 +856,7 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 			if (p < E)
 				continue;
 			int take = clen[l] != 0;
-			if (take && l + 1 < lanes && clen[l + 1] >= clen[l] && clen[l + 1] &&
+			if (take && lazy && l + 1 < lanes && clen[l + 1] >= clen[l] && clen[l + 1] &&
 			    4 * ((int)clen[l + 1] - (int)clen[l]) + ((int)ilog2(dist[l]) - (int)ilog2(dist[l + 1])) > 2)
 				take = 0;
 			if (take) {
@@ -956,7 +958,7 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_LAT_SEG_BYTES(level));
 	if (level >= HD_WG_LEVEL && !part)      /* the workgroup levels take a block of any length as one stream (a latency
 	                                         * segment parsed in parts keeps the two-way tables of its part wavefronts) */
-		return deflate_wg(dest, destLen, source, sourceLen, flush);
+		return deflate_wg(dest, destLen, source, sourceLen, flush, level);
 	if (level >= 1 && sourceLen > HD_SEG_LIMIT)
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_SEG_BYTES);
 	if (level <= 0)

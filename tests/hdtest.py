@@ -278,6 +278,12 @@ RATIO_BOUNDS = {
     # 0.974 / 0.989 / 0.995 of it) and clearly beat its level 1 (0.969 / 0.951 / 0.955) on every set
     (6, "libdeflate2"): {"fastq/65280": 0.98, "text/65280": 0.995, "text/1048576": 1.00},
     (6, "libdeflate1"): {"fastq/65280": 0.97, "text/65280": 0.955, "text/1048576": 0.96},
+    # Round 4, later: levels 3..5 are the same workgroup parse with fewer ways (3: one way, greedy; 4: one way, lazy; 5: two
+    # ways) -- measured 1.057 / 1.034 / 1.044 (level 3) and 1.038 / 1.019 / 1.030 (level 5) of libdeflate-6: level 3 already
+    # beats the reference's level 1 on every set (0.996 / 0.971 / 0.975 of it), level 5 its level 2 but for 0.2 % on 1 MiB text
+    (3, "libdeflate1"): {"fastq/65280": 1.00, "text/65280": 0.975, "text/1048576": 0.98},
+    (5, "libdeflate2"): {"fastq/65280": 0.985, "text/65280": 0.997, "text/1048576": 1.005},
+    (5, "libdeflate6"): {"fastq/65280": 1.04, "text/65280": 1.02, "text/1048576": 1.032},
     # (levels 7..9 are level 6's parse in the throughput form; against libdeflate-9: 1.054 / 1.027 / 1.044)
     (9, "libdeflate9"): {"fastq/65280": 1.055, "text/65280": 1.03, "text/1048576": 1.045},
 }
