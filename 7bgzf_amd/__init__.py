@@ -27,7 +27,7 @@ DEFLATE_HIP = 11
 HD_E_NODEVICE, HD_E_ARG, HD_E_NOMEM = 100, 101, 102
 
 BGZF_BLOCK = 0xff00          # applet/7bgzf.c:146-147, htslib BGZF_BLOCK_SIZE
-WG_LEVEL = 6                 # include/hipdeflate_params.h HD_WG_LEVEL: levels >= this are the workgroup parse (one stream per block)
+WG_LEVEL = 3                 # include/hipdeflate_params.h HD_WG_LEVEL: levels >= this are the workgroup parse (one stream per block)
 BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 

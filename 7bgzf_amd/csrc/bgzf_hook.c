@@ -367,10 +367,15 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 					t_last = t;
 				}
 				/* (while g_max_inflight batches are out the window stays open -- 2 ms at most, should one hang) */
-				if ((t >= deadline || t - t_last >= g_linger_us * 1000) &&
-				    (__atomic_load_n(&g_inflight, __ATOMIC_RELAXED) < g_max_inflight || t >= hard))
+				const int full = __atomic_load_n(&g_inflight, __ATOMIC_RELAXED) >= g_max_inflight;
+				if ((t >= deadline || t - t_last >= g_linger_us * 1000) && (!full || t >= hard))
 					break;
-				cpu_relax();
+				/* with every device slot taken and more callers than CPUs, the leaders in flight and the HIP runtime's
+				 * thread need this CPU more than a spinning window does */
+				if (full && __atomic_load_n(&g_active, __ATOMIC_RELAXED) + 1 >= g_ncpu)
+					sched_yield();
+				else
+					cpu_relax();
 			}
 		}
 		pthread_mutex_lock(&g_mu);
