@@ -37,7 +37,8 @@ constexpr uint32_t WG_STEPS = HD_WG_CUT / 64;
 constexpr uint32_t WG_AHEAD = 24;                // pieces the ring is filled ahead of the oldest piece in work (or of the table
                                                  // turn, whichever is older): piece k takes the place of piece k - 64 and a
                                                  // parser reads up to 32 pieces behind its own, so anything below 32 is safe
-constexpr uint32_t WG_SPIN_LIMIT = 1u << 20;     // a turn that does not come: the block is given up (stored), never a hang
+constexpr uint32_t WG_SPIN_LIMIT = 1u << 16;     // a turn that does not come (~40 ms of polls where a wait is microseconds): the block is
+                                                 // given up (stored), never a hang
 static_assert(HD_WG_CUT == HD_PIECE && WG_STEPS == 16, "a piece of the parse is a piece of the ring");
 static_assert(HD_WG_RING == 65536 && HD_WG_WINDOW == 32768 && HD_WG_VCAP == 16, "the kernel is written for this geometry");
 constexpr uint32_t WG_TABLE_BYTES = 65536;      // ways x buckets x 2 at every level
@@ -229,8 +230,10 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				ha[t] = hash_slot_addr6(v, vh, hk);
 			}
 			// ---- the turn: 16 steps of buckets, in order --------------------------------------------------------------
+#ifndef HD_WG_EXP_NO_TURN                           /* experiment (timing only: the bytes then depend on the race): no table turn */
 			if (!wg_wait(vturn, j, vfail))
 				break;
+#endif
 			__builtin_amdgcn_s_setprio(3);
 			wg_u32x16 cx, cy;
 			// one step's buckets: read, { itself, the WAYS - 1 newest before } written back; of the lanes of a step that share

@@ -3,7 +3,7 @@ set -e
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/exp_wg; mkdir -p $O
-for V in "base" "static:-DHD_WG_EXP_STATIC_DEAL" $HD_WG_VARIANTS; do
+for V in ${HD_WG_VARIANTS:-base static:-DHD_WG_EXP_STATIC_DEAL}; do
   name=${V%%:*}; flags=""; [ "$V" != "$name" ] && flags=${V#*:}
   (cd 7bgzf_amd/csrc && rm -f hd_api.o && make EXTRA="$flags" ../libhipdeflate.so > $O/build_$name.log 2>&1) || { tail -5 $O/build_$name.log; exit 1; }
   for cfg in "migz6 --data text --block-kib 1024" "bgzf6 " "bgzf6_text --data text"; do

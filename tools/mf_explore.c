@@ -15,7 +15,7 @@
 #include <stdio.h>
 
 typedef struct {
-	unsigned win_bits, buckets, ways, key, G, intra, vcap, minlen, lazy, adapt, split, seg, prime, toks, h3, far5, ins_all, k2, b2, lazyd, cut, splitg;
+	unsigned win_bits, buckets, ways, key, G, intra, vcap, minlen, lazy, adapt, split, seg, prime, toks, h3, far5, ins_all, k2, b2, lazyd, cut, splitg, rr;
 } cfg_t;
 
 static uint32_t hash_key(const uint8_t *p, unsigned key, unsigned buckets)
@@ -136,7 +136,7 @@ static int code_segment(bw_t *w, const uint8_t *in, size_t n, size_t prime, cons
 				unsigned m = 0;
 				while (m < room && base[p + m] == base[q + m])
 					m++;
-				if (m > best) {                         /* newest first: an older one only when strictly longer */
+				if (m > best || (c->rr && m == best && m && (uint32_t)(p - q) < bd)) {   /* newest first: an older one only when strictly longer (rr: the ways are in no order, the nearer wins a tie) */
 					best = m;
 					bd = (uint32_t)(p - q);
 				}
@@ -159,8 +159,12 @@ static int code_segment(bw_t *w, const uint8_t *in, size_t n, size_t prime, cons
 						last = 0;
 			if (last) {
 				uint32_t *e = bk + (size_t)hb * W;
-				memmove(e + 1, e, (W - 1) * 4);
-				e[0] = (uint32_t)(p + 1);
+				if (c->rr) {                            /* rr: the way is the step's number mod W -- a store that needs no read */
+					e[(S / G) % W] = (uint32_t)(p + 1);
+				} else {
+					memmove(e + 1, e, (W - 1) * 4);
+					e[0] = (uint32_t)(p + 1);
+				}
 			}
 			if (h3)
 				h3[((base[p] | base[p + 1] << 8 | base[p + 2] << 16) * 0x9E3779B1u) >> 17] = (uint32_t)(p + 1);
@@ -307,7 +311,7 @@ int main(int argc, char **argv)
 #define KEY(name, field) if (!strcmp(k, name)) c.field = v
 		KEY("win", win_bits); KEY("buckets", buckets); KEY("ways", ways); KEY("key", key); KEY("G", G); KEY("intra", intra);
 		KEY("vcap", vcap); KEY("minlen", minlen); KEY("lazy", lazy); KEY("adapt", adapt); KEY("split", split); KEY("seg", seg);
-		KEY("prime", prime); KEY("toks", toks); KEY("h3", h3); KEY("far5", far5); KEY("ins_all", ins_all); KEY("k2", k2); KEY("b2", b2); KEY("lazyd", lazyd); KEY("cut", cut); KEY("splitg", splitg);
+		KEY("prime", prime); KEY("toks", toks); KEY("h3", h3); KEY("far5", far5); KEY("ins_all", ins_all); KEY("k2", k2); KEY("b2", b2); KEY("lazyd", lazyd); KEY("cut", cut); KEY("splitg", splitg); KEY("rr", rr);
 	}
 	FILE *f = fopen(argv[1], "rb");
 	if (!f)
