@@ -89,8 +89,12 @@ const char *hipdeflate_version(void);
 /* ---- per-block codecs: drop-in zlibutil backends ------------------------ */
 
 /* zlibutil_code_enc (lib/zlibutil.h:47).  *destLen in = capacity, out = bytes.
- * Output is raw DEFLATE ending in a BFINAL block.  level as
- * include/hipdeflate_params.h.  Re-entrant and thread-safe. */
+ * Output is raw DEFLATE ending in a BFINAL block.  Levels (include/hipdeflate_params.h): 0 stored; 1 greedy + static Huffman
+ * (the speed level); 2 greedy + dynamic Huffman in one wavefront's 4 KiB window; 3..9 the workgroup parse -- a 32 KiB window and a
+ * 64 KiB multi-way table shared by a workgroup, block splitting -- with 1 way greedy (3), 1 way lazy (4), 2 ways (5), 4 ways (6..9):
+ * level 3 is below the reference's libdeflate level 1 in size on every measured set, level 6 within 3 % of its level 6.  (The
+ * per-call forms here and the hook take latency mode, which keeps the one-wavefront parse of rounds 2-3 at every dynamic level.)
+ * Re-entrant and thread-safe. */
 int hip_deflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen, int level);
 
