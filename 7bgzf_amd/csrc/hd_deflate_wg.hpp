@@ -122,7 +122,14 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	WG_LDS WgLds *const Lp = (WG_LDS WgLds *)&L;
 	const wg_word_p vturn = (wg_word_p)&Lp->turn, vfilled = (wg_word_p)&Lp->filled, vfail = (wg_word_p)&Lp->fail,
 			vcur = (wg_word_p)Lp->cur;
-	const uint32_t npieces = (n + HD_WG_CUT - 1) / HD_WG_CUT;
+	// A block longer than the room its slot leaves for the payload is refused (the member is then tried stored, which does
+	// not fit either: status 1) -- the records are sized by the slot (wg_layout(a.split_max)), and the twin says the same
+	const uint32_t hdr_b = frame_hdr_bytes(a.frame), trl_b = frame_trl_bytes(a.frame), sfx_b = frame_sfx_bytes(a.frame);
+	uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
+	if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
+		cap64 = 65536;
+	const bool refused = cap64 < hdr_b + trl_b + sfx_b || n > cap64 - hdr_b - trl_b - sfx_b;
+	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
 
 	// ---- LDS: the table zero, the words ------------------------------------------------------------------------------
 	for (uint32_t i = threadIdx.x; i < WG_TABLE_BYTES / 16; i += 64 * WG_NW)
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	__syncthreads();
 	if (w == WG_NP && lane == 0) {
 		uint32_t *m = (uint32_t *)(rec + lay.off_rec);
-		m[0] = uniform(*vfail) ? 0xffffffffu : 0u;
+		m[0] = (uniform(*vfail) || refused) ? 0xffffffffu : 0u;
 		m[1] = crcv;
 		a.split_ovf[b] = 0;
 	}

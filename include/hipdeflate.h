@@ -94,6 +94,8 @@ const char *hipdeflate_version(void);
  * 64 KiB multi-way table shared by a workgroup, block splitting -- with 1 way greedy (3), 1 way lazy (4), 2 ways (5), 4 ways (6..9):
  * level 3 is below the reference's libdeflate level 1 in size on every measured set, level 6 within 3 % of its level 6.  (The
  * per-call forms here and the hook take latency mode, which keeps the one-wavefront parse of rounds 2-3 at every dynamic level.)
+ * In the batch calls below, levels >= 3 refuse (status != 0) a block that is longer than the room its slot leaves for the payload,
+ * whatever it would have compressed to: the parse's records are sized by the slot.  The reference's callers allocate 1.5 x the block.
  * Re-entrant and thread-safe. */
 int hip_deflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen, int level);

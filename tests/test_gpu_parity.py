@@ -489,6 +489,29 @@ def test_encode_capacity_errors(pkg):
     assert pkg.hip_deflate(text, 1, cap=5021)[1] == hdtest.oracle_twin(text, 1)[1]      # the ordinary form
 
 
+@pytest.mark.parametrize("level", [3, 6])
+def test_workgroup_levels_refuse_a_block_longer_than_its_room(pkg, level):
+    """Levels >= 3: the parse kernel's records are sized by the slot, so a block longer than the room its slot leaves for the
+    payload is refused (status != 0), as the twin refuses it -- whatever it would have compressed to -- and its neighbours
+    in the batch are coded as ever."""
+    s = hdtest.synth()
+    text = bytes(s.text_like(40000, seed=3))
+    blocks = [text[:9000], text, text[100:8100], text[:12001]]
+    blob, offs, lens = b"", [], []
+    for b in blocks:
+        offs.append(len(blob))
+        lens.append(len(b))
+        blob += b + bytes(-len(b) % 16)
+    slot = 12000                                              # blocks 1 and 3 are longer than that
+    members, crc, st = pkg.batch_deflate(blob, offs, lens, level, pkg.FRAME_RAW, slot=slot)
+    for i, b in enumerate(blocks):
+        r, twin = hdtest.oracle_twin(b, level, cap=slot)
+        assert (st[i] == 0) == (r == 0), i
+        assert (st[i] != 0) == (len(b) > slot), i
+        if r == 0:
+            assert members[i] == twin and zlib.decompress(members[i], -15) == b
+
+
 # ---- decode ----------------------------------------------------------------------
 
 
