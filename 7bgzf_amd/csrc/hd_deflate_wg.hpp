@@ -11,16 +11,18 @@
 // A block is cut into PIECES of HD_WG_CUT = 1024 bytes (16 steps of 64 positions) and no match crosses a piece boundary, so
 // the parse of a piece -- which candidate wins, the lazy rule, which lanes start a token -- depends on nothing but what the
 // table held when the piece's positions looked their buckets up.  The wavefronts:
-//   * wavefront 15, the FILLER: moves the block through the ring one piece at a time, a few pieces ahead of the table turn,
-//     and folds the block's CRC-32 from the pieces as they pass;
-//   * wavefronts 0..14, the PARSERS: parser w takes pieces w, w + 15, ...  For a piece it hashes its 16 steps (any time
+//   * wavefront 15, the FILLER: moves the block through the ring one piece at a time, at most WG_AHEAD pieces ahead of the
+//     oldest piece still in work, and folds the block's CRC-32 from the pieces as they pass;
+//   * wavefronts 0..14, the PARSERS: each takes the next piece from a counter.  For a piece it hashes its 16 steps (any time
 //     after the bytes are in the ring), then waits for the piece's TURN -- the one thing that has an order: a step's lanes
 //     must read their buckets as the steps before left them -- and with the turn reads and rewrites the 16 x 64 buckets
-//     (one ds_read_b64, two ds_write_b32 per step; the four old entries of every lane stay in registers), hands the turn to
-//     the next piece, and then verifies, resolves and walks its piece alone, beside fourteen others doing the same.
+//     (one ds_read_b64, two ds_write_b32 per step at four ways; the old entries of every lane stay in registers), hands the
+//     turn to the next piece, and then verifies, resolves and walks its piece alone, beside fourteen others doing the same.
+// WAYS (1, 2, 4 positions per bucket = candidates verified per position) and LAZY are template parameters: the level ladder
+// (include/hipdeflate_params.h HD_WG_WAYS / HD_WG_LAZY).
 // The first version of this file (round 4, earlier) dealt single STEPS round robin and passed two turns per step (table,
-// parse merge); 12 GB/s.  With the cut the parse needs no turn at all, the table turn is passed once per KiB, and a
-// wavefront's piece is 16 steps of straight-line work.
+// parse merge); 12 GB/s.  With the cut the parse needs no turn at all, the table turn is passed once per KiB (it costs 2 %,
+// measured by leaving it out), and a wavefront's piece is 16 steps of straight-line work: 118 GB/s at four ways.
 //
 // Output: per piece its tokens (at most one per byte: piece k's start at token k * HD_WG_CUT of the block's record) and
 // { tokens, literals, matches below 9 bytes, longer matches }; per block { status, CRC-32 }.  The emit-only kernel of
