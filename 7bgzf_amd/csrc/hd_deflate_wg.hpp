@@ -1,9 +1,9 @@
 // hd_deflate_wg.hpp -- levels >= HD_WG_LEVEL, throughput form: the WORKGROUP parse (BASELINE config 5, "level-6-like").
 //
-// Replaces, for BGZF_METHOD=hip6..9, the matchfinder and the parser of libdeflate's lazy levels -- hc_matchfinder
+// Replaces, for levels 3..9 (HD_WG_LEVEL), the matchfinder and the parser of libdeflate's greedy and lazy levels -- hc_matchfinder
 // (lib/libdeflate/hc_matchfinder.h:183-338: hash chains of depth 35 over a 32 KiB window) and deflate_compress_lazy_generic
 // (lib/libdeflate/deflate_compress.c:2606-2809) -- with what ONE WORKGROUP holds in a CU's LDS: the whole DEFLATE window
-// (a 64 KiB ring, distances up to 32768) and HD_WG_BUCKETS x HD_WG_WAYS table entries, shared by HD_WG_WAVES wavefronts
+// (a 64 KiB ring, distances up to 32768) and 64 KiB of table (HD_WG_BUCKETS(level) x HD_WG_WAYS(level) 16-bit entries), shared by HD_WG_WAVES wavefronts
 // (include/hipdeflate_params.h "WORKGROUP LEVELS" states the algorithm; oracle/hd_deflate_twin.c deflate_wg() is its serial
 // statement and must give the same bytes).  Rounds 1-3 gave every wavefront a private ring and table: 8 KiB + 2560 two-way
 // buckets was what a share of LDS held, and "level 6" came out at libdeflate-1's ratio.
