@@ -65,14 +65,26 @@ struct hook_batch {
 	uint32_t len[HOOK_MAX_BATCH];
 };
 
-static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t g_cv_free = PTHREAD_COND_INITIALIZER;  /* a context became free */
-static struct hook_batch g_batch[HOOK_CTX];
-static int g_open = -1;       /* the batch that is collecting, -1 = none */
-static int g_active;          /* callers inside the hook right now (atomic) */
-static int g_running;         /* blocks of the batches that are closed and not yet done (under g_mu) */
-static int g_method = -1;     /* -1 unparsed, 1 parsed */
-static int g_level = 1;
+/* One ENGINE per (level, frame): the hook's (BGZF members at BGZF_METHOD's level) and, since round 4, one per level and raw
+ * frame for the per-block codecs -- hip_deflate / hip_deflate_flush called from the reference's -@N threads
+ * (applet/7bgzf.c:211) share launches exactly as htslib's workers do in the hook (16 callers: 3.8 -> 8.6 GB/s at level 1,
+ * and 64 callers no longer collapse to 1.2). */
+struct hook_eng {
+	pthread_mutex_t mu;
+	pthread_cond_t cv_free;      /* a context became free */
+	struct hook_batch batch[HOOK_CTX];
+	int open;                    /* the batch that is collecting, -1 = none */
+	int active;                  /* callers inside the engine right now (atomic) */
+	int running;                 /* blocks of the batches that are closed and not yet done (under mu) */
+	int inflight;                /* under mu; read without by a leader in its window */
+	int failed;
+	int level, frame;            /* frame: HD_FRAME_BGZF, HD_FRAME_RAW or HD_FRAME_RAW_FLUSH */
+	int loud;                    /* the hook prints codec errors as the reference does (bgzf_compress.c:163-169) */
+};
+#define HOOK_ENG_INIT(fr, ld) { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_free = PTHREAD_COND_INITIALIZER, .open = -1, .level = 1, .frame = (fr), .loud = (ld) }
+static struct hook_eng g_hook = HOOK_ENG_INIT(HD_FRAME_BGZF, 1);
+static struct hook_eng g_codec[10][2] = { [0 ... 9] = { HOOK_ENG_INIT(HD_FRAME_RAW, 0), HOOK_ENG_INIT(HD_FRAME_RAW_FLUSH, 0) } };
+static pthread_once_t g_env_once = PTHREAD_ONCE_INIT, g_knobs_once = PTHREAD_ONCE_INIT;
 static long g_window_us = 60; /* a leader never waits longer than this for the batch to fill */
 static long g_linger_us = 8;  /* ... nor longer than this after the last caller joined */
 static long g_spin_us = 400;  /* a member spins this long for its batch before it sleeps */
@@ -80,9 +92,7 @@ static long g_spin_us = 400;  /* a member spins this long for its batch before i
  * alone, 173 us each for two), a third and fourth do not (266, 297 us each -- tools/hook_bench.c HOOK_PAR): while two are out,
  * the collecting batch stays open and grows */
 static int g_max_inflight = 2;
-static int g_inflight;         /* under g_mu; read without by a leader in its window */
 static int g_batch_target = HOOK_MAX_BATCH;
-static int g_failed;
 static int g_ncpu = 1;
 /* HIPDEFLATE_HOOK_STATS=1: where the time of a call goes, printed at exit (ns sums; tools/hook_bench.c reads it) */
 static int g_stats;
@@ -176,8 +186,7 @@ static void parse_env(void)
 {
 	/* bgzf_compress.c:53-113: name = prefix, level = trailing decimal digits */
 	const char *s = getenv("BGZF_METHOD");
-	g_method = 1;                       /* this library's one coder */
-	g_level = 6;                        /* unset / empty: the reference's default is zlib at level 6 (bgzf_compress.c:54,:102) */
+	int g_level = 6;                        /* unset / empty: the reference's default is zlib at level 6 (bgzf_compress.c:54,:102) */
 	if (s && *s) {
 		size_t l = strlen(s), i = l;
 		int level = -1, digit = 1;
@@ -205,6 +214,13 @@ static void parse_env(void)
 			fprintf(stderr, "hipdeflate: BGZF_METHOD=%s: this library holds the hip coder only; coding with hip%d\n", s, g_level);
 		}
 	}
+	g_hook.level = g_level;
+}
+
+/* the batcher's knobs: read once, by whichever engine runs first (the hook's method above only when the HOOK is first called:
+ * a process may have used the codecs long before it sets BGZF_METHOD) */
+static void parse_knobs(void)
+{
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
 		g_window_us = atol(w);
@@ -239,7 +255,7 @@ static int code_alone(void *dst, size_t *dlen, const void *src, size_t slen)
 	unsigned char *tmp = (unsigned char *)malloc(65536);
 	if (!tmp)
 		return -1;
-	int rc = hipdeflate_batch_deflate((const uint8_t *)src, &off, &len, 1, g_level, HD_FRAME_BGZF, tmp, 65536, 65536, &olen,
+	int rc = hipdeflate_batch_deflate((const uint8_t *)src, &off, &len, 1, g_hook.level, HD_FRAME_BGZF, tmp, 65536, 65536, &olen,
 					  NULL, &st);
 	int ret = rc ? -1 : (st || olen > *dlen) ? 1 : 0;
 	if (ret == 1)
@@ -252,7 +268,7 @@ static int code_alone(void *dst, size_t *dlen, const void *src, size_t slen)
 	return ret;
 }
 
-static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen);
+static int eng_compress(struct hook_eng *e, void *_dst, size_t *_dlen, const void *src, size_t slen);
 
 int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int level_unused)
 {
@@ -271,51 +287,67 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 		       28);
 		return 0;
 	}
-	__atomic_add_fetch(&g_active, 1, __ATOMIC_RELAXED);
-	const int ret = hook_compress(_dst, _dlen, src, slen);
-	__atomic_sub_fetch(&g_active, 1, __ATOMIC_RELAXED);
+	pthread_once(&g_env_once, parse_env);
+	pthread_once(&g_knobs_once, parse_knobs);
+	if (*_dlen < 26)                            /* bgzf_compress.c:116 */
+		return -1;
+	if (slen > 0x10000)                         /* a BGZF member cannot hold it */
+		return 1;
+	if (slen > HOOK_BLOCK || __atomic_load_n(&g_hook.failed, __ATOMIC_RELAXED))
+		return g_hook.failed ? -1 : code_alone(_dst, _dlen, src, slen);
+	__atomic_add_fetch(&g_hook.active, 1, __ATOMIC_RELAXED);
+	const int ret = eng_compress(&g_hook, _dst, _dlen, src, slen);
+	__atomic_sub_fetch(&g_hook.active, 1, __ATOMIC_RELAXED);
 	return ret;
 }
 
-static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen)
+/* The per-block codecs' way in (hd_api.hip deflate_one): one block of 1 .. 0xff00 bytes whose room covers the latency form's
+ * worst case and the stored form -- then the bytes do not depend on the room, and callers with different rooms can share a
+ * launch.  0 ok, 1 codec error, -1 the engine cannot run (the caller takes its own context), -2 not for a batch. */
+__attribute__((visibility("hidden"))) int hd_codec_batch(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t slen,
+							 int level, int flush)
 {
-	pthread_mutex_lock(&g_mu);
-	if (g_method < 0)
-		parse_env();
-	if (*_dlen < 26) {                          /* bgzf_compress.c:116 */
-		pthread_mutex_unlock(&g_mu);
+	if (level < 0 || level > 9 || !slen || slen > HOOK_BLOCK)
+		return -2;
+	pthread_once(&g_knobs_once, parse_knobs);
+	struct hook_eng *e = &g_codec[level][flush ? 1 : 0];
+	if (__atomic_load_n(&e->failed, __ATOMIC_RELAXED))
 		return -1;
-	}
-	if (slen > 0x10000) {                       /* a BGZF member cannot hold it */
-		pthread_mutex_unlock(&g_mu);
-		return 1;
-	}
-	if (slen > HOOK_BLOCK || g_failed) {
-		const int failed = g_failed;
-		pthread_mutex_unlock(&g_mu);
-		return failed ? -1 : code_alone(_dst, _dlen, src, slen);
+	e->level = level;                           /* (the same value from every caller) */
+	__atomic_add_fetch(&e->active, 1, __ATOMIC_RELAXED);
+	const int ret = eng_compress(e, dest, destLen, src, slen);
+	__atomic_sub_fetch(&e->active, 1, __ATOMIC_RELAXED);
+	return ret;
+}
+
+static int eng_compress(struct hook_eng *e, void *_dst, size_t *_dlen, const void *src, size_t slen)
+{
+	pthread_mutex_lock(&e->mu);
+	if (e->failed) {
+		pthread_mutex_unlock(&e->mu);
+		return -1;
 	}
 	/* ---- join the collecting batch, or open one ---------------------------------------------- */
 	struct hook_batch *b;
 	const int64_t t_enter = g_stats ? now_ns() : 0;
 	for (;;) {
-		if (g_open >= 0) {
-			b = &g_batch[g_open];
+		if (e->open >= 0) {
+			b = &e->batch[e->open];
 			break;
 		}
 		int k;
-		for (k = 0; k < HOOK_CTX && __atomic_load_n(&g_batch[k].state, __ATOMIC_ACQUIRE) != 0; k++)
+		for (k = 0; k < HOOK_CTX && __atomic_load_n(&e->batch[k].state, __ATOMIC_ACQUIRE) != 0; k++)
 			;
 		if (k < HOOK_CTX) {
-			b = &g_batch[k];
+			b = &e->batch[k];
 			if (!b->lat) {
 				/* batch context k lives on entry k of the device list (HIPDEFLATE_DEVICES), round robin */
 				const int ndev = hipdeflate_device_count();
-				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, g_level, HD_FRAME_BGZF | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
+				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, e->level, e->frame | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
 								HOOK_BLOCK);
 				if (!b->lat) {
-					g_failed = 1;
-					pthread_mutex_unlock(&g_mu);
+					e->failed = 1;
+					pthread_mutex_unlock(&e->mu);
 					return -1;                          /* coder missing */
 				}
 			}
@@ -323,10 +355,10 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 			__atomic_store_n(&b->ready, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->taken, 0, __ATOMIC_RELAXED);
 			__atomic_store_n(&b->state, 1, __ATOMIC_RELEASE);
-			g_open = k;
+			e->open = k;
 			break;
 		}
-		pthread_cond_wait(&g_cv_free, &g_mu);   /* every context is busy: wait for one to drain */
+		pthread_cond_wait(&e->cv_free, &e->mu);   /* every context is busy: wait for one to drain */
 	}
 	const int idx = __atomic_fetch_add(&b->n, 1, __ATOMIC_RELAXED);     /* (written under g_mu; the leader's window loop reads it without) */
 	const int leader = idx == 0;
@@ -334,14 +366,14 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	/* Everybody who could join has: the callers inside the hook that are not in a batch on the device are all here
 	 * (callers released together by the previous batch come back within microseconds of each other, and count
 	 * as inside while they copy their members out).  Or the batch is full. */
-	const int want = __atomic_load_n(&g_active, __ATOMIC_RELAXED) - g_running;
-	if (b->n >= HOOK_MAX_BATCH || ((b->n >= g_batch_target || b->n >= want) && g_inflight < g_max_inflight)) {
+	const int want = __atomic_load_n(&e->active, __ATOMIC_RELAXED) - e->running;
+	if (b->n >= HOOK_MAX_BATCH || ((b->n >= g_batch_target || b->n >= want) && e->inflight < g_max_inflight)) {
 		__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
-		g_running += b->n;
-		__atomic_add_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
-		g_open = -1;
+		e->running += b->n;
+		__atomic_add_fetch(&e->inflight, 1, __ATOMIC_RELAXED);
+		e->open = -1;
 	}
-	pthread_mutex_unlock(&g_mu);
+	pthread_mutex_unlock(&e->mu);
 
 	const int64_t t_joined = g_stats ? now_ns() : 0;
 	memcpy(hipdeflate_lat_input(b->lat, (uint32_t)idx), src, slen);      /* own block, no lock held */
@@ -367,35 +399,35 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 					t_last = t;
 				}
 				/* (while g_max_inflight batches are out the window stays open -- 2 ms at most, should one hang) */
-				const int full = __atomic_load_n(&g_inflight, __ATOMIC_RELAXED) >= g_max_inflight;
+				const int full = __atomic_load_n(&e->inflight, __ATOMIC_RELAXED) >= g_max_inflight;
 				if ((t >= deadline || t - t_last >= g_linger_us * 1000) && (!full || t >= hard))
 					break;
 				/* with every device slot taken and more callers than CPUs, the leaders in flight and the HIP runtime's
 				 * thread need this CPU more than a spinning window does */
-				if (full && __atomic_load_n(&g_active, __ATOMIC_RELAXED) + 1 >= g_ncpu)
+				if (full && __atomic_load_n(&e->active, __ATOMIC_RELAXED) + 1 >= g_ncpu)
 					sched_yield();
 				else
 					cpu_relax();
 			}
 		}
-		pthread_mutex_lock(&g_mu);
+		pthread_mutex_lock(&e->mu);
 		if (__atomic_load_n(&b->state, __ATOMIC_RELAXED) == 1) {          /* window over */
 			__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
-			g_running += b->n;
-			__atomic_add_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
-			g_open = -1;
+			e->running += b->n;
+			__atomic_add_fetch(&e->inflight, 1, __ATOMIC_RELAXED);
+			e->open = -1;
 		}
 		const int n = b->n;
-		pthread_mutex_unlock(&g_mu);
+		pthread_mutex_unlock(&e->mu);
 		const int64_t t_closed = g_stats ? now_ns() : 0;
 		while (__atomic_load_n(&b->ready, __ATOMIC_ACQUIRE) < n)     /* the others are still copying in */
 			cpu_relax();
 		const int64_t t_ready = g_stats ? now_ns() : 0;
 		b->rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
-		pthread_mutex_lock(&g_mu);
-		g_running -= n;
-		__atomic_sub_fetch(&g_inflight, 1, __ATOMIC_RELAXED);
-		pthread_mutex_unlock(&g_mu);
+		pthread_mutex_lock(&e->mu);
+		e->running -= n;
+		__atomic_sub_fetch(&e->inflight, 1, __ATOMIC_RELAXED);
+		pthread_mutex_unlock(&e->mu);
 		/* (an exchange, i.e. a full fence: the load of `sleepers` below must not pass this store -- a member that
 		 * has counted itself in and still reads state 2 goes to sleep) */
 		(void)__atomic_exchange_n(&b->state, 3, __ATOMIC_SEQ_CST);
@@ -415,7 +447,7 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 		 * own thread, which a leader's hipStreamSynchronize waits for -- off its CPU: those members sleep at once (16
 		 * callers on 16 CPUs, hip2: 4.51 -> 4.76 GB/s); otherwise a member spins g_spin_us for its batch first (it
 		 * sees the leader's store within a cache miss) */
-		const int crowded = __atomic_load_n(&g_active, __ATOMIC_RELAXED) + 1 >= g_ncpu;
+		const int crowded = __atomic_load_n(&e->active, __ATOMIC_RELAXED) + 1 >= g_ncpu;
 		const int64_t deadline = crowded ? 0 : now_ns() + g_spin_us * 1000;
 		int spins = 0, st;
 		while ((st = __atomic_load_n(&b->state, __ATOMIC_ACQUIRE)) != 3) {
@@ -444,7 +476,8 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	if (rc || !m) {
 		ret = -1;                                   /* coder missing */
 	} else if (st || olen > *_dlen) {
-		fprintf(stderr, "hip_deflate %d\n", st ? st : 1);
+		if (e->loud)
+			fprintf(stderr, "hip_deflate %d\n", st ? st : 1);
 		ret = 1;                                    /* codec error, bgzf_compress.c:163-169 */
 	} else {
 		memcpy(_dst, m, olen);                      /* own member, no lock held */
@@ -454,10 +487,10 @@ static int hook_compress(void *_dst, size_t *_dlen, const void *src, size_t slen
 	if (g_stats)
 		ST_ADD(st_copy_out, now_ns() - t_done);
 	if (__atomic_add_fetch(&b->taken, 1, __ATOMIC_ACQ_REL) == nb) {
-		pthread_mutex_lock(&g_mu);
+		pthread_mutex_lock(&e->mu);
 		__atomic_store_n(&b->state, 0, __ATOMIC_RELEASE);   /* drained: the context can collect again */
-		pthread_cond_broadcast(&g_cv_free);
-		pthread_mutex_unlock(&g_mu);
+		pthread_cond_broadcast(&e->cv_free);
+		pthread_mutex_unlock(&e->mu);
 	}
 	return ret;
 }

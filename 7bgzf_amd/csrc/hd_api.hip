@@ -1573,11 +1573,37 @@ static void codec_release(hipdeflate_lat *c, int level)
 	hipdeflate_lat_close(c);
 }
 
+extern "C" int hd_codec_batch(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t slen, int level, int flush);
+static bool codec_batching()
+{
+	static const bool on = [] {
+		const char *e = getenv("HIPDEFLATE_CODEC_BATCH");
+		return !(e && *e == '0');
+	}();
+	return on;
+}
+
 static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char *source, size_t sourceLen, int level,
 		       int frame)
 {
 	if (!dest || !destLen || (!source && sourceLen) || sourceLen > 0xffffffffu - 65536u)
 		return HD_E_ARG;
+	// Concurrent callers -- the reference creates a thread per block, -@N at once (applet/7bgzf.c:211) -- share launches: the
+	// hook's micro-batcher with an engine per (level, frame) (bgzf_hook.c hd_codec_batch).  For a block whose room covers
+	// the latency form's worst case AND the stored form the bytes do not depend on the room (what the reference's 1.5 x
+	// allocation always gives), so callers with different rooms can sit in one batch; everything else takes its own context
+	// below.  HIPDEFLATE_CODEC_BATCH=0 turns it off (A/B).
+	if (sourceLen && sourceLen <= CODEC_BLOCK && level >= 0 && level <= 9 && codec_batching() && ensure() == 0) {
+		const bool fl = frame == HD_FRAME_RAW_FLUSH;
+		const uint32_t lat = HD_LAT_SEG_BYTES(level);
+		const uint64_t need_lat = level >= 1 && sourceLen > lat ? HD_SEGN_WORST((uint64_t)sourceLen, lat, fl) : 0;
+		const uint64_t need_st = HD_STORED_SIZE((uint64_t)sourceLen) + (fl ? 5u : 0u) + 8u;
+		if (*destLen >= need_lat && *destLen >= need_st) {
+			const int r = hd_codec_batch(dest, destLen, source, sourceLen, level, fl ? 1 : 0);
+			if (r == 0 || r == 1)
+				return r;                                /* (-1 / -2: not for a batch, or its engine is down) */
+		}
+	}
 	if (sourceLen <= CODEC_BLOCK && ensure() == 0) {
 		if (hipdeflate_lat *c = codec_acquire(level)) {
 			const size_t cap = *destLen > c->slot ? c->slot : *destLen;

@@ -96,7 +96,8 @@ const char *hipdeflate_version(void);
  * per-call forms here and the hook take latency mode, which keeps the one-wavefront parse of rounds 2-3 at every dynamic level.)
  * In the batch calls below, levels >= 3 refuse (status != 0) a block that is longer than the room its slot leaves for the payload,
  * whatever it would have compressed to: the parse's records are sized by the slot.  The reference's callers allocate 1.5 x the block.
- * Re-entrant and thread-safe. */
+ * Re-entrant and thread-safe; concurrent callers whose room covers the latency form's worst case and the stored form share launches
+ * (the hook's micro-batcher, an engine per level and frame; HIPDEFLATE_CODEC_BATCH=0: a context per call). */
 int hip_deflate(unsigned char *dest, size_t *destLen,
 		const unsigned char *source, size_t sourceLen, int level);
 
