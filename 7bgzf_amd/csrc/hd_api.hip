@@ -1702,6 +1702,11 @@ int g_inf_active = 0, g_inf_running = 0;                      // callers inside 
 int g_inf_inflight = 0, g_inf_max_inflight = 2;               // closed batches not yet done / HIPDEFLATE_INFLATE_INFLIGHT
 long g_inf_window_ns = 400000, g_inf_linger_ns = 60000;       // HIPDEFLATE_INFLATE_WINDOW_US / _LINGER_US
 int g_inf_failed = 0;
+// "Everybody who is inside has joined" closes a batch only once it holds as many streams as the last batch that was closed
+// by the LINGER time did: the reference creates its -@N threads one after the other (applet/7bgzf.c:330-345), tens of
+// microseconds apart, and a batch that closes as soon as it is complete goes out with the first one or two of them -- sixteen
+// streams became five launches of 1.5 ms, one behind the other.  A lone caller pays the linger time once.
+int g_inf_expect = 0x7fffffff;
 // A batch is ~1.5 ms on the device whatever it holds (one wavefront per stream, the chip is empty), and the device runs two
 // launches side by side but hardly a third (measured on the latency contexts, DESIGN "Hook": 152 us alone, 173 us each for
 // two, 266+ for three): so at most two batches are out, and while they are the collecting batch stays open and grows.
@@ -1850,7 +1855,7 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	b->out_used += out_need;
 	__atomic_store_n(&b->n, idx + 1, __ATOMIC_RELAXED);
 	// everybody who could join has: the callers inside that are not in a closed batch are all here (or the batch is full)
-	if (b->n >= (int)INFB_SLOTS || (b->n >= g_inf_active - g_inf_running && g_inf_inflight < g_inf_max_inflight)) {
+	if (b->n >= (int)INFB_SLOTS || (b->n >= g_inf_active - g_inf_running && b->n >= g_inf_expect && g_inf_inflight < g_inf_max_inflight)) {
 		__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
 		g_inf_running += b->n;
 		g_inf_inflight++;
@@ -1879,9 +1884,14 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 				const bool slot = __atomic_load_n(&g_inf_inflight, __ATOMIC_RELAXED) < g_inf_max_inflight;
 				// complete (every caller that is inside and not on the device has joined), or nobody came for the linger
 				// time, or the window is over -- and a launch slot is free (20 ms at most, should a batch hang)
-				const bool complete = now_n >= __atomic_load_n(&g_inf_active, __ATOMIC_RELAXED) - __atomic_load_n(&g_inf_running, __ATOMIC_RELAXED);
-				if (((complete || t >= deadline || t - t_last >= g_inf_linger_ns) && slot) || t >= hard)
+				const bool complete = now_n >= __atomic_load_n(&g_inf_active, __ATOMIC_RELAXED) - __atomic_load_n(&g_inf_running, __ATOMIC_RELAXED) &&
+						      now_n >= __atomic_load_n(&g_inf_expect, __ATOMIC_RELAXED);
+				const bool lingered = t >= deadline || t - t_last >= g_inf_linger_ns;
+				if (((complete || lingered) && slot) || t >= hard) {
+					if (lingered && slot)
+						__atomic_store_n(&g_inf_expect, now_n, __ATOMIC_RELAXED);    // what a batch of these callers holds
 					break;
+				}
 				if (!slot && (++spins & 15) == 0)
 					sched_yield();                       // two batches are out for a millisecond yet: leave the CPU to their callers
 				else
