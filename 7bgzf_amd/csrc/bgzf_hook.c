@@ -313,7 +313,7 @@ __attribute__((visibility("hidden"))) int hd_codec_batch(unsigned char *dest, si
 	struct hook_eng *e = &g_codec[level][flush ? 1 : 0];
 	if (__atomic_load_n(&e->failed, __ATOMIC_RELAXED))
 		return -1;
-	e->level = level;                           /* (the same value from every caller) */
+	__atomic_store_n(&e->level, level, __ATOMIC_RELAXED);       /* (the same value from every caller of this engine) */
 	__atomic_add_fetch(&e->active, 1, __ATOMIC_RELAXED);
 	const int ret = eng_compress(e, dest, destLen, src, slen);
 	__atomic_sub_fetch(&e->active, 1, __ATOMIC_RELAXED);
