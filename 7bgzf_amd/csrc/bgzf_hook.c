@@ -78,7 +78,7 @@ struct hook_eng {
 	int running;                 /* blocks of the batches that are closed and not yet done (under mu) */
 	int inflight;                /* under mu; read without by a leader in its window */
 	int failed;
-	int level, frame;            /* frame: HD_FRAME_BGZF, HD_FRAME_RAW or HD_FRAME_RAW_FLUSH */
+	int level, frame;            /* level: the hook's (BGZF_METHOD; a codec engine's is its index); frame: HD_FRAME_BGZF, HD_FRAME_RAW or HD_FRAME_RAW_FLUSH */
 	int loud;                    /* the hook prints codec errors as the reference does (bgzf_compress.c:163-169) */
 };
 #define HOOK_ENG_INIT(fr, ld) { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_free = PTHREAD_COND_INITIALIZER, .open = -1, .level = 1, .frame = (fr), .loud = (ld) }
@@ -268,7 +268,7 @@ static int code_alone(void *dst, size_t *dlen, const void *src, size_t slen)
 	return ret;
 }
 
-static int eng_compress(struct hook_eng *e, void *_dst, size_t *_dlen, const void *src, size_t slen);
+static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen, const void *src, size_t slen);
 
 int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int level_unused)
 {
@@ -296,7 +296,7 @@ int bgzf_compress(void *_dst, size_t *_dlen, const void *src, size_t slen, int l
 	if (slen > HOOK_BLOCK || __atomic_load_n(&g_hook.failed, __ATOMIC_RELAXED))
 		return g_hook.failed ? -1 : code_alone(_dst, _dlen, src, slen);
 	__atomic_add_fetch(&g_hook.active, 1, __ATOMIC_RELAXED);
-	const int ret = eng_compress(&g_hook, _dst, _dlen, src, slen);
+	const int ret = eng_compress(&g_hook, g_hook.level, _dst, _dlen, src, slen);
 	__atomic_sub_fetch(&g_hook.active, 1, __ATOMIC_RELAXED);
 	return ret;
 }
@@ -313,14 +313,13 @@ __attribute__((visibility("hidden"))) int hd_codec_batch(unsigned char *dest, si
 	struct hook_eng *e = &g_codec[level][flush ? 1 : 0];
 	if (__atomic_load_n(&e->failed, __ATOMIC_RELAXED))
 		return -1;
-	__atomic_store_n(&e->level, level, __ATOMIC_RELAXED);       /* (the same value from every caller of this engine) */
 	__atomic_add_fetch(&e->active, 1, __ATOMIC_RELAXED);
-	const int ret = eng_compress(e, dest, destLen, src, slen);
+	const int ret = eng_compress(e, level, dest, destLen, src, slen);
 	__atomic_sub_fetch(&e->active, 1, __ATOMIC_RELAXED);
 	return ret;
 }
 
-static int eng_compress(struct hook_eng *e, void *_dst, size_t *_dlen, const void *src, size_t slen)
+static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen, const void *src, size_t slen)
 {
 	pthread_mutex_lock(&e->mu);
 	if (e->failed) {
@@ -343,7 +342,7 @@ static int eng_compress(struct hook_eng *e, void *_dst, size_t *_dlen, const voi
 			if (!b->lat) {
 				/* batch context k lives on entry k of the device list (HIPDEFLATE_DEVICES), round robin */
 				const int ndev = hipdeflate_device_count();
-				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, e->level, e->frame | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
+				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, level, e->frame | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
 								HOOK_BLOCK);
 				if (!b->lat) {
 					e->failed = 1;

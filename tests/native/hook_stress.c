@@ -1,7 +1,8 @@
 /*
  * hook_stress.c -- TEST ONLY: T threads x N calls of bgzf_compress() (bgzf_hook.c compiled with a sanitizer, linked
  * against stub_hipdeflate.c), every member checked against the block that went in; then the zlibutil_hip mirror
- * (hd_zlibutil_buffer_*) driven from threads the way applet/7bgzf.c:211 drives zlibutil_buffer_code.
+ * (hd_zlibutil_buffer_*) driven from threads the way applet/7bgzf.c:211 drives zlibutil_buffer_code; round 4: the codec
+ * engines of the same batcher (hd_codec_batch) from the same T threads.
  *   hook_stress [threads=64] [calls=10000]
  */
 #include <pthread.h>
@@ -45,6 +46,33 @@ static void *worker(void *arg)
 	return NULL;
 }
 
+/* the per-block codecs' engines (bgzf_hook.c hd_codec_batch: one per level and raw frame), driven the same way; the stub's
+ * contexts answer with the same stored BGZF-framed members whatever the frame */
+int hd_codec_batch(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t slen, int level, int flush);
+static void *codec_worker(void *arg)
+{
+	const unsigned id = (unsigned)(uintptr_t)arg;
+	unsigned char *src = (unsigned char *)malloc(0xff00), *dst = (unsigned char *)malloc(0x18000);
+	unsigned seed = id * 2246822519u + 777;
+	for (int k = 0; k < g_calls / 4 + 1; k++) {
+		seed = seed * 1664525u + 1013904223u;
+		const size_t n = 1 + (seed >> 8) % 0xff00;
+		for (size_t i = 0; i < n; i += 61)
+			src[i] = (unsigned char)(seed >> (i % 24));
+		src[n - 1] = (unsigned char)k;
+		src[0] = (unsigned char)id;
+		size_t dlen = 0x18000;
+		const int r = hd_codec_batch(dst, &dlen, src, n, 1 + (int)(id % 3), (int)(id & 1));
+		if (r != 0 || dlen != 18 + 5 + n + 8 || memcmp(dst + 23, src, n) || dst[23] != (unsigned char)id)
+			__atomic_add_fetch(&g_bad, 1, __ATOMIC_RELAXED);
+	}
+	if (hd_codec_batch(dst, &(size_t){ 0x18000 }, src, 0, 1, 0) != -2 || hd_codec_batch(dst, &(size_t){ 0x18000 }, src, 0x10000, 1, 0) != -2)
+		__atomic_add_fetch(&g_bad, 1, __ATOMIC_RELAXED);                   /* not for a batch: empty, or longer than a slot */
+	free(src);
+	free(dst);
+	return NULL;
+}
+
 static void *zlibutil_worker(void *arg)
 {
 	const unsigned id = (unsigned)(uintptr_t)arg;
@@ -76,6 +104,10 @@ int main(int argc, char **argv)
 	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)(T > 8 ? T : 8));
 	for (int i = 0; i < T; i++)
 		pthread_create(&th[i], NULL, worker, (void *)(uintptr_t)i);
+	for (int i = 0; i < T; i++)
+		pthread_join(th[i], NULL);
+	for (int i = 0; i < T; i++)
+		pthread_create(&th[i], NULL, codec_worker, (void *)(uintptr_t)i);
 	for (int i = 0; i < T; i++)
 		pthread_join(th[i], NULL);
 	for (int i = 0; i < 8; i++)
