@@ -12,13 +12,15 @@
  * Level map (role of lib/libdeflate/deflate_compress.c:3874-3990 in the
  * reference, where a level selects matchfinder + parser + Huffman mode):
  *   0      stored blocks only          (store_deflate, lib/zlibutil.c:302)
- *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like")
- *   2      greedy parse, dynamic Huffman, level-1 window (fast on DNA-like data)
- *   3..4   greedy parse, dynamic Huffman, 8 KiB window
- *   5      lazy parse (one-lane lookahead), dynamic Huffman, 8 KiB window
- *   6      the same with a six-byte hash key and two positions per bucket, both verified
- *          (config 5, "level-6-like"; the role of hc_matchfinder's chains at the depth LDS affords)
- *   7..9   level 6's matchfinder with a larger window and table
+ *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like"), one wavefront's 4 KiB window
+ *   2      greedy parse, dynamic Huffman, the same window (fast on DNA-like data)
+ *   3..9   THROUGHPUT FORM (batches): the workgroup parse -- a 32 KiB window and a 64 KiB multi-way table shared by the
+ *          sixteen wavefronts of a workgroup, block splitting ("WORKGROUP LEVELS" below; config 5, "level-6-like"):
+ *          3 one way greedy, 4 one way lazy, 5 two ways, 6..9 four ways
+ *   3..9   LATENCY FORM (one block per call, the hook; HD_FRAME_LATENCY): the one-wavefront geometries below, parsed in
+ *          parts -- 3..4 greedy / lazy in an 8 KiB window, 5 lazy with a one-way table, 6..9 a six-byte key and two
+ *          positions per bucket in the same 8 KiB geometry (the HD_L7.. / HD_L9.. sets are rounds 2-3's throughput levels,
+ *          kept for the experiment builds)
  */
 #ifndef HIPDEFLATE_PARAMS_H
 #define HIPDEFLATE_PARAMS_H
