@@ -1363,7 +1363,9 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
 // then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
-template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0>
+// PARTS_ONLY: levels 3..9 come here for their latency segments alone (a.parts != 0; their throughput form is the workgroup
+// parse) -- the whole-block split path and the fused kernel are then not instantiated
+template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0, bool PARTS_ONLY = false>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t sub = a.parts ? part_sub_batch(a.nblocks, a.parts) : split_sub_batch(a.nblocks, a.split_max, level);
@@ -1384,6 +1386,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 		}
 		return;
 	}
+	if constexpr (!PARTS_ONLY) {
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
@@ -1396,6 +1399,7 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	f.split_ovf = s.split_ovf;
 	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA, DEEP>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
+	}
 }
 
 void launch_wg(const DeflateArgs &a, int level, hipStream_t st);       // hd_deflate_wg.hpp
@@ -1409,13 +1413,13 @@ inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t s
 	if (level == 2)
 		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	else if (level == 3)
-		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
+		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST, 0, true>(a, level, st);
 	else if (level == 4)
-		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST>(a, level, st);
+		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST, 0, true>(a, level, st);
 	else if (level < HD_DEEP_LEVEL)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 0>(a, level, st);
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 0, true>(a, level, st);
 	else            // levels 6..9, latency segments parsed in parts: the two-way tables in the 8 KiB geometry (a part is 2 KiB)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1>(a, 6, st);
+		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1, true>(a, 6, st);
 	return 0;
 }
 
