@@ -182,3 +182,39 @@ def test_hd7bgzf_g2_over_the_device_list_equals_g1(pkg, tmp_path):
         assert pkg.bgzf_decompress_bytes(outs[0]) == data
         p = subprocess.run([exe, "-d", "-g2"], input=outs[0], env=env2, capture_output=True)
         assert p.returncode == 0 and p.stdout == data
+
+
+def test_hip_deflate_from_32_threads_mixed_levels_frames_and_rooms(pkg):
+    """hip_deflate / hip_deflate_flush from 32 threads at once, every thread with its own levels, frames, lengths and rooms:
+    callers whose room makes the bytes independent of it share launches (bgzf_hook.c hd_codec_batch, an engine per level and
+    frame), the others -- a room below the latency form's worst case or below the stored form -- take a context of their
+    own; either way a call gives what the twin gives for that block and that room (lib/zlibutil.h:47: re-entrant, no shared
+    state the caller could see)."""
+    import threading
+    import zlib
+    import numpy as np
+    s = hdtest.synth()
+    pool = bytes(s.fastq_like(400000, seed=71)) + bytes(s.text_like(400000, seed=72)) + bytes(s.random_bytes(70000, seed=73))
+    bad = []
+
+    def work(t):
+        rng = np.random.default_rng(1000 + t)
+        for k in range(6):
+            level = int(rng.choice([1, 2, 3, 6]))
+            flush = bool(rng.integers(0, 2))
+            n = int(rng.choice([1, 100, 4080, 8160, 8161, 30000, 0xff00])) if k % 2 else int(rng.integers(1, 0xff00 + 1))
+            o = int(rng.integers(0, len(pool) - n))
+            data = pool[o:o + n]
+            cap = [n + n // 2 + 64, n + 12, max(16, n // 2), 65536][int(rng.integers(0, 4))]
+            fn, tw = (pkg.hip_deflate_flush, hdtest.codec_twin_flush) if flush else (pkg.hip_deflate, hdtest.codec_twin)
+            r, z = fn(data, level, cap=cap)
+            rt, zt = tw(data, level, cap=cap)
+            if (r != 0) != (rt != 0) or (r == 0 and (z != zt or zlib.decompressobj(-15).decompress(z + (b"\x03\x00" if flush else b"")) != data)):
+                bad.append((t, k, level, flush, n, cap, r, rt))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(32)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]
