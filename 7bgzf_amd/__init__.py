@@ -40,7 +40,7 @@ _vp = ctypes.c_void_p
 
 # every symbol include/hipdeflate.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "hipdeflate_init", "hipdeflate_shutdown", "hipdeflate_available", "hipdeflate_version",
+    "hipdeflate_init", "hipdeflate_shutdown", "hipdeflate_available", "hipdeflate_version", "hipdeflate_stall_count",
     "hip_deflate", "hip_deflate_flush", "hip_inflate", "hipdeflate_batch_deflate", "hipdeflate_batch_inflate",
     "hipdeflate_batch_deflate_dev", "hipdeflate_batch_inflate_dev", "hipdeflate_scan_sizes_dev",
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
@@ -97,6 +97,8 @@ def lib():
     L.hipdeflate_bound.restype = ctypes.c_uint64
     L.hipdeflate_bound.argtypes = [ctypes.c_uint64, ctypes.c_int]
     L.hipdeflate_init.argtypes = [ctypes.c_int]
+    L.hipdeflate_stall_count.restype = ctypes.c_uint64
+    L.hipdeflate_stall_count.argtypes = []
     L.hipdeflate_init_devices.argtypes = [_vp, ctypes.c_int]
     L.hipdeflate_use_device.argtypes = [ctypes.c_int]
     L.hipdeflate_pipe_open_on.restype = _vp

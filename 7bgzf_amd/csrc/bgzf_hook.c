@@ -93,9 +93,6 @@ static long g_spin_us = 400;  /* a member spins this long for its batch before i
  * the collecting batch stays open and grows */
 static int g_max_inflight = 2;
 static int g_batch_target = HOOK_MAX_BATCH;
-/* experiment (HIPDEFLATE_HOOK_FORM=throughput): levels >= 3 coded in their throughput form -- the workgroup parse, one workgroup
- * per block -- instead of the latency form's segments */
-static int g_form_throughput;
 static int g_ncpu = 1;
 /* HIPDEFLATE_HOOK_STATS=1: where the time of a call goes, printed at exit (ns sums; tools/hook_bench.c reads it) */
 static int g_stats;
@@ -224,8 +221,6 @@ static void parse_env(void)
  * a process may have used the codecs long before it sets BGZF_METHOD) */
 static void parse_knobs(void)
 {
-	const char *fm = getenv("HIPDEFLATE_HOOK_FORM");
-	g_form_throughput = fm && !strcmp(fm, "throughput");
 	const char *w = getenv("HIPDEFLATE_BATCH_US");
 	if (w && *w)
 		g_window_us = atol(w);
@@ -347,7 +342,7 @@ static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen
 			if (!b->lat) {
 				/* batch context k lives on entry k of the device list (HIPDEFLATE_DEVICES), round robin */
 				const int ndev = hipdeflate_device_count();
-				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, level, e->frame | (g_form_throughput && level >= HD_WG_LEVEL ? 0 : HD_FRAME_LATENCY), HOOK_MAX_BATCH,
+				b->lat = hipdeflate_lat_open_on(ndev > 0 ? k % ndev : 0, level, e->frame | HD_FRAME_LATENCY, HOOK_MAX_BATCH,
 								HOOK_BLOCK);
 				if (!b->lat) {
 					e->failed = 1;

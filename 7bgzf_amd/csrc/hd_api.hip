@@ -20,6 +20,7 @@
 #include "hd_deflate_static.hpp"
 #include "hd_deflate_dynamic.hpp"
 #include "hd_deflate_wg.hpp"
+#include "hd_emit_wg.hpp"
 #include "hd_inflate.hpp"
 #include "hd_compact.hpp"
 #include "hd_segment.hpp"
@@ -97,6 +98,7 @@ struct Ctx {
 	char desc[256] = "hipdeflate (not initialised)";
 	hipStream_t stream = nullptr;
 	CrcTables *d_ct = nullptr;
+	uint32_t *d_stalls = nullptr;    // blocks the workgroup parse gave up on (hipdeflate_stall_count)
 	// host-pointer API pools (guarded by mu)
 	std::mutex mu;
 	Buf d_in, d_meta, d_slots, d_packed, d_scratch, d_scan;
@@ -307,6 +309,8 @@ int ctx_init(Ctx &g, int device)
 	HD_CHECK(hipMalloc((void **)&g.d_ct, sizeof(CrcTables)));
 	HD_CHECK(hipMemcpy(g.d_ct, h, sizeof(CrcTables), hipMemcpyHostToDevice));
 	free(h);
+	HD_CHECK(hipMalloc((void **)&g.d_stalls, 16));
+	HD_CHECK(hipMemset(g.d_stalls, 0, 16));
 	// Several lanes' ds_write_b16 to one table entry in one instruction: the highest lane's data must stay (the parse
 	// kernels and their CPU twin lean on it, hd_deflate_static.hpp fetch()).  Probed once per context: on a device
 	// that arbitrates differently the streams would still be valid DEFLATE but not the twin's bytes, and ranks of one
@@ -316,6 +320,8 @@ int ctx_init(Ctx &g, int device)
 			"reproducible on it and refuse to run\n", device, bad);
 		(void)hipFree(g.d_ct);
 		g.d_ct = nullptr;
+		(void)hipFree(g.d_stalls);
+		g.d_stalls = nullptr;
 		(void)hipStreamDestroy(g.stream);
 		g.stream = nullptr;
 		return g.failed = HD_E_NODEVICE;
@@ -401,8 +407,14 @@ extern "C" {
 int hipdeflate_init(int device)
 {
 	{
+		// device < 0 = "from the environment": HIPDEFLATE_DEVICES (a list) if set, else HIPDEFLATE_DEVICE / LOCAL_RANK /
+		// 0 -- the same list every other entry point would configure lazily (-1 used to pin a list of one
+		// and HIPDEFLATE_DEVICES was never read by the hosts that call this first)
 		std::lock_guard<std::mutex> lk(g_init_mu);
-		configure_locked(&device, 1);
+		if (device < 0)
+			configure_locked(nullptr, 0);
+		else
+			configure_locked(&device, 1);
 	}
 	return ensure();
 }
@@ -449,6 +461,22 @@ int hipdeflate_use_device(int index)
 
 int hipdeflate_available(void) { return ensure(); }
 
+uint64_t hipdeflate_stall_count(void)
+{
+	uint64_t sum = 0;
+	std::lock_guard<std::mutex> lk(g_init_mu);
+	for (int i = 0; i < HD_MAX_CTX; i++) {
+		Ctx &g = g_all[i];
+		if (!g.ready || !g.d_stalls)
+			continue;
+		uint32_t v = 0;
+		if (hipSetDevice(g.device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+		    hipMemcpy(&v, g.d_stalls, 4, hipMemcpyDeviceToHost) == hipSuccess)
+			sum += v;
+	}
+	return sum;
+}
+
 const char *hipdeflate_version(void) { return cur().desc; }
 
 static void infb_drain();
@@ -469,6 +497,8 @@ void hipdeflate_shutdown(void)
 				&g.h_out, &g.d_tok, &g.d_tiles })
 			b->release();
 		(void)hipFree(g.d_ct);
+		(void)hipFree(g.d_stalls);
+		g.d_stalls = nullptr;
 		(void)hipStreamDestroy(g.stream);
 		if (g.ev_tok)
 			(void)hipEventDestroy(g.ev_tok);
@@ -486,7 +516,7 @@ void hipdeflate_shutdown(void)
 
 static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level, bool latency)
 {
-	if (level >= 1 && latency && cap > HD_LAT_SEG_BYTES(level))
+	if (level >= 1 && level < HD_WG_LEVEL && latency && cap > HD_LAT_SEG_BYTES(level))      // (the workgroup levels have no segments in any mode)
 		return hd::segmented_scratch_bytes(nblocks, cap, level, HD_LAT_SEG_BYTES(level));
 	if (level >= 1 && level < HD_WG_LEVEL && cap > HD_SEG_LIMIT)       // (the workgroup levels take a block of any length whole)
 		return hd::segmented_scratch_bytes(nblocks, cap, level);
@@ -502,7 +532,7 @@ uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
 {
 	// (latency mode included: its segments are the smallest, their worst case the largest)
 	const uint32_t lat = HD_LAT_SEG_BYTES(level);
-	const uint64_t payload = (level >= 1 && block_bytes > lat) ? HD_SEGN_WORST(block_bytes, lat, 0)
+	const uint64_t payload = (level >= 1 && level < HD_WG_LEVEL && block_bytes > lat) ? HD_SEGN_WORST(block_bytes, lat, 0)
 								   : block_bytes + 5 * (block_bytes / 65535 + 1) + 5;
 	return (payload + 32 + 15) & ~(uint64_t)15;       // + the longest container (20 + 8 bytes)
 }
@@ -545,7 +575,11 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	// mode): such blocks are coded in segments, the ordinary coding leaves them alone
 	const uint32_t seg_lim = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	a.seg_bytes = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
-	a.seg_limit = (level >= 1 && (latency || level < HD_WG_LEVEL) && a.split_max > seg_lim) ? seg_lim : 0;
+	a.seg_limit = (level >= 1 && level < HD_WG_LEVEL && a.split_max > seg_lim) ? seg_lim : 0;
+	// the workgroup levels in latency mode: the same bytes, the member written by a workgroup (blocks up to 64 KiB: the
+	// parse refuses a block longer than its slot, so a slot of at most that says it for every block)
+	a.lat = (latency && level >= HD_WG_LEVEL && a.split_max <= hd::EW_BLOCK_MAX) ? 1u : 0u;
+	a.stalls = g.d_stalls;
 	a.hint = 0;
 	a.host_seg_off = nullptr;
 	a.host_seg_len = nullptr;
@@ -1366,7 +1400,7 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 		c->slot = 65536;
 	const uint32_t seg_lim = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	c->seg = c->latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
-	c->seg_limit = (level >= 1 && (c->latency || level < HD_WG_LEVEL) && c->slot > seg_lim) ? seg_lim : 0;
+	c->seg_limit = (level >= 1 && level < HD_WG_LEVEL && c->slot > seg_lim) ? seg_lim : 0;
 	c->S = c->seg_limit ? hd::seg_slots_per_block(c->slot, c->seg) : 0;
 	// [ in_off u64 | in_len, out_len, crc, status u32 | seg_off u64 [max_blocks * S] | seg_len u32 [max_blocks * S] ]
 	c->meta_seg = (((size_t)max_blocks * (8 + 4 + 4 + 4 + 4)) + 15) & ~(size_t)15;
@@ -1463,6 +1497,9 @@ static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int
 	a.split_ovf = nullptr;
 	a.seg_bytes = c->seg;
 	a.seg_limit = seg_limit;
+	// the workgroup levels: the member written by a workgroup (hd_emit_wg.hpp) when no block can be longer than 64 KiB
+	a.lat = (latency && c->level >= HD_WG_LEVEL && c->in_stride <= hd::EW_BLOCK_MAX) ? 1u : 0u;
+	a.stalls = g.d_stalls;
 	a.hint = seg_limit ? hint : 0;
 	a.host_seg_off = seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;
 	a.host_seg_len = seg_limit ? (const uint32_t *)((const uint64_t *)(c->dmeta + c->meta_seg) + (size_t)mb * c->S) : nullptr;
@@ -1596,7 +1633,7 @@ static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	if (sourceLen && sourceLen <= CODEC_BLOCK && level >= 0 && level <= 9 && codec_batching() && ensure() == 0) {
 		const bool fl = frame == HD_FRAME_RAW_FLUSH;
 		const uint32_t lat = HD_LAT_SEG_BYTES(level);
-		const uint64_t need_lat = level >= 1 && sourceLen > lat ? HD_SEGN_WORST((uint64_t)sourceLen, lat, fl) : 0;
+		const uint64_t need_lat = level >= 1 && level < HD_WG_LEVEL && sourceLen > lat ? HD_SEGN_WORST((uint64_t)sourceLen, lat, fl) : 0;
 		const uint64_t need_st = HD_STORED_SIZE((uint64_t)sourceLen) + (fl ? 5u : 0u) + 8u;
 		if (*destLen >= need_lat && *destLen >= need_st) {
 			const int r = hd_codec_batch(dest, destLen, source, sourceLen, level, fl ? 1 : 0);
@@ -1609,9 +1646,11 @@ static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 			const size_t cap = *destLen > c->slot ? c->slot : *destLen;
 			const uint32_t lat = HD_LAT_SEG_BYTES(level);
 			// latency form only when the room covers its worst case AND the context has a slot for every segment
-			const bool latency = level >= 1 && sourceLen > lat &&
-					     cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH) &&
-					     HD_SEGN_COUNT((uint32_t)sourceLen, lat) <= c->S;
+			// (the workgroup levels: one stream in either mode, "latency" only picks the kernels that write it)
+			const bool latency = level >= HD_WG_LEVEL ||
+					     (level >= 1 && sourceLen > lat &&
+					      cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH) &&
+					      HD_SEGN_COUNT((uint32_t)sourceLen, lat) <= c->S);
 			if (sourceLen)
 				memcpy(hipdeflate_lat_input(c, 0), source, sourceLen);
 			const uint32_t len = (uint32_t)sourceLen;
@@ -1638,7 +1677,7 @@ static int deflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	// One block per call: latency mode (several wavefronts for the block) whenever the room covers its worst case;
 	// the ordinary form otherwise, so that -- as libdeflate_deflate -- the call succeeds whenever the stored form fits
 	const uint32_t lat = HD_LAT_SEG_BYTES(level);
-	if (level >= 1 && sourceLen > lat && cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH))
+	if (level >= HD_WG_LEVEL || (level >= 1 && sourceLen > lat && cap >= HD_SEGN_WORST((uint64_t)sourceLen, lat, frame == HD_FRAME_RAW_FLUSH)))
 		frame |= HD_FRAME_LATENCY;
 	// the slot stride handed to the batch call only needs to cover `cap`
 	int r = hipdeflate_batch_deflate(source, &off, &len, 1, level, frame, dest, up16(cap) ? up16(cap) : 16,

@@ -738,7 +738,11 @@ int main(int argc, char **argv)
 			list[k] = k;
 		if (hipdeflate_init_devices(list, g_npipe))
 			return 1;
-	} else if (hipdeflate_init(-1)) {
+	} else if (hipdeflate_init(-1)) {                             /* (-1: HIPDEFLATE_DEVICES if set, else one device) */
+		return 1;
+	}
+	if (hipdeflate_device_count() < g_npipe) {
+		fprintf(stderr, "-g %d: the device list (HIPDEFLATE_DEVICES) has %d entries\n", g_npipe, hipdeflate_device_count());
 		return 1;
 	}
 	struct timeval t0, t1;

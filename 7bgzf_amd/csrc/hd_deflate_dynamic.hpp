@@ -1219,12 +1219,14 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
 				const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
 				wg_pieces = (const uint4 *)(rec + lay.off_ntok);
-				wg_np = (n + HD_WG_CUT - 1) / HD_WG_CUT;
 				wg_base = 0xffffff00u;
 				tok = (uint32_t *)rec;
 				crcv = m[1];
-				if (m[0] != 0)                               // (the workgroup parse gave the block up: stored)
+				if (m[0] != 0)                               // (the workgroup parse gave the block up, or refused it: stored)
 					alive = false;
+				// (a refused block is longer than the slot its record was sized by: its pieces' counts are not there to be
+				// walked -- ADVICE r4: the walk below ran over n / 1024 records before it looked at `alive`)
+				wg_np = alive ? (n + HD_WG_CUT - 1) / HD_WG_CUT : 0u;
 				for (uint32_t i = lane; i < 288; i += 64)
 					L.lf[i] = 0;
 				if (lane < 32)
@@ -1363,9 +1365,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 // occupancy its ring + table allow and without a persistent loop), tokens + histograms through HBM,
 // then the one emit-only kernel (16 waves per CU).  Larger blocks (none, unless a block is larger
 // than its slot and will fail anyway, or the scratch budget cannot hold even one): the fused kernel.
-// PARTS_ONLY: levels 3..9 come here for their latency segments alone (a.parts != 0; their throughput form is the workgroup
-// parse) -- the whole-block split path and the fused kernel are then not instantiated
-template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0, bool PARTS_ONLY = false>
+template <int W, int H, int MINLEN, int LAZY, int INTRA, int DEEP = 0>
 inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 {
 	const uint32_t sub = a.parts ? part_sub_batch(a.nblocks, a.parts) : split_sub_batch(a.nblocks, a.split_max, level);
@@ -1386,7 +1386,6 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 		}
 		return;
 	}
-	if constexpr (!PARTS_ONLY) {
 	for (uint32_t first = 0; sub && first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
@@ -1399,27 +1398,20 @@ inline void launch_level(const DeflateArgs &a, int level, hipStream_t st)
 	f.split_ovf = s.split_ovf;
 	f.skip_small = sub ? 1 : 0;                          // nothing went the split way: the fused kernel takes all
 	hipLaunchKernelGGL((k_deflate_dynamic<W, H, MINLEN, LAZY, 0, INTRA, DEEP>), dim3(dynamic_grid(a.nblocks, level)), dim3(64), 0, st, f);
-	}
 }
 
 void launch_wg(const DeflateArgs &a, int level, hipStream_t st);       // hd_deflate_wg.hpp
 
 inline int launch_deflate_dynamic(const DeflateArgs &a, int level, hipStream_t st)
 {
-	if (level >= HD_WG_LEVEL && !a.parts) {              // the workgroup levels: one workgroup per block, then the emit-only kernel
+	// the workgroup levels: one workgroup per block, then the emit-only kernel (the one-wavefront one, or -- a.lat, the
+	// per-block boundary -- a workgroup per member: hd_emit_wg.hpp).  Since round 5 these levels have no other form: the
+	// latency segments parsed in parts (a.parts) are level 2's alone
+	if (level >= HD_WG_LEVEL) {
 		launch_wg(a, level, st);
 		return 0;
 	}
-	if (level == 2)
-		launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
-	else if (level == 3)
-		launch_level<HD_L3_WIN_BITS, HD_L3_HASH_BITS, HD_L3_MIN_LEN, 0, HD_INTRA_DIST, 0, true>(a, level, st);
-	else if (level == 4)
-		launch_level<HD_L4_WIN_BITS, HD_L4_HASH_BITS, HD_L4_MIN_LEN, 1, HD_INTRA_DIST, 0, true>(a, level, st);
-	else if (level < HD_DEEP_LEVEL)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 0, true>(a, level, st);
-	else            // levels 6..9, latency segments parsed in parts: the two-way tables in the 8 KiB geometry (a part is 2 KiB)
-		launch_level<HD_L5_WIN_BITS, HD_L5_HASH_BITS, HD_L5_MIN_LEN, 1, HD_INTRA_DIST, 1, true>(a, 6, st);
+	launch_level<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, HD_INTRA_DIST>(a, level, st);
 	return 0;
 }
 

@@ -75,6 +75,12 @@ struct DeflateArgs {
 	// != 0: the records in `scratch` are the workgroup parse's (hd_deflate_wg.hpp wg_layout: a token per byte, a DEFLATE
 	// block per HD_WG_SPLIT_MIN bytes); the emit-only kernel reads them so
 	uint32_t wg = 0;
+	// the workgroup levels, HD_FRAME_LATENCY: a handful of blocks, each wanted back soon -- the member is written by a
+	// WORKGROUP (hd_emit_wg.hpp k_emit_wg: the same bytes as the one-wavefront emit kernel, sixteen wavefronts at them)
+	uint32_t lat = 0;
+	// a device word that counts the blocks the workgroup parse gave up on because a turn did not come (WG_SPIN_LIMIT;
+	// they are written stored): hipdeflate_stall_count()
+	uint32_t *stalls = nullptr;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)

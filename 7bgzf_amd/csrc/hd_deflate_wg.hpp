@@ -39,8 +39,13 @@ constexpr uint32_t WG_STEPS = HD_WG_CUT / 64;
 constexpr uint32_t WG_AHEAD = 24;                // pieces the ring is filled ahead of the oldest piece in work (or of the table
                                                  // turn, whichever is older): piece k takes the place of piece k - 64 and a
                                                  // parser reads up to 32 pieces behind its own, so anything below 32 is safe
-constexpr uint32_t WG_SPIN_LIMIT = 1u << 16;     // a turn that does not come (~40 ms of polls where a wait is microseconds): the block is
-                                                 // given up (stored), never a hang
+#ifndef HD_WG_SPIN_LIMIT
+#define HD_WG_SPIN_LIMIT (1u << 16)
+#endif
+constexpr uint32_t WG_SPIN_LIMIT = HD_WG_SPIN_LIMIT;   // a turn that does not come (~40 ms of polls where a wait is microseconds): the block is
+                                                 // given up (stored, valid, NOT the twin's bytes) and counted in a.stalls -- never a
+                                                 // hang, never silent: hipdeflate_stall_count() (bench.py, the GPU suite and the fuzz
+                                                 // tools assert 0; tests/test_gpu_parity.py runs a build with a limit of 0 to see it move)
 static_assert(HD_WG_CUT == HD_PIECE && WG_STEPS == 16, "a piece of the parse is a piece of the ring");
 static_assert(HD_WG_RING == 65536 && HD_WG_WINDOW == 32768 && HD_WG_VCAP == 16, "the kernel is written for this geometry");
 constexpr uint32_t WG_TABLE_BYTES = 65536;      // ways x buckets x 2 at every level
@@ -448,11 +453,16 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	__syncthreads();
 	if (w == WG_NP && lane == 0) {
 		uint32_t *m = (uint32_t *)(rec + lay.off_rec);
-		m[0] = (uniform(*vfail) || refused) ? 0xffffffffu : 0u;
+		const bool stalled = uniform(*vfail) != 0;
+		m[0] = (stalled || refused) ? 0xffffffffu : 0u;
 		m[1] = crcv;
 		a.split_ovf[b] = 0;
+		if (stalled && a.stalls)
+			atomicAdd(a.stalls, 1u);
 	}
 }
+
+void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hpp
 
 // blocks [first, first + count) of a sub-batch: the workgroup parse, then the emit-only kernel over its records
 inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
@@ -475,6 +485,11 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, 0, st, s);
 		else
 			hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, 0, st, s);
+		if (a.lat) {
+			// the per-block boundary (HD_FRAME_LATENCY, blocks up to 64 KiB): the member written by a workgroup, the same bytes
+			launch_emit_wg(s, st);
+			continue;
+		}
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;
 		hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0, st, s);
 	}

@@ -55,11 +55,16 @@ extern "C" {
 #define HD_FRAME_GZIP  5     /* RFC 1952 as lib/zlibutil.c:379-405: 1f 8b 08 00 <mtime = 0> 02 00, raw
                               * DEFLATE, CRC32, ISIZE (the reference stamps time(NULL); a batch has no clock) */
 
-/* OR'ed into `frame`: LATENCY MODE for batches far smaller than the machine (hipdeflate_params.h, HD_LAT_SEG_BYTES):
- * levels >= 1 code every block longer than 4080 (level 1) / 8160 (levels >= 2) bytes as independent flushed segments
- * of that size, one wavefront each (levels >= 2: four parse wavefronts per segment, HD_LAT_PART_BYTES), stitched on
- * the device -- a 0xff00-byte block is done in about a tenth of the time one wavefront needs for it.  The bytes differ from the throughput form (both are what the CPU twin gives for
- * the same mode); bgzf_compress, hip_deflate and hip_deflate_flush use this mode. */
+/* OR'ed into `frame`: LATENCY MODE for batches far smaller than the machine -- what bgzf_compress, hip_deflate and
+ * hip_deflate_flush use (one block per call, bgzf_compress.c:163-169, lib/zlibutil.c:179-192).
+ *   levels 1..2  every block longer than 4080 (level 1) / 8160 (level 2) bytes is coded as independent flushed segments of
+ *                that size, one wavefront each (level 2: four parse wavefronts per segment, HD_LAT_PART_BYTES), stitched on
+ *                the device (hipdeflate_params.h HD_LAT_SEG_BYTES): a 0xff00-byte block in about a tenth of one wavefront's
+ *                time.  The bytes differ from the throughput form (both are what the CPU twin gives for the same mode).
+ *   levels 3..9  ONE CODEC PER LEVEL (round 5; as the reference has, deflate_compress.c:3951-3955): the flag changes the
+ *                schedule, not the stream -- the workgroup parse on the whole block and, for blocks up to 64 KiB, the member
+ *                written by a workgroup of sixteen wavefronts (hd_emit_wg.hpp) instead of by one; byte for byte the
+ *                throughput form's output. */
 #define HD_FRAME_LATENCY 0x100
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -69,9 +74,10 @@ extern "C" {
  * is a HIP device ordinal and an ordinal may be listed twice (two independent contexts on one card: how the
  * multi-device hosts are rehearsed on a one-GPU box).  The list is fixed by the first of:
  *   hipdeflate_init_devices(list, n)            an explicit list (n <= 32);
- *   hipdeflate_init(device)                     a list of one; device -1 = HIPDEFLATE_DEVICE, else LOCAL_RANK, else 0
- *                                               (a torch.distributed / RCCL rank owns one card);
- *   any other entry point, lazily               HIPDEFLATE_DEVICES=0,1,2,... if set, else as hipdeflate_init(-1).
+ *   hipdeflate_init(device)                     device >= 0: a list of one;
+ *   hipdeflate_init(-1), or any other entry     HIPDEFLATE_DEVICES=0,1,2,... if set (a list), else a list of one:
+ *   point, lazily                               HIPDEFLATE_DEVICE, else LOCAL_RANK (a torch.distributed / RCCL rank owns
+ *                                               one card), else 0.
  * Contexts are created on first use.  A thread's calls run on entry 0 unless it chose another with
  * hipdeflate_use_device(index) (thread-local, like hipSetDevice); pipes and latency contexts stay on the entry they
  * were opened on whatever thread calls them; the LD_PRELOAD hook and the per-block codecs spread their batch contexts
@@ -85,6 +91,11 @@ void hipdeflate_shutdown(void);              /* every context; the next call con
 int  hipdeflate_available(void);
 /* human-readable build/device description, never NULL */
 const char *hipdeflate_version(void);
+/* Blocks the workgroup parse (levels >= 3) has given up on since the contexts were made, over all of them: a table turn that
+ * did not come within ~40 ms of polling (a preempted or single-stepped device) -- such a block is written STORED: valid, status
+ * 0, but not the bytes an undisturbed run writes.  0 in every healthy run; bench.py, the GPU tests and the fuzz tools assert
+ * it.  (Synchronises the devices.) */
+uint64_t hipdeflate_stall_count(void);
 
 /* ---- per-block codecs: drop-in zlibutil backends ------------------------ */
 
@@ -92,8 +103,8 @@ const char *hipdeflate_version(void);
  * Output is raw DEFLATE ending in a BFINAL block.  Levels (include/hipdeflate_params.h): 0 stored; 1 greedy + static Huffman
  * (the speed level); 2 greedy + dynamic Huffman in one wavefront's 4 KiB window; 3..9 the workgroup parse -- a 32 KiB window and a
  * 64 KiB multi-way table shared by a workgroup, block splitting -- with 1 way greedy (3), 1 way lazy (4), 2 ways (5), 4 ways (6..9):
- * level 3 is below the reference's libdeflate level 1 in size on every measured set, level 6 within 3 % of its level 6.  (The
- * per-call forms here and the hook take latency mode, which keeps the one-wavefront parse of rounds 2-3 at every dynamic level.)
+ * level 3 is below the reference's libdeflate level 1 in size on every measured set, level 6 within 3 % of its level 6 -- through
+ * every entry point: the per-call forms here and the hook write the batch calls' bytes at levels >= 3 (HD_FRAME_LATENCY above).
  * In the batch calls below, levels >= 3 refuse (status != 0) a block that is longer than the room its slot leaves for the payload,
  * whatever it would have compressed to: the parse's records are sized by the slot.  The reference's callers allocate 1.5 x the block.
  * Re-entrant and thread-safe; concurrent callers whose room covers the latency form's worst case and the stored form share launches

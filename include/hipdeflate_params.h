@@ -235,7 +235,7 @@
 #define HD_LAT_SEG_PRIME   1           /* 0: segments are not primed, only parts (A/B builds: tools/exp_seg_prime.sh) */
 #endif
 #define HD_LAT_PARTS_MAX   4u
-#define HD_LAT_PARTS(level, seg) ((level) >= 2 && (seg) == HD_LAT_SEG_BYTES(level) ? HD_LAT_PARTS_MAX : 0u)
+#define HD_LAT_PARTS(level, seg) ((level) >= 2 && (level) < HD_WG_LEVEL && (seg) == HD_LAT_SEG_BYTES(level) ? HD_LAT_PARTS_MAX : 0u)
 
 /* one compressed stream handed to the inflate kernel must be shorter than this: it keeps stream positions
  * as 32-bit bit counts (8 n + 64 + 24 < 2^32) */

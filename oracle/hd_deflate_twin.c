@@ -955,12 +955,14 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 {
 	/* (the per-block codecs and the hook take the latency form only when the room covers its worst case, and the
 	 * ordinary form otherwise -- as libdeflate_deflate they succeed whenever the stored form fits) */
+	/* the workgroup levels take a block of any length as one stream, in EITHER mode: one codec per level (round 5; the
+	 * reference's deflate_compress.c:3951-3955 -- what bgzf_compress.c:163-169 and lib/zlibutil.c:179-192 call is what
+	 * applet/7bgzf.c's loop calls).  On the device latency mode only changes who writes the member (hd_emit_wg.hpp) */
+	if (level >= HD_WG_LEVEL)
+		return deflate_wg(dest, destLen, source, sourceLen, flush, level);
 	if (level >= 1 && lat && sourceLen > HD_LAT_SEG_BYTES(level) &&
 	    *destLen >= HD_SEGN_WORST((uint64_t)sourceLen, HD_LAT_SEG_BYTES(level), flush))
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_LAT_SEG_BYTES(level));
-	if (level >= HD_WG_LEVEL && !part)      /* the workgroup levels take a block of any length as one stream (a latency
-	                                         * segment parsed in parts keeps the two-way tables of its part wavefronts) */
-		return deflate_wg(dest, destLen, source, sourceLen, flush, level);
 	if (level >= 1 && sourceLen > HD_SEG_LIMIT)
 		return twin_segmented(dest, destLen, source, sourceLen, level, flush, HD_SEG_BYTES);
 	if (level <= 0)
@@ -970,16 +972,7 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level == 2)
 		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
 				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part, prime);
-	if (level == 3)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L3_WIN_BITS, HD_L3_HASH_BITS,
-				       HD_L3_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part, prime);
-	if (level == 4)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L4_WIN_BITS, HD_L4_HASH_BITS,
-				       HD_L4_MIN_LEN, 1, HD_INTRA_DIST, flush, 0, part, prime);
-	/* level 5: the one-way table; levels 6..9 (latency segments parsed in parts; every other form of these levels is the
-	 * workgroup parse above): the same geometry with the two-way buckets */
-	return deflate_dynamic(dest, destLen, source, sourceLen, HD_L5_WIN_BITS, HD_L5_HASH_BITS,
-			       HD_L5_MIN_LEN, 1, HD_INTRA_DIST, flush, level >= HD_DEEP_LEVEL, part, prime);
+	return write_stored(dest, destLen, source, sourceLen, flush);   /* (not reached) */
 }
 
 int hdo_deflate_twin(uint8_t *dest, size_t *destLen, const uint8_t *source,

@@ -289,6 +289,17 @@ RATIO_BOUNDS = {
 }
 
 
+# The LATENCY form (hipdeflate.h HD_FRAME_LATENCY: what bgzf_compress, hip_deflate and the reference's own loops on the
+# backend write) against the reference's encoders, in a BGZF member's room (round 4: hook hip6 0.2770 against
+# the reference's libdeflate1 0.2731).  Since round 5 the latency form of levels >= 3 is the throughput form's bytes, so these
+# rows are implied by RATIO_BOUNDS -- they stay as the statement about the BOUNDARY: twin (CPU) and hip_deflate (GPU)
+LAT_RATIO_BOUNDS = {
+    (6, "libdeflate1"): {"fastq/65280": 0.985, "text/65280": 0.985},
+    (6, "libdeflate6"): {"fastq/65280": 1.045, "text/65280": 1.045},
+    (3, "libdeflate1"): {"fastq/65280": 1.01, "text/65280": 1.01},
+}
+
+
 def ratio_sets():
     import json
     for e in json.load(open(os.path.join(GOLDEN, "ratio_ref.json"))):

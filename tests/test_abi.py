@@ -62,6 +62,20 @@ def test_fails_loudly_without_gpu(pkg):
         pkg.bgzf_compress_bytes(b"abc")
 
 
+def test_device_list_from_the_environment_survives_init_minus_one(pkg):
+    """hipdeflate_init(-1) -- what every host tool calls first -- reads HIPDEFLATE_DEVICES like the lazy entry points do
+    (ADVICE r4: it used to pin a list of one, so `hd7bgzf -g 2` under HIPDEFLATE_DEVICES=0,0 put both pipes on entry 0);
+    an explicit ordinal is still a list of one.  No GPU needed: the list is configured before a context is made."""
+    child = ("import ctypes,sys; L=ctypes.CDLL(%r); r=L.hipdeflate_init(int(sys.argv[1])); "
+             "print('COUNT', L.hipdeflate_device_count())") % pkg.LIB_PATH
+    for arg, env, want in (("-1", {"HIPDEFLATE_DEVICES": "0,0"}, 2), ("-1", {"HIPDEFLATE_DEVICES": "0,1,2"}, 3),
+                           ("-1", {}, 1), ("0", {"HIPDEFLATE_DEVICES": "0,0"}, 1)):
+        e = {k: v for k, v in os.environ.items() if k != "HIPDEFLATE_DEVICES"}
+        e.update(env)
+        p = subprocess.run([__import__("sys").executable, "-c", child, arg], env=e, capture_output=True, text=True, timeout=120)
+        assert "COUNT %d" % want in p.stdout, (arg, env, p.stdout, p.stderr[-500:])
+
+
 def test_hook_constants_without_gpu(pkg):
     """slen == 0 -> canned EOF member; too-small capacity -> -1 (bgzf_compress.c:40-51)."""
     import json
@@ -155,7 +169,13 @@ def test_kernel_resource_budgets():
     # kernels, so the 16 / 32 KiB geometries of rounds 2-3 are gone)
     # (round 4, later: levels 3..9 reach the one-wavefront kernels only for their latency segments, parsed in parts: their fused
     # kernels are not instantiated any more -- the fused kernel is level 2's)
-    assert len(dyn) == 1 and len(emit) == 2 and len(sta) == 7 and len(inf) == 1 and len(inf_lat) == 1 and len(wg) == 4, list(kernels)
+    # (round 5: levels 3..9 are the workgroup parse in EVERY form -- one codec per level --, their member written by the one-wavefront
+    # emit kernel or, behind the per-block boundary, by a workgroup (k_emit_wg); the one-wavefront parse kernels left are level 1's
+    # (plain and primed) and level 2's)
+    emit_wg = {k: v for k, v in kernels.items() if "k_emit_wg" in k}
+    assert len(dyn) == 1 and len(emit) == 2 and len(sta) == 3 and len(inf) == 1 and len(inf_lat) == 1 and len(wg) == 4 and len(emit_wg) == 1, list(kernels)
+    (v,) = emit_wg.values()
+    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 163840, v      # sixteen wavefronts, one workgroup per CU
     for k, v in kernels.items():
         assert v["ScratchSize"] == 0, (k, v)
     for k, v in dyn.items():

@@ -182,6 +182,9 @@ def test_hd7bgzf_g2_over_the_device_list_equals_g1(pkg, tmp_path):
         assert pkg.bgzf_decompress_bytes(outs[0]) == data
         p = subprocess.run([exe, "-d", "-g2"], input=outs[0], env=env2, capture_output=True)
         assert p.returncode == 0 and p.stdout == data
+    # -g N needs N entries in the list: a shorter HIPDEFLATE_DEVICES is an error, not N pipes on one entry
+    p = subprocess.run([exe, "-G1", "-g3"], input=data[:100000], env=env2, capture_output=True)
+    assert p.returncode != 0 and b"has 2 entries" in p.stderr, p.stderr[-500:]
 
 
 def test_hip_deflate_from_32_threads_mixed_levels_frames_and_rooms(pkg):

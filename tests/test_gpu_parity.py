@@ -357,6 +357,29 @@ def test_ratio_envelope(pkg, level, refkey):
         assert got <= hdtest.RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))
 
 
+@pytest.mark.parametrize("level,refkey", sorted(hdtest.LAT_RATIO_BOUNDS))
+def test_latency_form_ratio_against_the_reference(pkg, level, refkey):
+    """The per-block boundary against the REFERENCE's encoders: hip_deflate() -- one block per call, as
+    lib/zlibutil.c:179-192 is called -- on the 0xff00-byte sets of tests/golden/ratio_ref.json, in the room of a BGZF member:
+    level 6 below the reference's libdeflate level 1 and within 4.5 % of its level 6, level 3 at its level 1; every stream ==
+    the twin's latency form == (levels >= 3) the throughput form."""
+    for name, e, data in hdtest.ratio_sets():
+        if name not in hdtest.LAT_RATIO_BOUNDS[(level, refkey)]:
+            continue
+        nb, blk, total = e["nblocks"], e["block"], 0
+        for i in range(nb):
+            chunk = data[i * blk:(i + 1) * blk]
+            r, z = pkg.hip_deflate(chunk, level, cap=65536 - 26)
+            assert r == 0
+            if i in (0, nb // 2, nb - 1):
+                assert z == hdtest.codec_twin(chunk, level, cap=65536 - 26)[1] == hdtest.oracle_twin(chunk, level, cap=65536 - 26)[1]
+                assert zlib.decompress(z, -15) == chunk
+            total += len(z)
+        got = total / e["ref_bytes"][refkey]
+        assert got <= hdtest.LAT_RATIO_BOUNDS[(level, refkey)][name], (name, level, refkey, round(got, 4))
+    assert pkg.lib().hipdeflate_stall_count() == 0
+
+
 @pytest.mark.parametrize("level", [1, 2, 6])
 def test_encode_long_blocks_in_segments_every_frame_and_the_capacity_rule(pkg, level):
     """Blocks longer than HD_SEG_LIMIT are coded as flushed 0xff00-byte segments and stitched on the device
@@ -807,10 +830,10 @@ def test_device_huffman_construction_matches_oracle_on_adversarial_frequencies(p
 
 @pytest.mark.parametrize("level", [1, 2, 3, 6, 9])
 def test_latency_mode_members_match_twin(pkg, level):
-    """HD_FRAME_LATENCY: every block longer than HD_LAT_SEG_BYTES(level) is coded as independent flushed segments
-    (4080 bytes at level 1, 8160 above), one wavefront each, stitched on the device.  Member == CPU twin in the
-    same mode, == input after zlib, CRC-32 folded from the segments' == zlib.crc32; blocks up to the segment
-    size are the ordinary form; in BGZF, RAW and flush framing."""
+    """HD_FRAME_LATENCY.  Levels 1-2: every block longer than HD_LAT_SEG_BYTES(level) is coded as independent flushed
+    segments (4080 bytes at level 1, 8160 at level 2), one wavefront each, stitched on the device.  Levels >= 3 (round 5):
+    the workgroup parse on the whole block and the member written by a workgroup (k_emit_wg) -- the throughput form's bytes.
+    Member == CPU twin in the same mode, == input after zlib, CRC-32 == zlib.crc32; in BGZF, RAW and flush framing."""
     s = hdtest.synth()
     blocks = [bytes(s.fastq_like(0xff00, seed=60)), bytes(s.text_like(0xff00, seed=61)), bytes(s.random_bytes(0xff00, seed=62)),
               bytes(0xff00), bytes(s.fastq_like(4080, seed=63)), bytes(s.fastq_like(4081, seed=64)),
@@ -832,8 +855,11 @@ def test_latency_mode_members_match_twin(pkg, level):
             r, twin = fn(b, level, cap=65536 - hdr - trl)
             assert r == 0 and m[hdr:len(m) - trl] == twin, (i, frame, level, len(m), len(twin))
             assert int(crc[i]) == zlib.crc32(b), i
-            if len(b) > seg:                                 # really segmented: a flush marker inside
-                assert twin != (hdtest.oracle_twin_flush if frame == pkg.FRAME_RAW_FLUSH else hdtest.oracle_twin)(b, level)[1]
+            plain = (hdtest.oracle_twin_flush if frame == pkg.FRAME_RAW_FLUSH else hdtest.oracle_twin)(b, level, cap=65536 - hdr - trl)[1]
+            if level >= 3:                                   # one codec per level: latency mode changes the schedule, not the stream
+                assert twin == plain, (i, frame, level)
+            elif len(b) > seg:                               # really segmented: a flush marker inside
+                assert twin != plain
             if frame == pkg.FRAME_BGZF:
                 assert int.from_bytes(m[16:18], "little") == len(m) - 1 and len(m) <= 65536
                 assert int.from_bytes(m[-8:-4], "little") == zlib.crc32(b) and int.from_bytes(m[-4:], "little") == len(b)
@@ -920,3 +946,46 @@ print("ok")
             env["BGZF_METHOD"] = method
         p = subprocess.run([sys.executable, "-c", prog, str(want)], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0 and "ok" in p.stdout, (method, p.stdout[-300:], p.stderr[-600:])
+
+
+def test_workgroup_parse_stalls_are_counted(pkg):
+    """The one timing-dependent byte path: a workgroup whose table turn does not come within
+    WG_SPIN_LIMIT polls gives the block up and it is written STORED with status 0 -- valid, but not the twin's bytes.  It is
+    counted: hipdeflate_stall_count().  The product build must show 0 after everything this suite ran (asserted here and
+    in bench.py's `verified`); a build with a limit of ZERO polls (libhipdeflate_stall.so, Makefile) makes the counter move,
+    and what it writes still inflates to the input."""
+    import subprocess
+    import sys
+    assert pkg.lib().hipdeflate_stall_count() == 0
+    so = os.path.join(os.path.dirname(pkg.LIB_PATH), "libhipdeflate_stall.so")
+    assert os.path.exists(so), "make -C 7bgzf_amd/csrc"
+    prog = r'''
+import ctypes, sys, zlib
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hdtest
+L = ctypes.CDLL(%r)
+L.hipdeflate_stall_count.restype = ctypes.c_uint64
+nb, blk = 24, 0xff00
+data = np.frombuffer(bytes(hdtest.synth().text_like(nb * blk, seed=5)), dtype=np.uint8).copy()
+off = (np.arange(nb, dtype=np.uint64) * blk)
+ln = np.full(nb, blk, dtype=np.uint32)
+out = np.zeros(nb * 65536, dtype=np.uint8)
+olen = np.zeros(nb, dtype=np.uint32); crc = np.zeros(nb, dtype=np.uint32); st = np.zeros(nb, dtype=np.int32)
+p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+for frame in (0, 0x100):                                     # the throughput form, the latency form (k_emit_wg)
+    r = L.hipdeflate_batch_deflate(p(data), p(off), p(ln), nb, 6, frame, p(out), ctypes.c_uint64(65536), 65536, p(olen), p(crc), p(st))
+    assert r == 0 and not st.any(), (r, st)
+    stored = 0
+    for i in range(nb):
+        m = bytes(out[i * 65536:i * 65536 + olen[i]])
+        assert zlib.decompress(m, -15) == bytes(data[i * blk:(i + 1) * blk]), i
+        stored += len(m) > blk
+    print("STORED", frame, stored)
+print("STALLS", L.hipdeflate_stall_count())
+''' % (hdtest.ROOT, os.path.join(hdtest.ROOT, "tests"), so)
+    p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    stalls = int(p.stdout.split("STALLS")[1].split()[0])
+    stored = sum(int(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("STORED"))
+    assert stalls > 0 and stalls == stored, p.stdout[-500:]
