@@ -539,9 +539,10 @@ uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
 
 /* ---- device-pointer API ---------------------------------------------------- */
 
-int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, int level,
-				 int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
-				 void *crc32, void *status, void *stream)
+// max_in: the longest block of the batch where the host knows the lengths (0: only the device does)
+static int batch_deflate_dev_impl(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, int level,
+				  int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
+				  void *crc32, void *status, void *stream, uint32_t max_in)
 {
 	Ctx &g = cur();
 	int r = ensure();
@@ -576,8 +577,11 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 	const uint32_t seg_lim = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_LIMIT;
 	a.seg_bytes = latency ? HD_LAT_SEG_BYTES(level) : HD_SEG_BYTES;
 	a.seg_limit = (level >= 1 && level < HD_WG_LEVEL && a.split_max > seg_lim) ? seg_lim : 0;
-	// the workgroup levels in latency mode: the same bytes, the member written by a workgroup (blocks up to 64 KiB: the
-	// parse refuses a block longer than its slot, so a slot of at most that says it for every block)
+	// the workgroup levels: the parse's records are sized by the longest block where the host knows it, else by the slot
+	// (k_parse_wg refuses a block longer than its record)
+	if (level >= HD_WG_LEVEL && max_in)
+		a.split_max = max_in;
+	// ... and in latency mode the member is written by a workgroup, the same bytes (blocks up to 64 KiB)
 	a.lat = (latency && level >= HD_WG_LEVEL && a.split_max <= hd::EW_BLOCK_MAX) ? 1u : 0u;
 	a.stalls = g.d_stalls;
 	a.hint = 0;
@@ -605,6 +609,14 @@ int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void 
 		return r;
 	}
 	return launch_deflate(a, level, (hipStream_t)stream);
+}
+
+int hipdeflate_batch_deflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, int level,
+				 int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
+				 void *crc32, void *status, void *stream)
+{
+	return batch_deflate_dev_impl(in, in_off, in_len, nblocks, level, frame, out, out_stride, out_cap, out_len, crc32, status,
+				      stream, 0);
 }
 
 static int batch_inflate_dev(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, void *out,
@@ -763,8 +775,9 @@ int hipdeflate_batch_deflate(const uint8_t *in, const uint64_t *in_off, const ui
 	uint64_t *d_doff = (uint64_t *)(d_st + nblocks);
 	HD_CHECK(hipMemcpyAsync(g.d_in.p, hin, in_total, hipMemcpyHostToDevice, g.stream));
 	HD_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)nblocks * 12, hipMemcpyHostToDevice, g.stream));
-	r = hipdeflate_batch_deflate_dev(g.d_in.p, d_off, d_len, nblocks, level, frame, g.d_slots.p, slot,
-					 (uint32_t)(cap_user < slot ? cap_user : slot), d_olen, d_crc, d_st, g.stream);
+	r = batch_deflate_dev_impl(g.d_in.p, d_off, d_len, nblocks, level, frame, g.d_slots.p, slot,
+				   (uint32_t)(cap_user < slot ? cap_user : slot), d_olen, d_crc, d_st, g.stream,
+				   max_len ? (uint32_t)max_len : 1u);
 	if (r)
 		return r;
 	// gather on the device so that only the compressed bytes cross PCIe
@@ -1031,8 +1044,8 @@ int hipdeflate_pipe_submit(hipdeflate_pipe *p, size_t nbytes)
 		uint64_t *d_total = d_doff + s.nb;
 		HD_CHECK(hipMemcpyAsync(s.d_in.p, s.h_in.p, nbytes, hipMemcpyHostToDevice, s.st));
 		HD_CHECK(hipMemcpyAsync(d_off, h_off, (size_t)s.nb * 12, hipMemcpyHostToDevice, s.st));
-		if ((r = hipdeflate_batch_deflate_dev(s.d_in.p, d_off, d_len, s.nb, p->level, p->frame, s.d_slots.p,
-						      p->slot_stride, (uint32_t)p->slot_stride, d_olen, d_crc, d_st, s.st)))
+		if ((r = batch_deflate_dev_impl(s.d_in.p, d_off, d_len, s.nb, p->level, p->frame, s.d_slots.p,
+						p->slot_stride, (uint32_t)p->slot_stride, d_olen, d_crc, d_st, s.st, p->block)))
 			return r;
 		if ((r = hipdeflate_scan_sizes_dev(d_olen, s.nb, 0, d_doff, d_total, s.st)))
 			return r;
@@ -1406,7 +1419,8 @@ hipdeflate_lat *hipdeflate_lat_open(int level, int frame, uint32_t max_blocks, u
 	c->meta_seg = (((size_t)max_blocks * (8 + 4 + 4 + 4 + 4)) + 15) & ~(size_t)15;
 	const size_t meta = c->meta_seg + (size_t)max_blocks * c->S * 12 + 64;
 	c->flag_off = meta - 16;
-	const uint64_t scr = scratch_need(max_blocks, c->slot, level, c->latency);
+	// (the workgroup levels' records are sized by the longest block, not by the slot)
+	const uint64_t scr = scratch_need(max_blocks, level >= HD_WG_LEVEL ? c->in_stride : c->slot, level, c->latency);
 	if (c->h_in.reserve((size_t)max_blocks * c->in_stride) || c->h_out.reserve((size_t)max_blocks * c->slot) ||
 	    c->h_meta.reserve(meta) || (scr && c->d_scratch.reserve(scr)) || c->d_count.reserve(16) ||
 	    hipMemset(c->d_count.p, 0, 16) != hipSuccess ||
@@ -1493,12 +1507,12 @@ static int lat_run_ex(hipdeflate_lat *c, const uint32_t *in_len, uint32_t n, int
 	a.first = 0;
 	a.count = 0;
 	a.skip_small = 0;
-	a.split_max = hd::split_max_block(c->slot, c->slot);
+	a.split_max = c->level >= HD_WG_LEVEL ? c->in_stride : hd::split_max_block(c->slot, c->slot);
 	a.split_ovf = nullptr;
 	a.seg_bytes = c->seg;
 	a.seg_limit = seg_limit;
 	// the workgroup levels: the member written by a workgroup (hd_emit_wg.hpp) when no block can be longer than 64 KiB
-	a.lat = (latency && c->level >= HD_WG_LEVEL && c->in_stride <= hd::EW_BLOCK_MAX) ? 1u : 0u;
+	a.lat = (latency && c->level >= HD_WG_LEVEL && a.split_max <= hd::EW_BLOCK_MAX) ? 1u : 0u;
 	a.stalls = g.d_stalls;
 	a.hint = seg_limit ? hint : 0;
 	a.host_seg_off = seg_limit ? (const uint64_t *)(c->dmeta + c->meta_seg) : nullptr;

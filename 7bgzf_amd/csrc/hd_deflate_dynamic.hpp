@@ -172,8 +172,11 @@ struct HuffScratch {
 
 // Code lengths + canonical (bit-reversed) codewords for one alphabet.
 // out[s] = code | len << 16.  Mirrors build_code() of the twin step by step.
+// lone: the caller is a wavefront ALONE on its SIMD (k_emit_wg): the register form of the merge below -- fewer instructions, what
+// sixteen emit wavefronts per CU want -- is a chain of v_readlane -> scalar compare -> branch that such a wavefront runs at ~670
+// cycles per node; the lane-0 form against LDS takes ~210 (measured, tools/exp_emit_wg_stats.py)
 __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms, uint32_t maxbits, uint32_t *out,
-					 HuffScratch &h, uint32_t lane)
+					 HuffScratch &h, uint32_t lane, bool lone = false)
 {
 	BUILD_T0();
 	// working copy, dummies so that at least two symbols are used
@@ -231,7 +234,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 	BUILD_T(1);
 	// The serial part: the two-queue merge and the depths of its nodes.
 	nu = uniform(nu);
-	if (nu <= 128) {
+	if (nu <= 128 && !lone) {
 		// Up to 128 used symbols -- every offset and precode alphabet, the litlen alphabet of DNA-like data and most text --:
 		// the queues live in REGISTERS, element x in lane x % 64 of register x / 64, and the whole wave runs the loop in
 		// step.  A head is two v_readlane and a scalar select, a store is two compare-and-select pairs over all lanes, the

@@ -129,13 +129,11 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	WG_LDS WgLds *const Lp = (WG_LDS WgLds *)&L;
 	const wg_word_p vturn = (wg_word_p)&Lp->turn, vfilled = (wg_word_p)&Lp->filled, vfail = (wg_word_p)&Lp->fail,
 			vcur = (wg_word_p)Lp->cur;
-	// A block longer than the room its slot leaves for the payload is refused (the member is then tried stored, which does
-	// not fit either: status 1) -- the records are sized by the slot (wg_layout(a.split_max)), and the twin says the same
-	const uint32_t hdr_b = frame_hdr_bytes(a.frame), trl_b = frame_trl_bytes(a.frame), sfx_b = frame_sfx_bytes(a.frame);
-	uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
-	if (a.frame == HD_FRAME_BGZF && cap64 > 65536)
-		cap64 = 65536;
-	const bool refused = cap64 < hdr_b + trl_b + sfx_b || n > cap64 - hdr_b - trl_b - sfx_b;
+	// The records are sized by a.split_max: the longest block of the launch where the host knows the lengths (the
+	// host-pointer calls, pipes, latency contexts, the per-block codecs: round 5 -- a block LONGER THAN ITS ROOM is coded and
+	// goes through whenever its stream fits, as libdeflate_deflate's does, lib/zlibutil.c:179-192; rounds 4 refused it), the
+	// slot where only the device knows them (hipdeflate_batch_deflate_dev: there a block longer than its slot is refused)
+	const bool refused = n > a.split_max;
 	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
 
 	// ---- LDS: the table zero, the words ------------------------------------------------------------------------------
@@ -143,8 +141,30 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		((uint4 *)L.table)[i] = make_uint4(0, 0, 0, 0);
 	if (threadIdx.x < WG_NW)
 		L.cur[threadIdx.x] = 0xffffffffu;
+	// A block that fits the ring whole (every BGZF block; everything behind the per-block boundary) is brought in by ALL
+	// sixteen wavefronts at once, four 16-byte loads per lane in flight, before anybody parses: the filler's one piece
+	// ahead is one memory latency per KiB -- microseconds each when the block lies in the caller's pinned memory (the
+	// hook, hip_deflate: 64 round trips over PCIe were a quarter of a lone block's parse) -- and nothing is ever replaced
+	// in the ring, so there is no order to keep.  The filler then only folds the CRC-32 (from the ring) and parses too.
+	const bool bulk = npieces <= HD_WG_RING / HD_PIECE;
+	if (bulk) {
+		uint4 v[HD_WG_RING / HD_PIECE / WG_NW];
+#pragma unroll
+		for (uint32_t i = 0; i < HD_WG_RING / HD_PIECE / WG_NW; i++)
+			if (w + WG_NW * i < npieces)
+				v[i] = load_slot(src, n, w + WG_NW * i, lane, aligned);
+#pragma unroll
+		for (uint32_t i = 0; i < HD_WG_RING / HD_PIECE / WG_NW; i++)
+			if (w + WG_NW * i < npieces) {
+				const uint32_t o = (w + WG_NW * i) * HD_PIECE + 16 * lane;
+				*(uint4 *)((uint8_t *)L.ring32 + o) = v[i];
+				if (o < 32)                        // the mirror behind the ring's end
+					*(uint4 *)((uint8_t *)L.ring32 + HD_WG_RING + o) = v[i];
+			}
+	}
 	if (threadIdx.x == 0) {
-		L.turn = L.filled = L.fail = L.next = 0;
+		L.turn = L.fail = L.next = 0;
+		L.filled = bulk ? npieces : 0u;
 		L.table[WG_TABLE_BYTES / 4] = L.table[WG_TABLE_BYTES / 4 + 1] = 0;
 	}
 	__syncthreads();
@@ -155,9 +175,13 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		CrcLanes crc;
 		crc.init(lane, n);
 		uint4 pend = make_uint4(0, 0, 0, 0);
-		if (npieces)
+		if (bulk) {
+			for (uint32_t k = 0; k < npieces; k++)
+				crc.fold(ct, k, k * HD_PIECE + 16 * lane + 16 <= n, *(const uint4 *)((const uint8_t *)L.ring32 + k * HD_PIECE + 16 * lane));
+		} else if (npieces) {
 			pend = load_slot(src, n, 0, lane, aligned);
-		for (uint32_t k = 0; k < npieces; k++) {
+		}
+		for (uint32_t k = 0; !bulk && k < npieces; k++) {
 			// piece k takes the place of piece k - 64, and a parser reads up to 32 pieces behind its own: k stays within
 			// WG_AHEAD of the oldest piece still in work (the table turn counts as one: its holder is about to start)
 			if (k > WG_AHEAD) {
@@ -197,8 +221,9 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 			crc.fold(ct, k, k * HD_PIECE + 16 * lane + 16 <= n, v);
 		}
 		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
-	} else {
-		// ================= a parser =======================================================================================
+	}
+	if (w != WG_NP || bulk) {
+		// ================= a parser (bulk: the filler too, once its CRC is folded) =====================================
 		HashConsts6 hk;
 		hk.init(WG_TABLE_BYTES / 4);               // byte offset of a bucket of 2 WAYS bytes: (2 WAYS) * slot, below 64 KiB
 		hk.m = 0x10000u - 2 * WAYS;

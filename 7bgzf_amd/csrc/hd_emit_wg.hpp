@@ -38,14 +38,27 @@ struct EwLds {
 	HuffScratch hs2;                                // wavefront 1's
 	DynLds L;                                       // the open DEFLATE block's histograms, the precode
 	uint32_t lut[512];                              // litlen half of a token: codeword (+ extra bits) | bit count << 24
+	uint32_t ph[EW_MAX_PIECES][160];                // per piece: 320 symbol counts, 16 bits each (a piece holds <= 1024 tokens):
+	                                                // litlen symbol s at half s, offset symbol d at half 288 + d
 	uint32_t piece_bits[EW_MAX_PIECES];
+	uint32_t cuts[EW_MAX_PIECES + 2];               // [0] the number of DEFLATE blocks, [1 + i] the piece behind block i
 	uint32_t lsym[64];                              // length - 3 -> litlen symbol - 257, a byte each
 	uint32_t ctl[8];                                // 0: alive  1: dynamic code  2: bit position behind the block header  3: member bytes
 };
 
+#ifdef HD_EMIT_STATS
+// experiment build only: wavefront 0's cycles by phase, g_emit_stats[0..7] (tools/exp_emit_wg_stats.py)
+#define EW_T(k) do { if (threadIdx.x == 0) { const unsigned long long t_now = clock64(); atomicAdd(&g_emit_stats[k], t_now - t_ew); t_ew = t_now; } } while (0)
+#else
+#define EW_T(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 {
 	__shared__ EwLds E;
+#ifdef HD_EMIT_STATS
+	unsigned long long t_ew = clock64();
+#endif
 	const uint32_t lane = threadIdx.x & 63, w = uniform(threadIdx.x >> 6);
 	const uint32_t bi = blockIdx.x, b = a.first + bi;
 	const uint8_t *src = a.in + a.in_off[b];
@@ -121,95 +134,145 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 		put(code, nbits, bitpos + incl - nbits);
 		bitpos += readlane(incl, 63);
 	};
-	// f(token of lane i, tokens in the group) over the tokens of piece kk, four 64-token loads in flight
-	auto for_piece_tokens = [&](uint32_t kk, auto &&f) {
-		const uint32_t cnt = readlane(pv.x, kk);
-		const uint32_t *pt = tok + kk * HD_WG_CUT;
-		for (uint32_t base = 0; base < cnt; base += 256) {
-			uint32_t v[4];
+	// f(token of lane i, tokens in the group) over the tokens of pieces first, first + step, ... below end: the first 512
+	// tokens of a piece are eight loads in flight, and the next piece's are requested before this one's are used (the
+	// tokens lie in HBM / L2 where the parse left them: a round trip per 256 tokens was half of the passes' time)
+	constexpr uint32_t PG = 8;
+	auto for_tokens = [&](uint32_t first, uint32_t end, uint32_t step, auto &&enter, auto &&f, auto &&leave) {
+		uint32_t cur[PG], nxt[PG];
+		auto load = [&](uint32_t kk, uint32_t (&v)[PG]) {
+			const uint32_t cnt = readlane(pv.x, kk);
+			const uint32_t *pt = tok + kk * HD_WG_CUT;
 #pragma unroll
-			for (uint32_t j = 0; j < 4; j++)
-				v[j] = base + 64 * j + lane < cnt ? pt[base + 64 * j + lane] : 0u;
+			for (uint32_t j = 0; j < PG; j++)
+				v[j] = 64 * j + lane < cnt ? pt[64 * j + lane] : 0u;
+		};
+		if (first < end)
+			load(first, nxt);
+		for (uint32_t kk = first; kk < end; kk += step) {
 #pragma unroll
-			for (uint32_t j = 0; j < 4; j++)
-				if (base + 64 * j < cnt)
-					f(v[j], cnt - base - 64 * j < 64 ? cnt - base - 64 * j : 64u);
+			for (uint32_t j = 0; j < PG; j++)
+				cur[j] = nxt[j];
+			if (kk + step < end)
+				load(kk + step, nxt);
+			const uint32_t cnt = readlane(pv.x, kk);
+			enter(kk);
+#pragma unroll
+			for (uint32_t j = 0; j < PG; j++)
+				if (64 * j < cnt)
+					f(cur[j], cnt - 64 * j < 64 ? cnt - 64 * j : 64u);
+			for (uint32_t base = 64 * PG; base < cnt; base += 64)       // a dense piece: the rest one load at a time
+				f(base + lane < cnt ? tok[kk * HD_WG_CUT + base + lane] : 0u, cnt - base < 64 ? cnt - base : 64u);
+			leave(kk);
 		}
 	};
+	EW_T(0);
 
-	uint32_t k = 0, block_begin = 0;
-	do {
-		// ---- the cut: every wavefront alike (the emit-only kernel's scan, hd_deflate_dynamic.hpp; the twin's wg_split_check) ----
-		uint32_t obs0 = 0, obs1 = 0, obs2 = 0, sn = 0, no0 = 0, no1 = 0, no2 = 0, snn = 0, blk_tok = 0;
-		bool end = false;
-		const uint32_t k0 = k;
-		while (k < np && !end) {
-			blk_tok += readlane(pv.x, k);
-			snn += readlane(pv.x, k);
-			no0 += readlane(pv.y, k);
-			no1 += readlane(pv.z, k);
-			no2 += readlane(pv.w, k);
-			k++;
-			const uint32_t here = k * HD_WG_CUT;
-			if (k < np) {
-				end = blk_tok >= HD_DYN_BLOCK_TOKENS;
-				if (!end && snn >= HD_WG_SPLIT_OBS && here - block_begin >= HD_WG_SPLIT_MIN && n - here >= HD_WG_SPLIT_MIN) {
-					if (sn > 0) {
-						const uint32_t e0 = obs0 * snn, a0 = no0 * sn, e1 = obs1 * snn, a1 = no1 * sn, e2 = obs2 * snn, a2 = no2 * sn;
-						const uint32_t total = (a0 > e0 ? a0 - e0 : e0 - a0) + (a1 > e1 ? a1 - e1 : e1 - a1) + (a2 > e2 ? a2 - e2 : e2 - a2);
-						const uint32_t items = sn + snn, blen = here - block_begin;
-						uint32_t cutoff = snn * 200u / 512u * sn;
-						if (blen < 10000 && items < 8192)
-							cutoff += (cutoff >> 13) * (8192u - items);
-						end = total + (blen / 4096u) * sn >= cutoff;
-					}
-					if (!end) {
-						obs0 += no0;
-						obs1 += no1;
-						obs2 += no2;
-						sn += snn;
-						no0 = no1 = no2 = snn = 0;
+	// ---- wavefront 15 cuts the DEFLATE blocks (the emit-only kernel's scan, hd_deflate_dynamic.hpp; the twin's wg_split_check)
+	// while the others count every piece's symbols into the piece's own histogram ---------------------------------------------
+	if (w == EW_NW - 1) {
+		// one v_readlane per piece: tokens | literals << 11 | short matches << 22 (each <= 1024)
+		const uint32_t pk = pv.x | (pv.y << 11) | (pv.z << 22);
+		uint32_t k = 0, block_begin = 0, nblk = 0;
+		do {
+			uint32_t obs0 = 0, obs1 = 0, obs2 = 0, sn = 0, no0 = 0, no1 = 0, no2 = 0, snn = 0, blk_tok = 0;
+			bool end = false;
+			while (k < np && !end) {
+				const uint32_t q = readlane(pk, k);
+				const uint32_t qt = q & 2047, ql = (q >> 11) & 2047, qs = q >> 22;
+				blk_tok += qt;
+				snn += qt;
+				no0 += ql;
+				no1 += qs;
+				no2 += qt - ql - qs;
+				k++;
+				const uint32_t here = k * HD_WG_CUT;
+				if (k < np) {
+					end = blk_tok >= HD_DYN_BLOCK_TOKENS;
+					if (!end && snn >= HD_WG_SPLIT_OBS && here - block_begin >= HD_WG_SPLIT_MIN && n - here >= HD_WG_SPLIT_MIN) {
+						if (sn > 0) {
+							const uint32_t e0 = obs0 * snn, a0 = no0 * sn, e1 = obs1 * snn, a1 = no1 * sn, e2 = obs2 * snn, a2 = no2 * sn;
+							const uint32_t total = (a0 > e0 ? a0 - e0 : e0 - a0) + (a1 > e1 ? a1 - e1 : e1 - a1) + (a2 > e2 ? a2 - e2 : e2 - a2);
+							const uint32_t items = sn + snn, blen = here - block_begin;
+							uint32_t cutoff = snn * 200u / 512u * sn;
+							if (blen < 10000 && items < 8192)
+								cutoff += (cutoff >> 13) * (8192u - items);
+							end = total + (blen / 4096u) * sn >= cutoff;
+						}
+						if (!end) {
+							obs0 += no0;
+							obs1 += no1;
+							obs2 += no2;
+							sn += snn;
+							no0 = no1 = no2 = snn = 0;
+						}
 					}
 				}
 			}
-		}
-		const uint32_t k1 = k;
-		block_begin = k * HD_WG_CUT;
-		if (!alive)
-			break;
-		const bool final = k == np;
+			block_begin = k * HD_WG_CUT;
+			if (lane == 0)
+				E.cuts[1 + nblk] = k;
+			nblk++;
+		} while (k < np);
+		if (lane == 0)
+			E.cuts[0] = nblk;
+	} else if (alive) {
+		uint32_t *hp = nullptr;                                     // the histogram of the piece being counted
+		for_tokens(w, np, EW_NW - 1,
+			   [&](uint32_t kk) {
+				   hp = E.ph[kk];
+				   for (uint32_t i = lane; i < 160; i += 64)
+					   hp[i] = 0;
+			   },
+			   [&](uint32_t tk, uint32_t nv) {
+				   const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
+				   const uint32_t idx = (tk >> 16) & 0x1ffu;                // literal, or 256 + (length - 3)
+				   const uint32_t sym = is_match ? 257u + lsym[idx & 0xffu] : idx;
+				   uint32_t ds, eb, ev;
+				   off_slot((tk & 0xffff) + 1, ds, eb, ev);
+				   if (lane < nv) {
+					   atomicAdd(&hp[sym >> 1], 1u << (16 * (sym & 1)));
+					   if (is_match)
+						   atomicAdd(&hp[144 + (ds >> 1)], 1u << (16 * (ds & 1)));
+				   }
+			   },
+			   [&](uint32_t) {});
+	}
+	__syncthreads();
+	EW_T(1);
+	const uint32_t nblk = alive ? uniform(E.cuts[0]) : 0u;
 
-		// ---- the block's symbols, by all wavefronts ----------------------------------------------------------------------
-		if (threadIdx.x < 288)
-			L.lf[threadIdx.x] = 0;
-		else if (threadIdx.x < 320)
-			L.df[threadIdx.x - 288] = 0;
+	for (uint32_t blk = 0; blk < nblk && alive; blk++) {
+		const uint32_t k0 = blk ? uniform(E.cuts[blk]) : 0u, k1 = uniform(E.cuts[1 + blk]);
+		const bool final = k1 == np;
+		// ---- the block's symbols: the sum of its pieces' (packed adds: a block holds < 2^16 tokens) ---------------------------
+		if (threadIdx.x < 160) {
+			uint32_t acc = 0;
+			for (uint32_t kk = k0; kk < k1; kk++)
+				acc += E.ph[kk][threadIdx.x];
+			if (threadIdx.x < 144) {
+				L.lf[2 * threadIdx.x] = acc & 0xffffu;
+				L.lf[2 * threadIdx.x + 1] = acc >> 16;
+			} else {
+				L.df[2 * (threadIdx.x - 144)] = acc & 0xffffu;
+				L.df[2 * (threadIdx.x - 144) + 1] = acc >> 16;
+			}
+		}
 		__syncthreads();
-		for (uint32_t kk = k0 + w; kk < k1; kk += EW_NW)
-			for_piece_tokens(kk, [&](uint32_t tk, uint32_t nv) {
-				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
-				const uint32_t idx = (tk >> 16) & 0x1ffu;                // literal, or 256 + (length - 3)
-				const uint32_t sym = is_match ? 257u + lsym[idx & 0xffu] : idx;
-				uint32_t ds, eb, ev;
-				off_slot((tk & 0xffff) + 1, ds, eb, ev);
-				if (lane < nv) {
-					atomicAdd(&L.lf[sym], 1u);
-					if (is_match)
-						atomicAdd(&L.df[ds], 1u);
-				}
-			});
-		__syncthreads();
+		EW_T(2);
 		// ---- the codes: litlen on wavefront 0, offset on wavefront 1 -----------------------------------------------------
 		if (w == 0) {
 			if (lane == 0)
 				L.lf[256] += 1;                             // end of block
-			build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane);
+			build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane, true);
 		} else if (w == 1) {
-			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, E.hs2, lane);
+			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, E.hs2, lane, true);
 		}
 		__syncthreads();
+		EW_T(3);
 		// ---- wavefront 0: code lengths' RLE, precode, exact costs, the choice, the header (flush_block of the emit-only
-		// kernel, statement by statement); wavefront 1: the litlen table of the dynamic code meanwhile ----------------------
+		// kernel, statement by statement); wavefront 1: the litlen table; the others: what every piece weighs, from its
+		// histogram and the code lengths (dynamic code assumed: again below should the static code win) ----------------------
 		auto fill_lut = [&]() {
 #pragma unroll
 			for (uint32_t q = 0; q < 4; q++) {
@@ -222,8 +285,32 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				E.lut[256 + i] = (mc & 0xffff) | (lev << (mc >> 16)) | (((mc >> 16) + leb) << 24);
 			}
 		};
+		auto weigh = [&](uint32_t first, uint32_t step) {
+			for (uint32_t kk = first; kk < k1; kk += step) {
+				uint32_t bits = 0;
+				for (uint32_t i = lane; i < 160; i += 64) {
+					const uint32_t c = E.ph[kk][i];
+					uint32_t n0, n1;                                   // bits of one symbol 2 i / 2 i + 1: codeword + extra bits
+					if (i < 144) {
+						const uint32_t s0 = 2 * i, s1 = 2 * i + 1;
+						n0 = (Bd.lcode[s0] >> 16) + ((s0 >= 265 && s0 < 285) ? (s0 - 261) >> 2 : 0u);
+						n1 = (Bd.lcode[s1] >> 16) + ((s1 >= 265 && s1 < 285) ? (s1 - 261) >> 2 : 0u);
+					} else {
+						const uint32_t d0 = 2 * (i - 144), d1 = d0 + 1;
+						n0 = (Bd.dcode[d0] >> 16) + (d0 < 4 ? 0u : (d0 >> 1) - 1);
+						n1 = (Bd.dcode[d1] >> 16) + (d1 < 4 ? 0u : (d1 >> 1) - 1);
+					}
+					bits += (c & 0xffffu) * n0 + (c >> 16) * n1;
+				}
+				bits = readlane(wave_incl_scan(bits), 63);
+				if (lane == 0)
+					E.piece_bits[kk] = bits;
+			}
+		};
 		if (w == 1)
 			fill_lut();
+		if (w >= 2)
+			weigh(k0 + w - 2, EW_NW - 2);
 		if (w == 0) {
 			if (lane < 19)
 				L.pfreq[lane] = 0;
@@ -294,7 +381,7 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				}
 				ni += readlane(incl, 63);
 			}
-			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane);
+			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane, true);
 			uint32_t hclen = 19;
 			while (hclen > 4 && (uniform(L.pcode[k_perm19[hclen - 1]]) >> 16) == 0)
 				hclen--;
@@ -350,13 +437,6 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				}
 			} else if (fits) {
 				emit1(lane == 0 ? ((final && !flush) ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
-				for (uint32_t s = lane; s < 288; s += 64) {
-					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
-					const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
-					Bd.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
-				}
-				if (lane < 32)
-					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
 			}
 			if (lane == 0) {
 				E.ctl[0] = fits ? 1u : 0u;
@@ -365,59 +445,58 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 			}
 		}
 		__syncthreads();
+		EW_T(4);
 		alive = uniform(E.ctl[0]) != 0;
 		if (!alive)
 			break;
 		bitpos = uniform(E.ctl[2]);
-		if (uniform(E.ctl[1]) == 0) {                    // the static code won (rare): the table again, from the codes wavefront 0 left
+		if (uniform(E.ctl[1]) == 0) {
+			// the static code won (rare): its codes in place of the dynamic ones, the table and the pieces' weights again
+			if (w == 0) {
+				for (uint32_t s = lane; s < 288; s += 64) {
+					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
+					const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
+					Bd.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
+				}
+				if (lane < 32)
+					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
+			}
+			__syncthreads();
 			if (w == 1)
 				fill_lut();
+			if (w >= 2)
+				weigh(k0 + w - 2, EW_NW - 2);
 			__syncthreads();
 		}
-		// ---- what every piece weighs ---------------------------------------------------------------------------------------
-		for (uint32_t kk = k0 + w; kk < k1; kk += EW_NW) {
-			uint32_t bits = 0;
-			for_piece_tokens(kk, [&](uint32_t tk, uint32_t nv) {
-				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
-				const uint32_t na = E.lut[(tk >> 16) & 0x1ffu] >> 24;
-				uint32_t ds, deb, dev;
-				off_slot((tk & 0xffff) + 1, ds, deb, dev);
-				const uint32_t nb = is_match ? (Bd.dcode[ds] >> 16) + deb : 0u;
-				bits += lane < nv ? na + nb : 0u;
-			});
-			bits = readlane(wave_incl_scan(bits), 63);
-			if (lane == 0)
-				E.piece_bits[kk] = bits;
-		}
-		__syncthreads();
-		// ---- ... gives every piece its place; the pieces are coded side by side --------------------------------------------
+		// ---- every piece has its place; the pieces are coded side by side ----------------------------------------------------
 		const uint32_t pb = (lane >= k0 && lane < k1) ? E.piece_bits[lane] : 0u;
 		const uint32_t pincl = wave_incl_scan(pb);
-		for (uint32_t kk = k0 + w; kk < k1; kk += EW_NW) {
-			uint32_t bp = bitpos + readlane(pincl, kk) - readlane(pb, kk);
-			for_piece_tokens(kk, [&](uint32_t tk, uint32_t nv) {
-				const bool valid = lane < nv;
-				const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
-				const uint32_t le = E.lut[(tk >> 16) & 0x1ffu];
-				const uint32_t ca = le & 0xffffffu, na = le >> 24;
-				uint32_t ds, deb, dev;
-				off_slot((tk & 0xffff) + 1, ds, deb, dev);
-				const uint32_t dc = Bd.dcode[ds];
-				const uint32_t cb = (dc & 0xffff) | (dev << (dc >> 16));
-				const uint32_t nb = is_match ? (dc >> 16) + deb : 0u;
-				const uint32_t nbits = valid ? na + nb : 0u;
-				const uint64_t code = valid ? ((uint64_t)ca | ((uint64_t)(is_match ? cb : 0u) << na)) : 0ull;
-				const uint32_t incl = wave_incl_scan(nbits);
-				const uint32_t at = bp + incl - nbits;
-				const uint32_t sh = at & 31, i = at >> 5;
-				const uint64_t lo = code << sh;                      // bits [0, 64) of the shifted field
-				const uint32_t hi = sh ? (uint32_t)(code >> (64 - sh)) : 0u;   // and what a 48-bit field spills beyond
-				atomicOr(&E.stage[i], (uint32_t)lo);
-				atomicOr(&E.stage[i + 1], (uint32_t)(lo >> 32));
-				atomicOr(&E.stage[i + 2], hi);
-				bp += readlane(incl, 63);
-			});
-		}
+		uint32_t bp = 0;
+		for_tokens(k0 + w, k1, EW_NW,
+			   [&](uint32_t kk) { bp = bitpos + readlane(pincl, kk) - readlane(pb, kk); },
+			   [&](uint32_t tk, uint32_t nv) {
+				   const bool valid = lane < nv;
+				   const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
+				   const uint32_t le = E.lut[(tk >> 16) & 0x1ffu];
+				   const uint32_t ca = le & 0xffffffu, na = le >> 24;
+				   uint32_t ds, deb, dev;
+				   off_slot((tk & 0xffff) + 1, ds, deb, dev);
+				   const uint32_t dc = Bd.dcode[ds];
+				   const uint32_t cb = (dc & 0xffff) | (dev << (dc >> 16));
+				   const uint32_t nb = is_match ? (dc >> 16) + deb : 0u;
+				   const uint32_t nbits = valid ? na + nb : 0u;
+				   const uint64_t code = valid ? ((uint64_t)ca | ((uint64_t)(is_match ? cb : 0u) << na)) : 0ull;
+				   const uint32_t incl = wave_incl_scan(nbits);
+				   const uint32_t at = bp + incl - nbits;
+				   const uint32_t sh = at & 31, i = at >> 5;
+				   const uint64_t lo = code << sh;                      // bits [0, 64) of the shifted field
+				   const uint32_t hi = sh ? (uint32_t)(code >> (64 - sh)) : 0u;   // and what a 48-bit field spills beyond
+				   atomicOr(&E.stage[i], (uint32_t)lo);
+				   atomicOr(&E.stage[i + 1], (uint32_t)(lo >> 32));
+				   atomicOr(&E.stage[i + 2], hi);
+				   bp += readlane(incl, 63);
+			   },
+			   [&](uint32_t) {});
 		bitpos += readlane(pincl, 63);
 		{
 			const uint32_t eob = Bd.lcode[256];
@@ -425,9 +504,13 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				put(eob & 0xffff, eob >> 16, bitpos);
 			bitpos += uniform(eob) >> 16;
 		}
-	} while (alive && k < np);
+		EW_T(5);
+		// (no barrier here: the next block's sums go to L.lf / L.df, which nobody reads while coding; its codes and tables are
+		// written behind the barrier that follows the sums, which every wavefront reaches with its pieces coded)
+	}
 
 	__syncthreads();
+	EW_T(6);
 	if (!alive) {
 		if (w == 0)
 			write_stored_member(a, b, src, n, crcv, lane);
@@ -468,6 +551,7 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 		((uint4 *)dst32)[i] = ((const uint4 *)E.stage)[i];
 	if (threadIdx.x < ((total + 3) >> 2) - 4 * q16)
 		dst32[4 * q16 + threadIdx.x] = E.stage[4 * q16 + threadIdx.x];
+	EW_T(7);
 }
 
 inline void launch_emit_wg(const DeflateArgs &s, hipStream_t st)

@@ -105,8 +105,9 @@ uint64_t hipdeflate_stall_count(void);
  * 64 KiB multi-way table shared by a workgroup, block splitting -- with 1 way greedy (3), 1 way lazy (4), 2 ways (5), 4 ways (6..9):
  * level 3 is below the reference's libdeflate level 1 in size on every measured set, level 6 within 3 % of its level 6 -- through
  * every entry point: the per-call forms here and the hook write the batch calls' bytes at levels >= 3 (HD_FRAME_LATENCY above).
- * In the batch calls below, levels >= 3 refuse (status != 0) a block that is longer than the room its slot leaves for the payload,
- * whatever it would have compressed to: the parse's records are sized by the slot.  The reference's callers allocate 1.5 x the block.
+ * As libdeflate_deflate (lib/zlibutil.c:179-192) a call succeeds whenever the stream fits the room, also for a block longer than the
+ * room (applet/7png.c:112 gives 1.5 x the OLD compressed size).  One exception: hipdeflate_batch_deflate_dev at levels >= 3, where only
+ * the device knows the lengths and the parse's records are sized by the slot, refuses (status != 0) a block longer than its slot.
  * Re-entrant and thread-safe; concurrent callers whose room covers the latency form's worst case and the stored form share launches
  * (the hook's micro-batcher, an engine per level and frame; HIPDEFLATE_CODEC_BATCH=0: a context per call). */
 int hip_deflate(unsigned char *dest, size_t *destLen,

@@ -768,8 +768,9 @@ static int deflate_wg(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t 
 	const size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	const size_t stored = HD_STORED_SIZE(n);
 	const size_t limit = cap < stored - 1 ? cap : stored - 1;
-	if (n > cap)                            /* a block longer than its room is refused: the kernel's records are sized by the slot */
-		return write_stored(dest, destLen, in, n, flush);
+	/* (round 5: a block longer than its room is coded like any other and goes through when its stream fits -- the contract of
+	 * libdeflate_deflate, lib/zlibutil.c:179-192, which applet/7png.c:112 leans on with 1.5 x the OLD compressed size as
+	 * room; round 4 refused such a block because the kernel's records were sized by the slot) */
 	uint8_t *tmp = calloc(1, limit + 64 + 8);
 	uint16_t *bk = calloc((size_t)BUCKETS * WAYS, 2);
 	dynblk_t b;

@@ -259,13 +259,9 @@ def test_twin_flush_form_is_full_flush_of_twin(level):
         assert zlib.decompressobj(-15).decompress(prev + zf + b"\x03\x00") == \
             (zlib.decompressobj(-15).decompress(prev + b"\x03\x00") if prev else b"") + data, name
         prev = zf
-        # 5 bytes are kept free for the suffix: that capacity always works, 5 less never does -- at the workgroup levels
-        # (>= 3) only for a block that is not longer than its room: those refuse a longer one whatever it compresses to
-        # (the kernel's records are sized by the slot)
+        # 5 bytes are kept free for the suffix: that capacity always works, 5 less never does (round 5: at every level --
+        # the workgroup levels no longer refuse a block that is longer than its room)
         r3, z3 = hdtest.oracle_twin_flush(data, level, cap=len(zf) + 1)
-        if level >= 3 and len(data) > len(zf) + 1 - 5:
-            assert r3 != 0, name
-            r3, z3 = hdtest.oracle_twin_flush(data, level, cap=len(data) + 5)
         assert r3 == 0 and z3 == zf, name
         r4, _ = hdtest.oracle_twin_flush(data, level, cap=len(zf) - 5)
         assert r4 != 0, name
@@ -317,9 +313,10 @@ def test_twin_workgroup_levels_take_long_blocks_as_one_stream(level):
     # been coded with the text's code, i.e. the stream is shorter than one-code-for-all would be)
     r, zf = hdtest.oracle_twin_flush(data, level)
     assert r == 0 and zlib.decompressobj(-15).decompress(zf + b"\x03\x00") == data
-    # (the room rule of these levels: a block is refused when it is longer than its room, whatever it compresses to)
-    assert hdtest.oracle_twin(data, level, cap=len(data))[0] == 0
-    assert hdtest.oracle_twin(data, level, cap=len(data) - 1)[0] != 0
+    # (the room rule is libdeflate_deflate's, lib/zlibutil.c:179-192: the call succeeds exactly when the stream fits -- round 4
+    # refused a block longer than its room whatever it compressed to)
+    assert hdtest.oracle_twin(data, level, cap=len(data))[1] == z
+    assert hdtest.oracle_twin(data, level, cap=len(z))[1] == z
     assert hdtest.oracle_twin(data, level, cap=len(z) - 1)[0] != 0
     # incompressible: the stored form, which needs its 5 bytes per 65535
     noise = bytes(s.random_bytes(200000))
