@@ -520,7 +520,7 @@ static uint64_t scratch_need(uint32_t nblocks, uint32_t cap, int level, bool lat
 		return hd::segmented_scratch_bytes(nblocks, cap, level, HD_LAT_SEG_BYTES(level));
 	if (level >= 1 && level < HD_WG_LEVEL && cap > HD_SEG_LIMIT)       // (the workgroup levels take a block of any length whole)
 		return hd::segmented_scratch_bytes(nblocks, cap, level);
-	return level < 2 ? 0 : hd::dynamic_scratch_bytes(nblocks, cap, level);
+	return level < 2 ? 0 : hd::dynamic_scratch_bytes(nblocks, cap, level, 0, latency);
 }
 
 uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int level)

@@ -54,9 +54,12 @@ inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
 		sub = 1;
 	return sub < nblocks ? (uint32_t)sub : nblocks;
 }
-inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max)
+// lat: a latency launch of blocks up to 64 KiB -- room for their staged copies behind the records (hd_deflate_wg.hpp k_stage_in)
+inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max, bool lat = false)
 {
-	return (((uint64_t)nblocks * 4 + 15) & ~(uint64_t)15) + (uint64_t)wg_sub_batch(nblocks, split_max) * wg_layout(split_max).bytes + 16;
+	const uint32_t sub = wg_sub_batch(nblocks, split_max);
+	return (((uint64_t)nblocks * 4 + 15) & ~(uint64_t)15) + (uint64_t)sub * wg_layout(split_max).bytes + 16 +
+	       (lat && split_max <= 65536 ? (uint64_t)(sub < 128 ? sub : 128) * 65536 + 256 : 0);
 }
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
@@ -129,12 +132,12 @@ inline uint32_t part_sub_batch(uint32_t nsegs, uint32_t parts)
 }
 
 // parts != 0: the blocks are latency segments parsed in that many parts
-inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int level, uint32_t parts = 0)
+inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int level, uint32_t parts = 0, bool lat = false)
 {
 	if (level < 2)
 		return 0;
 	if (level >= HD_WG_LEVEL && !parts)
-		return wg_scratch_bytes(nblocks, split_max);
+		return wg_scratch_bytes(nblocks, split_max, lat);
 	if (parts)
 		return fused_scratch_bytes(nblocks, level) + (uint64_t)nblocks * 4 +
 		       (uint64_t)part_sub_batch(nblocks, parts) * parts * part_layout().bytes + 16;

@@ -78,6 +78,15 @@ struct DeflateArgs {
 	// the workgroup levels, HD_FRAME_LATENCY: a handful of blocks, each wanted back soon -- the member is written by a
 	// WORKGROUP (hd_emit_wg.hpp k_emit_wg: the same bytes as the one-wavefront emit kernel, sixteen wavefronts at them)
 	uint32_t lat = 0;
+	// ... and the PARSE of one block is shared by this many workgroups (k_parse_wg, a.lat launches of a few blocks: 1, 2 or 4):
+	// workgroup q replays the table stores of the pieces in front of its range -- hashes and bucket updates only, in the same
+	// order, so its table is what the one workgroup's would be there -- and parses its own range; same tokens, a fraction of
+	// the time a lone block spends on one CU.  0 = 1
+	uint32_t wg_split = 0;
+	// ... reading it from here (device memory: block i of the sub-batch at stage_in + i * 64 KiB, put there by k_stage_in)
+	// instead of a.in -- which for a latency context is the caller's pinned memory: four readers of a block over PCIe
+	// cost more than the shared parse gains
+	const uint8_t *stage_in = nullptr;
 	// a device word that counts the blocks the workgroup parse gave up on because a turn did not come (WG_SPIN_LIMIT;
 	// they are written stored): hipdeflate_stall_count()
 	uint32_t *stalls = nullptr;

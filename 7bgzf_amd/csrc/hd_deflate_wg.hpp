@@ -105,6 +105,25 @@ __device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uin
 
 typedef uint32_t wg_u32x16 __attribute__((ext_vector_type(16)));
 
+// the blocks of a latency launch, from wherever the caller has them (a latency context: pinned host memory) into device
+// memory, once, for the workgroups that share their parse: one workgroup per block, four 16-byte loads per thread in flight
+constexpr uint32_t WG_STAGE_STRIDE = 65536;
+__global__ __launch_bounds__(1024) void k_stage_in(DeflateArgs a, uint8_t *stage)
+{
+	const uint32_t bi = blockIdx.x, b = a.first + bi;
+	const uint8_t *src = a.in + a.in_off[b];
+	const uint32_t n = a.in_len[b] < WG_STAGE_STRIDE ? a.in_len[b] : WG_STAGE_STRIDE;
+	const bool aligned = (((uintptr_t)src) & 15) == 0;
+	uint4 v[4];
+#pragma unroll
+	for (uint32_t i = 0; i < 4; i++)
+		v[i] = load_slot(src, n, 16 * i + (threadIdx.x >> 6), threadIdx.x & 63, aligned);
+#pragma unroll
+	for (uint32_t i = 0; i < 4; i++)
+		if ((16 * i + (threadIdx.x >> 6)) * HD_PIECE < n)
+			*(uint4 *)(stage + (uint64_t)bi * WG_STAGE_STRIDE + (16 * i + (threadIdx.x >> 6)) * HD_PIECE + 16 * (threadIdx.x & 63)) = v[i];
+}
+
 __device__ __forceinline__ uint64_t wg_uniform64(uint64_t v)
 {
 	return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
@@ -117,8 +136,12 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	static_assert(WAYS == 1 || WAYS == 2 || WAYS == 4, "a bucket is 2, 4 or 8 bytes");
 	__shared__ WgLds L;
 	const uint32_t lane = threadIdx.x & 63, w = uniform(threadIdx.x >> 6);      // (the compiler must know that w is one value per wavefront)
-	const uint32_t bi = blockIdx.x, b = a.first + bi;
-	const uint8_t *src = a.in + a.in_off[b];
+	// a.wg_split workgroups share a block's parse (latency launches): workgroup q of SP takes the pieces [pfirst, plast) and,
+	// to have the table the pieces in front of them leave, REPLAYS those pieces' table turns first (hashes + bucket stores,
+	// no verify, no tokens: an eighth of a piece's work)
+	const uint32_t SP = a.wg_split > 1 ? a.wg_split : 1u;
+	const uint32_t bi = blockIdx.x / SP, q = blockIdx.x % SP, b = a.first + bi;
+	const uint8_t *src = a.stage_in ? a.stage_in + (uint64_t)bi * WG_STAGE_STRIDE : a.in + a.in_off[b];
 	const uint32_t n = a.in_len[b];
 	const bool aligned = (((uintptr_t)src) & 15) == 0;
 	const CrcTables *ct = a.ct;
@@ -135,6 +158,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	// slot where only the device knows them (hipdeflate_batch_deflate_dev: there a block longer than its slot is refused)
 	const bool refused = n > a.split_max;
 	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
+	const uint32_t pfirst = npieces * q / SP, plast = npieces * (q + 1) / SP;    // (SP == 1: all of them)
 
 	// ---- LDS: the table zero, the words ------------------------------------------------------------------------------
 	for (uint32_t i = threadIdx.x; i < WG_TABLE_BYTES / 16; i += 64 * WG_NW)
@@ -175,7 +199,9 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 		CrcLanes crc;
 		crc.init(lane, n);
 		uint4 pend = make_uint4(0, 0, 0, 0);
-		if (bulk) {
+		if (bulk && q) {
+			// (the block's CRC-32 is workgroup 0's)
+		} else if (bulk) {
 			for (uint32_t k = 0; k < npieces; k++)
 				crc.fold(ct, k, k * HD_PIECE + 16 * lane + 16 <= n, *(const uint4 *)((const uint8_t *)L.ring32 + k * HD_PIECE + 16 * lane));
 		} else if (npieces) {
@@ -247,9 +273,9 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 			j = uniform(j);
 #endif
 			if (lane == 0)
-				vcur[w] = j < npieces ? j : 0xffffffffu;
+				vcur[w] = j < plast ? j : 0xffffffffu;
 			WG_BARRIER();
-			if (j >= npieces)
+			if (j >= plast)
 				break;
 			const uint32_t P0 = j * HD_WG_CUT;
 			const uint32_t pend = n - P0 < HD_WG_CUT ? n : P0 + HD_WG_CUT;         // the piece's end
@@ -317,6 +343,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 				*vturn = j + 1;
 			WG_BARRIER();
 			__builtin_amdgcn_s_setprio(0);
+			if (j < pfirst)
+				continue;                              // a replayed piece: its stores are in the table, another workgroup parses it
 
 			// ---- the piece: verify, lazy rule, walk, tokens -- nothing here waits for another wavefront ----------------
 			uint32_t E = P0;                           // first position no token covers yet
@@ -479,9 +507,12 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	if (w == WG_NP && lane == 0) {
 		uint32_t *m = (uint32_t *)(rec + lay.off_rec);
 		const bool stalled = uniform(*vfail) != 0;
-		m[0] = (stalled || refused) ? 0xffffffffu : 0u;
-		m[1] = crcv;
-		a.split_ovf[b] = 0;
+		if (q == 0) {
+			m[0] = (stalled || refused) ? 0xffffffffu : 0u;
+			m[1] = crcv;
+			a.split_ovf[b] = 0;
+		}
+		((uint8_t *)&m[2])[q & 3] = stalled ? 1 : 0;       // (a.wg_split > 1: the emit kernel looks at every sharer's byte)
 		if (stalled && a.stalls)
 			atomicAdd(a.stalls, 1u);
 	}
@@ -501,7 +532,18 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 	for (uint32_t first = 0; first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
-		const dim3 grid(s.count), block(64 * HD_WG_WAVES);
+		// a handful of blocks wanted back soon (a.lat: each at most 64 KiB, the ring holds it whole): four or two workgroups
+		// share a block's parse while that leaves the 256 CUs room for all of them
+		s.wg_split = !a.lat ? 1u : s.count <= 64 ? 4u : s.count <= 128 ? 2u : 1u;
+		s.stage_in = nullptr;
+		if (s.wg_split > 1) {
+			// (the staging area lies behind the records: wg_scratch_bytes(..., lat))
+			uint8_t *stage = s.scratch + (uint64_t)sub * wg_layout(a.split_max).bytes;
+			stage = (uint8_t *)(((uintptr_t)stage + 255) & ~(uintptr_t)255);
+			hipLaunchKernelGGL(k_stage_in, dim3(s.count), dim3(1024), 0, st, s, stage);
+			s.stage_in = stage;
+		}
+		const dim3 grid(s.count * s.wg_split), block(64 * HD_WG_WAVES);
 		if (HD_WG_WAYS(level) == 4)
 			hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, 0, st, s);
 		else if (HD_WG_WAYS(level) == 2)

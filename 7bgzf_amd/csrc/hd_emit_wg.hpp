@@ -32,19 +32,217 @@ constexpr uint32_t EW_BLOCK_MAX = 65536;            // the longest block: the ho
                                                     // block of the launch is longer (a latency context's input stride, or a slot
                                                     // of at most this many bytes: the parse refuses a block longer than its room)
 
+#define EW_LDS __attribute__((address_space(3)))
+constexpr uint32_t EW_SLOTS = 4;                    // DEFLATE blocks whose codes are built side by side (a wavefront each)
+struct EwSlot {
+	DynBuild build;                                 // the block's construction scratch and codes
+	DynLds L;                                       // its histograms, the precode
+	uint32_t lut[512];                              // litlen half of a token: codeword (+ extra bits) | bit count << 24
+	uint32_t info[8];                               // 0: the block's bits  1: dynamic code  2: header bits  3: code-length items  4: hlit  5: hdist  6: hclen
+};
 struct EwLds {
 	__attribute__((aligned(16))) uint32_t stage[EW_STAGE_DW];
-	DynBuild build;                                 // wavefront 0's construction scratch, the codes
-	HuffScratch hs2;                                // wavefront 1's
-	DynLds L;                                       // the open DEFLATE block's histograms, the precode
-	uint32_t lut[512];                              // litlen half of a token: codeword (+ extra bits) | bit count << 24
+	EwSlot slot[EW_SLOTS];
 	uint32_t ph[EW_MAX_PIECES][160];                // per piece: 320 symbol counts, 16 bits each (a piece holds <= 1024 tokens):
 	                                                // litlen symbol s at half s, offset symbol d at half 288 + d
 	uint32_t piece_bits[EW_MAX_PIECES];
 	uint32_t cuts[EW_MAX_PIECES + 2];               // [0] the number of DEFLATE blocks, [1 + i] the piece behind block i
 	uint32_t lsym[64];                              // length - 3 -> litlen symbol - 257, a byte each
-	uint32_t ctl[8];                                // 0: alive  1: dynamic code  2: bit position behind the block header  3: member bytes
+	uint32_t ctl[8];                                // 3: member bytes
 };
+
+// one field per lane (nbits <= 32, 0 = none), in lane order, ORed into the image at bit `bitpos`; returns the bits placed
+__device__ __forceinline__ uint32_t ew_emit1(EW_LDS uint32_t *stage, uint32_t bitpos, uint32_t code, uint32_t nbits)
+{
+	const uint32_t incl = wave_incl_scan(nbits);
+	if (nbits) {
+		const uint32_t bp = bitpos + incl - nbits, sh = bp & 31, i = bp >> 5;
+		__hip_atomic_fetch_or(&stage[i], code << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (sh + nbits > 32)
+			__hip_atomic_fetch_or(&stage[i + 1], code >> (32 - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	return readlane(incl, 63);
+}
+
+// One wavefront, one DEFLATE block (its histograms are in S->L): the codes, the RLE of their lengths, the precode, the exact
+// cost, dynamic or static, the litlen table -- flush_block of the emit-only kernel (hd_deflate_dynamic.hpp) statement by
+// statement, everything but the bits; what the header needs later stays in the slot.
+__device__ __forceinline__ void ew_prepare_block(EW_LDS EwSlot *S, uint32_t lane)
+{
+	EW_LDS uint32_t *const lf = S->L.lf, *const df = S->L.df, *const pfreq = S->L.pfreq, *const pcode = S->L.pcode;
+	EW_LDS uint32_t *const lcode = S->build.lcode, *const dcode = S->build.dcode;
+	EW_LDS uint16_t *const items = (EW_LDS uint16_t *)&S->build.hs.nf[64];           // (DynBuild::items() / lens())
+	EW_LDS uint8_t *const lens = (EW_LDS uint8_t *)&S->build.hs.nf[64 + 160];
+	EW_LDS uint16_t *const run_start = S->build.hs.parent;                           // free until the precode is built
+	if (lane == 0)
+		lf[256] += 1;                                   // end of block
+	build_code((const uint32_t *)lf, 288, HD_LITLEN_MAXBITS, (uint32_t *)lcode, *(HuffScratch *)&S->build.hs, lane, true);
+	build_code((const uint32_t *)df, 32, HD_OFFSET_MAXBITS, (uint32_t *)dcode, *(HuffScratch *)&S->build.hs, lane, true);
+	if (lane < 19)
+		pfreq[lane] = 0;
+	uint32_t hlit, hdist;
+	{
+		const uint64_t ml = __ballot(lane < 29 && (lcode[257 + lane] >> 16) != 0);
+		const uint64_t md = __ballot(lane < 29 && (dcode[1 + lane] >> 16) != 0);
+		hlit = ml ? 257 + 64 - (uint32_t)__clzll((long long)ml) : 257;
+		hdist = md ? 1 + 64 - (uint32_t)__clzll((long long)md) : 1;
+	}
+	const uint32_t total = hlit + hdist;
+	for (uint32_t i = lane; i < total; i += 64)
+		lens[i] = (uint8_t)((i < hlit ? lcode[i] : dcode[i - hlit]) >> 16);
+	uint32_t nruns = 0;
+	for (uint32_t base = 0; base < total; base += 64) {
+		const uint32_t i = base + lane;
+		const bool st = i < total && (i == 0 || lens[i] != lens[i - 1]);
+		const uint64_t mm = __ballot(st);
+		if (st)
+			run_start[nruns + __popcll(mm & ((1ull << lane) - 1))] = (uint16_t)i;
+		nruns += (uint32_t)__popcll(mm);
+	}
+	if (lane == 0)
+		run_start[nruns] = (uint16_t)total;
+	uint32_t ni = 0;
+	for (uint32_t rb = 0; rb < nruns; rb += 64) {
+		const uint32_t r = rb + lane;
+		const bool valid = r < nruns;
+		const uint32_t s0 = valid ? run_start[r] : 0, len = valid ? run_start[r + 1] - s0 : 0;
+		const uint32_t v = valid ? lens[s0] : 0;
+		uint32_t rep, big, rest, lead;
+		if (v == 0) {
+			rep = 18; lead = 0;
+			big = len / 138; rest = len - 138 * big;
+		} else {
+			rep = 16; lead = valid ? 1u : 0u;
+			big = (len - lead) / 6; rest = (len - lead) - 6 * big;
+		}
+		const uint32_t full = v == 0 ? 138u : 6u, base_len = v == 0 ? 11u : 3u;
+		uint32_t extra_rep = 0, extra_sym = rep, extra_base = base_len;
+		if (rest >= base_len) {
+			extra_rep = 1;
+		} else if (v == 0 && rest >= 3) {
+			extra_rep = 1; extra_sym = 17; extra_base = 3;
+		}
+		const uint32_t tail = extra_rep ? 0u : rest;
+		const uint32_t c = valid ? lead + big + extra_rep + tail : 0u;
+		const uint32_t incl = wave_incl_scan(c);
+		uint32_t o = ni + incl - c;
+		if (valid) {
+			if (lead)
+				items[o++] = (uint16_t)v;
+			for (uint32_t j = 0; j < big; j++)
+				items[o++] = (uint16_t)(rep | ((full - base_len) << 8));
+			if (extra_rep)
+				items[o++] = (uint16_t)(extra_sym | ((rest - extra_base) << 8));
+			for (uint32_t j = 0; j < tail; j++)
+				items[o++] = (uint16_t)v;
+			if (lead + tail)
+				__hip_atomic_fetch_add(&pfreq[v], lead + tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (big)
+				__hip_atomic_fetch_add(&pfreq[rep], big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (extra_rep)
+				__hip_atomic_fetch_add(&pfreq[extra_sym], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		ni += readlane(incl, 63);
+	}
+	build_code((const uint32_t *)pfreq, 19, HD_PRECODE_MAXBITS, (uint32_t *)pcode, *(HuffScratch *)&S->build.hs, lane, true);
+	uint32_t hclen = 19;
+	while (hclen > 4 && (uniform(pcode[k_perm19[hclen - 1]]) >> 16) == 0)
+		hclen--;
+	uint32_t dyn = 0, sta = 0, extra = 0;
+	for (uint32_t base = 0; base < ni; base += 64) {
+		const uint32_t kx = base + lane;
+		if (kx < ni) {
+			const uint32_t sym = items[kx] & 31;
+			dyn += (pcode[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
+		}
+	}
+	// (what the header of the dynamic code takes: the 17 + 3 hclen bits in front, then the items)
+	const uint32_t hdr_dyn = readlane(wave_incl_scan(dyn), 63) + 3 + 5 + 5 + 4 + 3 * hclen;
+	dyn = 0;
+	for (uint32_t base = 0; base < 286; base += 64) {
+		const uint32_t s = base + lane;
+		if (s < 286) {
+			const uint32_t f = lf[s];
+			dyn += f * (lcode[s] >> 16);
+			sta += f * (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
+			if (s >= 265 && s < 285)
+				extra += f * ((s - 261) >> 2);
+		}
+	}
+	if (lane < 30) {
+		const uint32_t f = df[lane];
+		dyn += f * (dcode[lane] >> 16);
+		sta += f * 5u;
+		extra += f * (lane < 4 ? 0u : (lane >> 1) - 1);
+	}
+	dyn = readlane(wave_incl_scan(dyn), 63) + hdr_dyn;
+	sta = readlane(wave_incl_scan(sta), 63) + 3;
+	extra = readlane(wave_incl_scan(extra), 63);
+	const bool use_dynamic = dyn < sta;                      // tie -> static (deflate_compress.c:1861-1867)
+	if (!use_dynamic) {
+		// the static code won (rare): its codes in place of the dynamic ones
+		for (uint32_t s = lane; s < 288; s += 64) {
+			const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
+			const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
+			lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
+		}
+		if (lane < 32)
+			dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
+	}
+#pragma unroll
+	for (uint32_t q = 0; q < 4; q++) {
+		const uint32_t i = 64 * q + lane;                // literal i, length 3 + i
+		const uint32_t lc = lcode[i];
+		S->lut[i] = (lc & 0xffff) | (lc >> 16 << 24);
+		uint32_t ls, leb, lev;
+		len_slot(i + 3, ls, leb, lev);
+		const uint32_t mc = lcode[257 + ls];
+		S->lut[256 + i] = (mc & 0xffff) | (lev << (mc >> 16)) | (((mc >> 16) + leb) << 24);
+	}
+	if (lane == 0) {
+		S->info[0] = (use_dynamic ? dyn : sta) + extra;
+		S->info[1] = use_dynamic ? 1u : 0u;
+		S->info[2] = use_dynamic ? hdr_dyn : 3u;
+		S->info[3] = ni;
+		S->info[4] = hlit;
+		S->info[5] = hdist;
+		S->info[6] = hclen;
+	}
+}
+
+// ... and the bits of its header at `bstart`, its end-of-block code at the block's end (bbits on)
+__device__ __forceinline__ void ew_emit_header(EW_LDS EwSlot *S, EW_LDS uint32_t *stage, uint32_t bstart, uint32_t bbits, bool final_bit, uint32_t lane)
+{
+	EW_LDS uint32_t *const pcode = S->L.pcode;
+	EW_LDS uint16_t *const items = (EW_LDS uint16_t *)&S->build.hs.nf[64];
+	uint32_t bitpos = bstart;
+	if (uniform(S->info[1])) {
+		const uint32_t ni = uniform(S->info[3]), hlit = uniform(S->info[4]), hdist = uniform(S->info[5]), hclen = uniform(S->info[6]);
+		uint32_t c0 = 0, n0 = 0;
+		if (lane == 0) { c0 = final_bit ? 1u : 0u; n0 = 1; }
+		else if (lane == 1) { c0 = 2; n0 = 2; }
+		else if (lane == 2) { c0 = hlit - 257; n0 = 5; }
+		else if (lane == 3) { c0 = hdist - 1; n0 = 5; }
+		else if (lane == 4) { c0 = hclen - 4; n0 = 4; }
+		else if (lane < 5 + hclen) { c0 = pcode[k_perm19[lane - 5]] >> 16; n0 = 3; }
+		bitpos += ew_emit1(stage, bitpos, c0, n0);
+		for (uint32_t base = 0; base < ni; base += 64) {
+			const uint32_t kx = base + lane;
+			uint32_t cc = 0, nn = 0;
+			if (kx < ni) {
+				const uint32_t it = items[kx], sym = it & 31;
+				const uint32_t pc = pcode[sym];
+				cc = (pc & 0xffff) | ((it >> 8) << (pc >> 16));
+				nn = (pc >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
+			}
+			bitpos += ew_emit1(stage, bitpos, cc, nn);
+		}
+	} else {
+		bitpos += ew_emit1(stage, bitpos, lane == 0 ? (final_bit ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
+	}
+	const uint32_t eob = S->build.lcode[256];
+	ew_emit1(stage, bstart + bbits - (eob >> 16), lane == 0 ? (eob & 0xffff) : 0u, lane == 0 ? (eob >> 16) : 0u);
+}
 
 #ifdef HD_EMIT_STATS
 // experiment build only: wavefront 0's cycles by phase, g_emit_stats[0..7] (tools/exp_emit_wg_stats.py)
@@ -70,8 +268,6 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 	const uint4 *pieces = (const uint4 *)(rec + lay.off_ntok);
 	const uint32_t crcv = m[1];
 	uint32_t *dst32 = (uint32_t *)(a.out + (uint64_t)b * a.out_stride);
-	DynBuild &Bd = E.build;
-	DynLds &L = E.L;
 
 	const uint32_t hdr = frame_hdr_bytes(a.frame), trl = frame_trl_bytes(a.frame), sfx = frame_sfx_bytes(a.frame);
 	uint64_t cap64 = a.out_stride < a.out_cap ? a.out_stride : a.out_cap;
@@ -85,7 +281,7 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 	if (alive && cap - hdr - trl - sfx < limit)
 		limit = cap - hdr - trl - sfx;
 	const uint64_t limit_bits = 8ull * limit;
-	if (m[0] != 0)                                   // the parse refused the block or gave it up: stored
+	if (m[0] != 0 || (a.wg_split > 1 && (m[2] & (0xffffffffu >> (32 - 8 * a.wg_split))) != 0))   // the parse refused the block or gave it up (any sharer): stored
 		alive = false;
 	const uint32_t np = alive ? (n + HD_WG_CUT - 1) / HD_WG_CUT : 0u;
 	if (np > EW_MAX_PIECES) {                        // (launch_wg's promise: cannot happen; never run past the image)
@@ -242,63 +438,86 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 	EW_T(1);
 	const uint32_t nblk = alive ? uniform(E.cuts[0]) : 0u;
 
-	for (uint32_t blk = 0; blk < nblk && alive; blk++) {
-		const uint32_t k0 = blk ? uniform(E.cuts[blk]) : 0u, k1 = uniform(E.cuts[1 + blk]);
-		const bool final = k1 == np;
-		// ---- the block's symbols: the sum of its pieces' (packed adds: a block holds < 2^16 tokens) ---------------------------
-		if (threadIdx.x < 160) {
-			uint32_t acc = 0;
-			for (uint32_t kk = k0; kk < k1; kk++)
-				acc += E.ph[kk][threadIdx.x];
-			if (threadIdx.x < 144) {
-				L.lf[2 * threadIdx.x] = acc & 0xffffu;
-				L.lf[2 * threadIdx.x + 1] = acc >> 16;
-			} else {
-				L.df[2 * (threadIdx.x - 144)] = acc & 0xffffu;
-				L.df[2 * (threadIdx.x - 144) + 1] = acc >> 16;
+	// ---- the DEFLATE blocks, EW_SLOTS at a time: their codes are built SIDE BY SIDE, a wavefront per block (wavefronts 0..3: one
+	// per SIMD), because a member of 64 KiB is two or three blocks and a code construction is ~20 us of one wavefront's serial
+	// work; a block's bits are known exactly from its histogram and code lengths, so every block, header and piece has its place
+	// in the image before a single token is coded ------------------------------------------------------------------------------
+	for (uint32_t r0 = 0; r0 < nblk && alive; r0 += EW_SLOTS) {
+		const uint32_t nb = nblk - r0 < EW_SLOTS ? nblk - r0 : EW_SLOTS;               // blocks of this round
+		const uint32_t kr0 = r0 ? uniform(E.cuts[r0]) : 0u;                             // the round's first piece
+		uint32_t kend[EW_SLOTS];                                                        // the piece behind block i of the round
+#pragma unroll
+		for (uint32_t i = 0; i < EW_SLOTS; i++)
+			kend[i] = uniform(E.cuts[1 + r0 + (i < nb ? i : nb - 1)]);
+		// ---- the blocks' symbols: the sums of their pieces' (packed adds: a block holds < 2^16 tokens) -------------------------
+		{
+			const uint32_t i = threadIdx.x / 160, t = threadIdx.x % 160;
+			if (i < nb) {
+				const uint32_t k0 = i == 0 ? kr0 : i == 1 ? kend[0] : i == 2 ? kend[1] : kend[2];
+				const uint32_t k1 = i == 0 ? kend[0] : i == 1 ? kend[1] : i == 2 ? kend[2] : kend[3];
+				uint32_t acc = 0;
+				for (uint32_t kk = k0; kk < k1; kk++)
+					acc += E.ph[kk][t];
+				EW_LDS DynLds *Ls = &((EW_LDS EwSlot *)&E.slot[0])[i].L;
+				if (t < 144) {
+					Ls->lf[2 * t] = acc & 0xffffu;
+					Ls->lf[2 * t + 1] = acc >> 16;
+				} else {
+					Ls->df[2 * (t - 144)] = acc & 0xffffu;
+					Ls->df[2 * (t - 144) + 1] = acc >> 16;
+				}
 			}
 		}
 		__syncthreads();
 		EW_T(2);
-		// ---- the codes: litlen on wavefront 0, offset on wavefront 1 -----------------------------------------------------
-		if (w == 0) {
-			if (lane == 0)
-				L.lf[256] += 1;                             // end of block
-			build_code(L.lf, 288, HD_LITLEN_MAXBITS, Bd.lcode, Bd.hs, lane, true);
-		} else if (w == 1) {
-			build_code(L.df, 32, HD_OFFSET_MAXBITS, Bd.dcode, E.hs2, lane, true);
-		}
+		// ---- wavefront i < nb: the codes of block r0 + i, the RLE of their lengths, the precode, the exact cost, the choice
+		// (flush_block of the emit-only kernel, statement by statement), the litlen table -- everything but the bits -------------
+		// (its own function, the slot through an LDS-typed pointer: with `E.slot[w]` inline the compiler loses track of the
+		// address space and reaches LDS through flat instructions -- the serial RLE / cost code ran four times slower so --,
+		// and four inlined copies spill)
+		if (w < nb)
+			ew_prepare_block((EW_LDS EwSlot *)&E.slot[0] + w, lane);
 		__syncthreads();
 		EW_T(3);
-		// ---- wavefront 0: code lengths' RLE, precode, exact costs, the choice, the header (flush_block of the emit-only
-		// kernel, statement by statement); wavefront 1: the litlen table; the others: what every piece weighs, from its
-		// histogram and the code lengths (dynamic code assumed: again below should the static code win) ----------------------
-		auto fill_lut = [&]() {
+		// ---- every block of the round has its place (and the member its verdict: a block that does not fit ends it) ------------
+		uint32_t bstart[EW_SLOTS], bbits[EW_SLOTS];
+		{
+			uint32_t at = bitpos;
 #pragma unroll
-			for (uint32_t q = 0; q < 4; q++) {
-				const uint32_t i = 64 * q + lane;                // literal i, length 3 + i
-				const uint32_t lc = Bd.lcode[i];
-				E.lut[i] = (lc & 0xffff) | (lc >> 16 << 24);
-				uint32_t ls, leb, lev;
-				len_slot(i + 3, ls, leb, lev);
-				const uint32_t mc = Bd.lcode[257 + ls];
-				E.lut[256 + i] = (mc & 0xffff) | (lev << (mc >> 16)) | (((mc >> 16) + leb) << 24);
+			for (uint32_t i = 0; i < EW_SLOTS; i++) {
+				bstart[i] = at;
+				bbits[i] = i < nb ? uniform(E.slot[i].info[0]) : 0u;
+				if (i < nb && (uint64_t)(at - paybase) + bbits[i] > limit_bits)
+					alive = false;
+				at += bbits[i];
 			}
-		};
-		auto weigh = [&](uint32_t first, uint32_t step) {
-			for (uint32_t kk = first; kk < k1; kk += step) {
+			bitpos = at;
+		}
+		if (!alive)
+			break;
+		// ---- wavefront i < nb: the header of its block; the others: what every piece of the round weighs, from its histogram and
+		// the code lengths of its block ------------------------------------------------------------------------------------------
+		const EW_LDS EwSlot *const slots3 = (const EW_LDS EwSlot *)&E.slot[0];     // (LDS pointers stay LDS pointers: ds_read, not flat_load)
+		if (w < nb) {
+			const uint32_t bs = w == 0 ? bstart[0] : w == 1 ? bstart[1] : w == 2 ? bstart[2] : bstart[3];
+			const uint32_t bb = w == 0 ? bbits[0] : w == 1 ? bbits[1] : w == 2 ? bbits[2] : bbits[3];
+			ew_emit_header((EW_LDS EwSlot *)&E.slot[0] + w, (EW_LDS uint32_t *)E.stage, bs, bb, r0 + w + 1 == nblk && !flush, lane);
+		} else {
+			for (uint32_t kk = kr0 + (w - nb); kk < kend[EW_SLOTS - 1]; kk += EW_NW - nb) {
+				const uint32_t si = (kk >= kend[0] ? 1u : 0u) + (kk >= kend[1] ? 1u : 0u) + (kk >= kend[2] ? 1u : 0u);
+				const EW_LDS uint32_t *lc = slots3[si].build.lcode, *dc = slots3[si].build.dcode;
 				uint32_t bits = 0;
 				for (uint32_t i = lane; i < 160; i += 64) {
 					const uint32_t c = E.ph[kk][i];
 					uint32_t n0, n1;                                   // bits of one symbol 2 i / 2 i + 1: codeword + extra bits
 					if (i < 144) {
 						const uint32_t s0 = 2 * i, s1 = 2 * i + 1;
-						n0 = (Bd.lcode[s0] >> 16) + ((s0 >= 265 && s0 < 285) ? (s0 - 261) >> 2 : 0u);
-						n1 = (Bd.lcode[s1] >> 16) + ((s1 >= 265 && s1 < 285) ? (s1 - 261) >> 2 : 0u);
+						n0 = (lc[s0] >> 16) + ((s0 >= 265 && s0 < 285) ? (s0 - 261) >> 2 : 0u);
+						n1 = (lc[s1] >> 16) + ((s1 >= 265 && s1 < 285) ? (s1 - 261) >> 2 : 0u);
 					} else {
 						const uint32_t d0 = 2 * (i - 144), d1 = d0 + 1;
-						n0 = (Bd.dcode[d0] >> 16) + (d0 < 4 ? 0u : (d0 >> 1) - 1);
-						n1 = (Bd.dcode[d1] >> 16) + (d1 < 4 ? 0u : (d1 >> 1) - 1);
+						n0 = (dc[d0] >> 16) + (d0 < 4 ? 0u : (d0 >> 1) - 1);
+						n1 = (dc[d1] >> 16) + (d1 < 4 ? 0u : (d1 >> 1) - 1);
 					}
 					bits += (c & 0xffffu) * n0 + (c >> 16) * n1;
 				}
@@ -306,185 +525,34 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				if (lane == 0)
 					E.piece_bits[kk] = bits;
 			}
-		};
-		if (w == 1)
-			fill_lut();
-		if (w >= 2)
-			weigh(k0 + w - 2, EW_NW - 2);
-		if (w == 0) {
-			if (lane < 19)
-				L.pfreq[lane] = 0;
-			uint32_t hlit, hdist;
-			{
-				const uint64_t ml = __ballot(lane < 29 && (Bd.lcode[257 + lane] >> 16) != 0);
-				const uint64_t md = __ballot(lane < 29 && (Bd.dcode[1 + lane] >> 16) != 0);
-				hlit = ml ? 257 + 64 - (uint32_t)__clzll((long long)ml) : 257;
-				hdist = md ? 1 + 64 - (uint32_t)__clzll((long long)md) : 1;
-			}
-			const uint32_t total = hlit + hdist;
-			uint8_t *lens = Bd.lens();
-			uint16_t *items = Bd.items();
-			uint16_t *run_start = Bd.hs.parent;            // free until the precode is built
-			for (uint32_t i = lane; i < total; i += 64)
-				lens[i] = (uint8_t)((i < hlit ? Bd.lcode[i] : Bd.dcode[i - hlit]) >> 16);
-			uint32_t nruns = 0;
-			for (uint32_t base = 0; base < total; base += 64) {
-				const uint32_t i = base + lane;
-				const bool st = i < total && (i == 0 || lens[i] != lens[i - 1]);
-				const uint64_t mm = __ballot(st);
-				if (st)
-					run_start[nruns + __popcll(mm & ((1ull << lane) - 1))] = (uint16_t)i;
-				nruns += (uint32_t)__popcll(mm);
-			}
-			if (lane == 0)
-				run_start[nruns] = (uint16_t)total;
-			uint32_t ni = 0;
-			for (uint32_t rb = 0; rb < nruns; rb += 64) {
-				const uint32_t r = rb + lane;
-				const bool valid = r < nruns;
-				const uint32_t s0 = valid ? run_start[r] : 0, len = valid ? run_start[r + 1] - s0 : 0;
-				const uint32_t v = valid ? lens[s0] : 0;
-				uint32_t rep, big, rest, lead;
-				if (v == 0) {
-					rep = 18; lead = 0;
-					big = len / 138; rest = len - 138 * big;
-				} else {
-					rep = 16; lead = valid ? 1u : 0u;
-					big = (len - lead) / 6; rest = (len - lead) - 6 * big;
-				}
-				const uint32_t full = v == 0 ? 138u : 6u, base_len = v == 0 ? 11u : 3u;
-				uint32_t extra_rep = 0, extra_sym = rep, extra_base = base_len;
-				if (rest >= base_len) {
-					extra_rep = 1;
-				} else if (v == 0 && rest >= 3) {
-					extra_rep = 1; extra_sym = 17; extra_base = 3;
-				}
-				const uint32_t tail = extra_rep ? 0u : rest;
-				const uint32_t c = valid ? lead + big + extra_rep + tail : 0u;
-				const uint32_t incl = wave_incl_scan(c);
-				uint32_t o = ni + incl - c;
-				if (valid) {
-					if (lead)
-						items[o++] = (uint16_t)v;
-					for (uint32_t j = 0; j < big; j++)
-						items[o++] = (uint16_t)(rep | ((full - base_len) << 8));
-					if (extra_rep)
-						items[o++] = (uint16_t)(extra_sym | ((rest - extra_base) << 8));
-					for (uint32_t j = 0; j < tail; j++)
-						items[o++] = (uint16_t)v;
-					if (lead + tail)
-						atomicAdd(&L.pfreq[v], lead + tail);
-					if (big)
-						atomicAdd(&L.pfreq[rep], big);
-					if (extra_rep)
-						atomicAdd(&L.pfreq[extra_sym], 1u);
-				}
-				ni += readlane(incl, 63);
-			}
-			build_code(L.pfreq, 19, HD_PRECODE_MAXBITS, L.pcode, Bd.hs, lane, true);
-			uint32_t hclen = 19;
-			while (hclen > 4 && (uniform(L.pcode[k_perm19[hclen - 1]]) >> 16) == 0)
-				hclen--;
-			uint32_t dyn = 0, sta = 0, extra = 0;
-			for (uint32_t base = 0; base < ni; base += 64) {
-				const uint32_t kx = base + lane;
-				if (kx < ni) {
-					const uint32_t sym = Bd.items()[kx] & 31;
-					dyn += (L.pcode[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
-				}
-			}
-			for (uint32_t base = 0; base < 286; base += 64) {
-				const uint32_t s = base + lane;
-				if (s < 286) {
-					const uint32_t f = L.lf[s];
-					dyn += f * (Bd.lcode[s] >> 16);
-					sta += f * (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
-					if (s >= 265 && s < 285)
-						extra += f * ((s - 261) >> 2);
-				}
-			}
-			if (lane < 30) {
-				const uint32_t f = L.df[lane];
-				dyn += f * (Bd.dcode[lane] >> 16);
-				sta += f * 5u;
-				extra += f * (lane < 4 ? 0u : (lane >> 1) - 1);
-			}
-			dyn = readlane(wave_incl_scan(dyn), 63) + 3 + 5 + 5 + 4 + 3 * hclen;
-			sta = readlane(wave_incl_scan(sta), 63) + 3;
-			extra = readlane(wave_incl_scan(extra), 63);
-			const bool use_dynamic = dyn < sta;
-			const uint64_t blockbits = (uint64_t)(use_dynamic ? dyn : sta) + extra;
-			const bool fits = (uint64_t)(bitpos - paybase) + blockbits <= limit_bits;
-			if (fits && use_dynamic) {
-				uint32_t c0 = 0, n0 = 0;
-				if (lane == 0) { c0 = (final && !flush) ? 1u : 0u; n0 = 1; }
-				else if (lane == 1) { c0 = 2; n0 = 2; }
-				else if (lane == 2) { c0 = hlit - 257; n0 = 5; }
-				else if (lane == 3) { c0 = hdist - 1; n0 = 5; }
-				else if (lane == 4) { c0 = hclen - 4; n0 = 4; }
-				else if (lane < 5 + hclen) { c0 = L.pcode[k_perm19[lane - 5]] >> 16; n0 = 3; }
-				emit1(c0, n0);
-				for (uint32_t base = 0; base < ni; base += 64) {
-					const uint32_t kx = base + lane;
-					uint32_t cc = 0, nn = 0;
-					if (kx < ni) {
-						const uint32_t it = Bd.items()[kx], sym = it & 31;
-						const uint32_t pc = L.pcode[sym];
-						cc = (pc & 0xffff) | ((it >> 8) << (pc >> 16));
-						nn = (pc >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
-					}
-					emit1(cc, nn);
-				}
-			} else if (fits) {
-				emit1(lane == 0 ? ((final && !flush) ? 1u : 0u) : 1u, lane == 0 ? 1u : lane == 1 ? 2u : 0u);
-			}
-			if (lane == 0) {
-				E.ctl[0] = fits ? 1u : 0u;
-				E.ctl[1] = use_dynamic ? 1u : 0u;
-				E.ctl[2] = bitpos;
-			}
 		}
 		__syncthreads();
 		EW_T(4);
-		alive = uniform(E.ctl[0]) != 0;
-		if (!alive)
-			break;
-		bitpos = uniform(E.ctl[2]);
-		if (uniform(E.ctl[1]) == 0) {
-			// the static code won (rare): its codes in place of the dynamic ones, the table and the pieces' weights again
-			if (w == 0) {
-				for (uint32_t s = lane; s < 288; s += 64) {
-					const uint32_t len = s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u;
-					const uint32_t cw = s < 144 ? 0x30 + s : s < 256 ? 0x190 + (s - 144) : s < 280 ? s - 256 : 0xC0 + (s - 280);
-					Bd.lcode[s] = (len << 16) | (__brev(cw) >> (32 - len));
-				}
-				if (lane < 32)
-					Bd.dcode[lane] = (5u << 16) | (__brev(lane) >> 27);
-			}
-			__syncthreads();
-			if (w == 1)
-				fill_lut();
-			if (w >= 2)
-				weigh(k0 + w - 2, EW_NW - 2);
-			__syncthreads();
-		}
-		// ---- every piece has its place; the pieces are coded side by side ----------------------------------------------------
-		const uint32_t pb = (lane >= k0 && lane < k1) ? E.piece_bits[lane] : 0u;
-		const uint32_t pincl = wave_incl_scan(pb);
+		// ---- every piece has its place; the pieces of the round are coded side by side ----------------------------------------
+		const uint32_t pb = (lane >= kr0 && lane < kend[EW_SLOTS - 1]) ? E.piece_bits[lane] : 0u;
+		const uint32_t pex = wave_incl_scan(pb) - pb;                                   // bits of the round's pieces in front of piece `lane`
 		uint32_t bp = 0;
-		for_tokens(k0 + w, k1, EW_NW,
-			   [&](uint32_t kk) { bp = bitpos + readlane(pincl, kk) - readlane(pb, kk); },
+		const EW_LDS uint32_t *lut = nullptr, *dcode = nullptr;
+		for_tokens(kr0 + w, kend[EW_SLOTS - 1], EW_NW,
+			   [&](uint32_t kk) {
+				   const uint32_t si = (kk >= kend[0] ? 1u : 0u) + (kk >= kend[1] ? 1u : 0u) + (kk >= kend[2] ? 1u : 0u);
+				   const uint32_t kb = si == 0 ? kr0 : si == 1 ? kend[0] : si == 2 ? kend[1] : kend[2];    // the block's first piece
+				   const uint32_t bs = si == 0 ? bstart[0] : si == 1 ? bstart[1] : si == 2 ? bstart[2] : bstart[3];
+				   bp = bs + uniform(slots3[si].info[2]) + readlane(pex, kk) - readlane(pex, kb);
+				   lut = slots3[si].lut;
+				   dcode = slots3[si].build.dcode;
+			   },
 			   [&](uint32_t tk, uint32_t nv) {
 				   const bool valid = lane < nv;
 				   const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
-				   const uint32_t le = E.lut[(tk >> 16) & 0x1ffu];
+				   const uint32_t le = lut[(tk >> 16) & 0x1ffu];
 				   const uint32_t ca = le & 0xffffffu, na = le >> 24;
 				   uint32_t ds, deb, dev;
 				   off_slot((tk & 0xffff) + 1, ds, deb, dev);
-				   const uint32_t dc = Bd.dcode[ds];
+				   const uint32_t dc = dcode[ds];
 				   const uint32_t cb = (dc & 0xffff) | (dev << (dc >> 16));
-				   const uint32_t nb = is_match ? (dc >> 16) + deb : 0u;
-				   const uint32_t nbits = valid ? na + nb : 0u;
+				   const uint32_t nb2 = is_match ? (dc >> 16) + deb : 0u;
+				   const uint32_t nbits = valid ? na + nb2 : 0u;
 				   const uint64_t code = valid ? ((uint64_t)ca | ((uint64_t)(is_match ? cb : 0u) << na)) : 0ull;
 				   const uint32_t incl = wave_incl_scan(nbits);
 				   const uint32_t at = bp + incl - nbits;
@@ -497,16 +565,9 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 				   bp += readlane(incl, 63);
 			   },
 			   [&](uint32_t) {});
-		bitpos += readlane(pincl, 63);
-		{
-			const uint32_t eob = Bd.lcode[256];
-			if (w == 0 && lane == 0)
-				put(eob & 0xffff, eob >> 16, bitpos);
-			bitpos += uniform(eob) >> 16;
-		}
 		EW_T(5);
-		// (no barrier here: the next block's sums go to L.lf / L.df, which nobody reads while coding; its codes and tables are
-		// written behind the barrier that follows the sums, which every wavefront reaches with its pieces coded)
+		if (r0 + EW_SLOTS < nblk)
+			__syncthreads();                                    // (the next round's sums and codes take the slots' places)
 	}
 
 	__syncthreads();

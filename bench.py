@@ -314,15 +314,20 @@ class Bench:
         if not self.pkg.available():
             raise SystemExit("no usable MI355X; there is no CPU fallback to measure")
 
-    # a seeded tile replicated to G GiB in HBM
+    # a seeded tile replicated to G GiB in HBM.  FASTQ-like input of the ENCODE runs: every tile carries its own record ids
+    # ("tile with per-tile record-id offset") -- the ids are nine digits wide from the first record on, so a
+    # tile differs from tile 0 in the digits of its two id fields per record and in nothing else, and the digits are written
+    # on the device (no second pass of the CPU generator).  The decode runs on the reference's streams replicate one
+    # compressed tile (the reference's encoder runs on the host, once) and say so.
     def make_data(self, kind, block, whole_blocks):
         torch, args = self.torch, self.args
         tile_bytes = args.tile_mib << 20
         if whole_blocks:
             tile_bytes = tile_bytes // block * block      # whole blocks per tile: a compressed tile repeats too
         r = self.rank
+        first = 100_000_000 * (1 + r)                     # nine digits up to 999,999,999: 8 ranks x 512 tiles x ~205 k records fit
         if kind == "fastq":
-            tile_np = self.synth.fastq_like(tile_bytes, seed=1234 + r, first_record=1 + r * 10_000_000)
+            tile_np = self.synth.fastq_like(tile_bytes, seed=1234 + r, first_record=first)
         elif kind == "text":
             tile_np = self.synth.text_like(tile_bytes, seed=4321 + r)
         else:
@@ -331,6 +336,26 @@ class Bench:
         total = int(args.gib * (1 << 30))
         reps = max(1, total // tile_bytes)
         data = torch.from_numpy(tile_np).cuda().repeat(reps)
+        self.tiles_vary = False
+        if kind == "fastq" and not whole_blocks and reps > 1:
+            import re
+            tb = tile_np.tobytes()
+            pos = np.array([m.start(1) for m in re.finditer(rb"@SRR000001\.(\d{9}) \d{9}/1\n", tb)], dtype=np.int64)
+            nrec = len(pos)
+            assert nrec > tile_bytes // 400 and tb[pos[0]:pos[0] + 9] == b"%d" % first
+            dpos = torch.from_numpy(pos).cuda()
+            ids0 = torch.arange(nrec, device="cuda", dtype=torch.int64) + first
+            pw = torch.tensor([10 ** (8 - d) for d in range(9)], device="cuda", dtype=torch.int64)
+            col = torch.arange(9, device="cuda", dtype=torch.int64)
+            for t in range(1, reps):
+                ids = ids0 + t * (nrec + 1)                      # (+ 1: the tile's last, cut record)
+                assert int(ids[-1]) < 1_000_000_000
+                dig = ((ids[:, None] // pw[None, :]) % 10 + 48).to(torch.uint8)
+                at = t * tile_bytes + dpos[:, None] + col[None, :]
+                data[at] = dig
+                data[at + 10] = dig                              # the second id field, behind the blank
+            self.tiles_vary = True
+            del dpos, ids0
         return tile_np, data, reps
 
     def fence(self):
@@ -478,9 +503,14 @@ class Bench:
         del out
         if not ok:
             raise AssertionError("full-size verification failed: the packed stream does not inflate back to the input")
-        return {"bytes": int(data.numel()), "members": int(nb),
+        # the one timing-dependent byte path of the encoders (a workgroup parse that gave a table turn up: the block is then
+        # written stored, valid but not the twin's bytes) must not have been taken
+        stalls = int(self.pkg.lib().hipdeflate_stall_count())
+        if stalls:
+            raise AssertionError("%d workgroup-parse stalls: the measured run did not write the twin's bytes" % stalls)
+        return {"bytes": int(data.numel()), "members": int(nb), "stalls": stalls,
                 "how": "untimed: device inflate of the whole packed stream == input (torch.equal), per-member CRC-32 == "
-                       "encoder's == trailer field, ISIZE == block length"}
+                       "encoder's == trailer field, ISIZE == block length; hipdeflate_stall_count() == 0"}
 
     def decode(self, data, packed, in_off, in_len, want_crc, block, steps, warmup):
         torch, dev = self.torch, self.dev
@@ -577,7 +607,7 @@ def main():
         # in one piece at the end of the process instead of being followed by ~10 s of host-only work
         synth = importlib.import_module("7bgzf_amd.synth")
         tb = min(args.tile_mib, 64) << 20
-        ctile = (synth.fastq_like(tb, seed=1234, first_record=1) if args.data == "fastq" else
+        ctile = (synth.fastq_like(tb, seed=1234, first_record=100_000_000) if args.data == "fastq" else
                  synth.text_like(tb, seed=4321) if args.data == "text" else synth.random_bytes(tb, seed=99))
         cpu = cpu_baseline(ctile, max(args.level, 1), args.mode, block)
         del ctile
@@ -639,14 +669,15 @@ def main():
             "ms_per_step": s["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s %s, %s blocks, %s, %.2f GiB %s per GPU (seeded generator, "
-                                   "%d MiB tile x %d), %d blocks/GPU, %s" % (
+                                   "%d MiB tile x %d%s), %d blocks/GPU, %s" % (
                                        "MiGz" if args.block_kib else "BGZF", args.mode,
                                        ("%d KiB" % args.block_kib) if args.block_kib else "0xff00-byte",
                                        ("stream from the reference's %s (built from the reference tree)" % args.stream)
                                        if decode_ref else level_name(level),
                                        total / 2 ** 30, {"fastq": "FASTQ-like", "text": "enwik-like text",
                                                          "random": "random bytes"}[args.data],
-                                       args.tile_mib, reps, res["nb"], shard_txt),
+                                       args.tile_mib, reps, ", record ids offset per tile" if B.tiles_vary else
+                                       (", identical tiles" if reps > 1 else ""), res["nb"], shard_txt),
                        "blocks_per_gpu": res["nb"], "input_bytes_per_gpu": int(total), "ratio": s["ratio"], "parallelism": "block-range shard x%d" % world,
                        "step": ("encode kernel + size scan + %sgather into the contiguous stream; passes are "
                                 "software-pipelined as a stream of batches is: scan and gather of pass k run on a second "
@@ -748,7 +779,8 @@ def main():
                 r = B.decode(d2, packed, in_off, in_len, want_crc, block, xs, xw)
                 out = summary(r, xs, mode="decode")
                 out["workload"] = ("BGZF decode (inflate), 0xff00-byte blocks, %.2f GiB out, stream from the reference's "
-                                   "%s; output and per-block CRC-32 checked" % (d2.numel() / 2 ** 30, who))
+                                   "%s (one %d MiB tile compressed on the host, its stream replicated); output and per-block "
+                                   "CRC-32 checked" % (d2.numel() / 2 ** 30, who, args.tile_mib))
                 return out
             return run
         # BASELINE config 3 names both reference encoders

