@@ -2041,6 +2041,12 @@ int hipdeflate_test_emit_stats(uint64_t *out16)   // [0,8) phases of the emit ke
 	HD_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hd::g_emit_stats), 128));
 	return 0;
 }
+int hipdeflate_test_emit_stats32(uint64_t *out32)   // ... and [16,32): k_emit_wg's block builder
+{
+	HD_CHECK(hipDeviceSynchronize());
+	HD_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(hd::g_emit_stats), 256));
+	return 0;
+}
 #endif
 
 #ifdef HD_CLOCK_STAMPS

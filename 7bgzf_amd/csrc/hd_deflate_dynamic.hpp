@@ -147,7 +147,7 @@ inline uint64_t dynamic_scratch_bytes(uint32_t nblocks, uint32_t split_max, int 
 
 #ifdef HD_EMIT_STATS
 // experiment build only: cycles of the emit-only kernel by phase (tools/exp_emit_stats.sh)
-__device__ unsigned long long g_emit_stats[16];
+__device__ unsigned long long g_emit_stats[32];      // [16, 32): k_emit_wg's block builder, wavefront 0 (hd_emit_wg.hpp)
 #define EMIT_T0() const unsigned long long t_ph = EMIT ? clock64() : 0ull
 #define EMIT_T(k) do { if (EMIT && lane == 0) atomicAdd(&g_emit_stats[k], clock64() - t_ph); } while (0)
 #else
@@ -178,9 +178,18 @@ struct HuffScratch {
 // lone: the caller is a wavefront ALONE on its SIMD (k_emit_wg): the register form of the merge below -- fewer instructions, what
 // sixteen emit wavefronts per CU want -- is a chain of v_readlane -> scalar compare -> branch that such a wavefront runs at ~670
 // cycles per node; the lane-0 form against LDS takes ~210 (measured, tools/exp_emit_wg_stats.py)
-__device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms, uint32_t maxbits, uint32_t *out,
-					 HuffScratch &h, uint32_t lane, bool lone = false)
+// The pointers' types are template parameters: the same source for generic pointers (the emit-only kernels: flat instructions,
+// whose extra latency their sixteen wavefronts per CU hide) and for LDS-typed ones (k_emit_wg, hd_emit_wg.hpp: ds_read / ds_write --
+// a lone wavefront waits for every one of its LDS round trips, and through flat_load a construction took twice as long).
+template <class P>
+__device__ __forceinline__ void hs_count(P p)
 {
+	__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <class FP, class OP, class HP>
+__device__ __noinline__ void build_code_t(FP freq_in, uint32_t nsyms, uint32_t maxbits, OP out, HP hp, uint32_t lane, bool lone)
+{
+	auto &h = *hp;
 	BUILD_T0();
 	// working copy, dummies so that at least two symbols are used
 	uint32_t nu = 0;
@@ -206,7 +215,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 	// order, into keys freq << 9 | symbol (all distinct), and a key's rank is the number of smaller keys
 	// -- nu * ceil(nu / 64) compares instead of nsyms * ceil(nsyms / 64).  The keys borrow the upper
 	// half of the node-weight array, which the merge only reaches when it has consumed them.
-	uint32_t *const keys = &h.nf[288];
+	auto *const keys = &h.nf[288];
 	{
 		uint32_t at = 0;
 		for (uint32_t base = 0; base < nsyms; base += 64) {
@@ -294,11 +303,11 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			h.depth[lane1] = (uint8_t)ND1;
 		if (lane < nu) {
 			const uint32_t d = (uint32_t)h.depth[LP0] + 1;
-			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+			hs_count(&h.blc[d > maxbits ? maxbits : d]);
 		}
 		if (lane1 < nu) {
 			const uint32_t d = (uint32_t)h.depth[LP1] + 1;
-			atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+			hs_count(&h.blc[d > maxbits ? maxbits : d]);
 		}
 	} else {
 		// The serial parts run on lane 0 against LDS, ~100 cycles a round trip, so they are written to keep
@@ -351,7 +360,7 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 			const uint32_t x = base + lane;
 			if (x < nu) {
 				const uint32_t d = (uint32_t)h.depth[h.parent[x]] + 1;
-				atomicAdd(&h.blc[d > maxbits ? maxbits : d], 1u);
+				hs_count(&h.blc[d > maxbits ? maxbits : d]);
 			}
 		}
 	}
@@ -422,6 +431,13 @@ __device__ __noinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms,
 		}
 	}
 	BUILD_T(5);
+}
+
+// (the form the emit-only kernels call)
+__device__ __forceinline__ void build_code(const uint32_t *freq_in, uint32_t nsyms, uint32_t maxbits, uint32_t *out, HuffScratch &h,
+					    uint32_t lane, bool lone = false)
+{
+	build_code_t<const uint32_t *, uint32_t *, HuffScratch *>(freq_in, nsyms, maxbits, out, &h, lane, lone);
 }
 
 struct DynLds {

@@ -33,6 +33,7 @@ constexpr uint32_t EW_BLOCK_MAX = 65536;            // the longest block: the ho
                                                     // of at most this many bytes: the parse refuses a block longer than its room)
 
 #define EW_LDS __attribute__((address_space(3)))
+constexpr uint32_t EW_SCRATCH_DW = 1536;            // dwords of the image lent to an offset-code construction (>= sizeof(HuffScratch))
 constexpr uint32_t EW_SLOTS = 4;                    // DEFLATE blocks whose codes are built side by side (a wavefront each)
 struct EwSlot {
 	DynBuild build;                                 // the block's construction scratch and codes
@@ -67,17 +68,40 @@ __device__ __forceinline__ uint32_t ew_emit1(EW_LDS uint32_t *stage, uint32_t bi
 // One wavefront, one DEFLATE block (its histograms are in S->L): the codes, the RLE of their lengths, the precode, the exact
 // cost, dynamic or static, the litlen table -- flush_block of the emit-only kernel (hd_deflate_dynamic.hpp) statement by
 // statement, everything but the bits; what the header needs later stays in the slot.
+#ifdef HD_EMIT_STATS
+#define EWB_T(k) do { if (threadIdx.x == 0) { const unsigned long long t_now = clock64(); atomicAdd(&g_emit_stats[16 + (k)], t_now - t_b); t_b = t_now; } } while (0)
+#else
+#define EWB_T(k) do { } while (0)
+#endif
+// the litlen code of the slot's block (which = 0: the slot's own construction scratch) or its offset code (which = 1: scratch
+// lent by the caller -- the two constructions of a block run side by side on two wavefronts)
+__device__ __forceinline__ void ew_build_code(EW_LDS EwSlot *S, uint32_t which, EW_LDS HuffScratch *scratch, uint32_t lane)
+{
+#ifdef HD_EMIT_STATS
+	unsigned long long t_b = clock64();
+#endif
+	// (build_code_t with LDS-typed pointers: ds_read / ds_write instead of flat instructions)
+	if (which == 0) {
+		if (lane == 0)
+			S->L.lf[256] += 1;                              // end of block
+		build_code_t<const EW_LDS uint32_t *, EW_LDS uint32_t *, EW_LDS HuffScratch *>(S->L.lf, 288, HD_LITLEN_MAXBITS, S->build.lcode, scratch, lane, true);
+		EWB_T(0);
+	} else {
+		build_code_t<const EW_LDS uint32_t *, EW_LDS uint32_t *, EW_LDS HuffScratch *>(S->L.df, 32, HD_OFFSET_MAXBITS, S->build.dcode, scratch, lane, true);
+	}
+}
+
 __device__ __forceinline__ void ew_prepare_block(EW_LDS EwSlot *S, uint32_t lane)
 {
+#ifdef HD_EMIT_STATS
+	unsigned long long t_b = clock64();
+#endif
 	EW_LDS uint32_t *const lf = S->L.lf, *const df = S->L.df, *const pfreq = S->L.pfreq, *const pcode = S->L.pcode;
 	EW_LDS uint32_t *const lcode = S->build.lcode, *const dcode = S->build.dcode;
 	EW_LDS uint16_t *const items = (EW_LDS uint16_t *)&S->build.hs.nf[64];           // (DynBuild::items() / lens())
 	EW_LDS uint8_t *const lens = (EW_LDS uint8_t *)&S->build.hs.nf[64 + 160];
 	EW_LDS uint16_t *const run_start = S->build.hs.parent;                           // free until the precode is built
-	if (lane == 0)
-		lf[256] += 1;                                   // end of block
-	build_code((const uint32_t *)lf, 288, HD_LITLEN_MAXBITS, (uint32_t *)lcode, *(HuffScratch *)&S->build.hs, lane, true);
-	build_code((const uint32_t *)df, 32, HD_OFFSET_MAXBITS, (uint32_t *)dcode, *(HuffScratch *)&S->build.hs, lane, true);
+	// (the litlen and offset codes are in place: ew_build_code, two wavefronts per block)
 	if (lane < 19)
 		pfreq[lane] = 0;
 	uint32_t hlit, hdist;
@@ -144,7 +168,9 @@ __device__ __forceinline__ void ew_prepare_block(EW_LDS EwSlot *S, uint32_t lane
 		}
 		ni += readlane(incl, 63);
 	}
-	build_code((const uint32_t *)pfreq, 19, HD_PRECODE_MAXBITS, (uint32_t *)pcode, *(HuffScratch *)&S->build.hs, lane, true);
+	EWB_T(2);
+	build_code_t<const EW_LDS uint32_t *, EW_LDS uint32_t *, EW_LDS HuffScratch *>(pfreq, 19, HD_PRECODE_MAXBITS, pcode, &S->build.hs, lane, true);
+	EWB_T(3);
 	uint32_t hclen = 19;
 	while (hclen > 4 && (uniform(pcode[k_perm19[hclen - 1]]) >> 16) == 0)
 		hclen--;
@@ -179,6 +205,7 @@ __device__ __forceinline__ void ew_prepare_block(EW_LDS EwSlot *S, uint32_t lane
 	sta = readlane(wave_incl_scan(sta), 63) + 3;
 	extra = readlane(wave_incl_scan(extra), 63);
 	const bool use_dynamic = dyn < sta;                      // tie -> static (deflate_compress.c:1861-1867)
+	EWB_T(4);
 	if (!use_dynamic) {
 		// the static code won (rare): its codes in place of the dynamic ones
 		for (uint32_t s = lane; s < 288; s += 64) {
@@ -208,6 +235,7 @@ __device__ __forceinline__ void ew_prepare_block(EW_LDS EwSlot *S, uint32_t lane
 		S->info[5] = hdist;
 		S->info[6] = hclen;
 	}
+	EWB_T(5);
 }
 
 // ... and the bits of its header at `bstart`, its end-of-block code at the block's end (bbits on)
@@ -475,6 +503,23 @@ __global__ __launch_bounds__(64 * EW_NW) void k_emit_wg(DeflateArgs a)
 		// (its own function, the slot through an LDS-typed pointer: with `E.slot[w]` inline the compiler loses track of the
 		// address space and reaches LDS through flat instructions -- the serial RLE / cost code ran four times slower so --,
 		// and four inlined copies spill)
+		// The litlen code on wavefront i, the offset code on wavefront 4 + i (another SIMD's: tools/simd_probe.hip), its scratch
+		// lent from the image, which is all zeros and nobody's until the headers go in -- and is zeroed again below
+		static_assert(EW_SCRATCH_DW * 4 >= sizeof(HuffScratch) && 1024 + EW_SLOTS * EW_SCRATCH_DW <= EW_STAGE_DW, "the lent scratch lies inside the image");
+		// (only in the first round: behind it the image holds the blocks already coded, and a member of more than four
+		// DEFLATE blocks -- rare -- builds the later ones' two codes one after the other)
+		const bool lend = r0 == 0;
+		if (w < nb) {
+			ew_build_code((EW_LDS EwSlot *)&E.slot[0] + w, 0, &((EW_LDS EwSlot *)&E.slot[0] + w)->build.hs, lane);
+			if (!lend)
+				ew_build_code((EW_LDS EwSlot *)&E.slot[0] + w, 1, &((EW_LDS EwSlot *)&E.slot[0] + w)->build.hs, lane);
+		} else if (lend && w >= 4 && w - 4 < nb) {
+			ew_build_code((EW_LDS EwSlot *)&E.slot[0] + (w - 4), 1, (EW_LDS HuffScratch *)((EW_LDS uint32_t *)E.stage + 1024 + (w - 4) * EW_SCRATCH_DW), lane);
+		}
+		__syncthreads();
+		if (lend)
+			for (uint32_t i = threadIdx.x; i < EW_SLOTS * EW_SCRATCH_DW; i += 64 * EW_NW)
+				E.stage[1024 + i] = 0;
 		if (w < nb)
 			ew_prepare_block((EW_LDS EwSlot *)&E.slot[0] + w, lane);
 		__syncthreads();
