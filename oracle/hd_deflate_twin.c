@@ -120,11 +120,10 @@ typedef struct {
 	unsigned win;         /* ring size in bytes */
 	size_t filled;        /* bytes the GPU ring has been filled up to */
 	unsigned intra;       /* candidates at distances 1..intra inside the step (HD_INTRA_DIST) */
-	/* the lazy levels (5..9): six-byte key, two positions per bucket (include/hipdeflate_params.h "LAZY LEVELS").  The
-	 * role of hc_matchfinder_longest_match's chain walk (lib/libdeflate/hc_matchfinder.h:183-338) at depth 2 */
-	int deep;
-	uint32_t *bucket;     /* HD_BUCKETS dwords: low half newest, high half the one before */
 } mf_t;
+/* (rounds 2-4 also had the lazy levels' one-wavefront matchfinder here -- six-byte key, two positions per bucket, a one-lane
+ * lazy rule -- for the latency form of levels 3..9; since round 5 those levels are the workgroup parse in every form,
+ * deflate_wg() below, and the step parse is level 1's and level 2's: greedy, minimum length 4) */
 
 typedef struct {
 	unsigned lanes;           /* positions covered by lanes this step */
@@ -146,14 +145,12 @@ static uint32_t mf_index(const mf_t *mf, uint32_t v)
 	return HD_HASH_SLOT(v, HD_TABLE_ENTRIES((unsigned)__builtin_ctz(mf->win), mf->hash_bits));
 }
 
-static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry,
-		       unsigned minlen, int lazy, step_t *st)
+static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned carry, step_t *st)
 {
-	uint32_t cand[HD_WAVE], cand2[HD_WAVE], pre[HD_WAVE];
-	uint8_t ok[HD_WAVE], cap8[HD_WAVE];
+	uint32_t cand[HD_WAVE];
+	uint8_t ok[HD_WAVE];
 	unsigned lanes = n - S < HD_WAVE ? (unsigned)(n - S) : HD_WAVE;
-	const unsigned keyb = mf->deep ? HD_LAZY_KEY_BYTES : HD_MIN_MATCH;       /* bytes a position needs to be hashed */
-	const unsigned nbuckets = HD_BUCKETS((unsigned)__builtin_ctz(mf->win), mf->hash_bits);
+	const unsigned keyb = HD_MIN_MATCH;       /* bytes a position needs to be hashed */
 
 	/* the ring is refilled a 1 KiB piece at a time until it holds
 	 * HD_LOOKAHEAD bytes past S (or the whole input) */
@@ -165,19 +162,10 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 	for (unsigned l = 0; l < lanes; l++) {          /* 1. look up */
 		size_t p = S + l;
 		ok[l] = 0;
-		cand2[l] = 0;
 		if (p + keyb > n)
 			continue;
 		uint32_t v = load32(in + p);
-		uint32_t e;
-		if (mf->deep) {
-			pre[l] = mf->bucket[HD_HASH_SLOT6(v, in[p + 4] | (in[p + 5] << 8), nbuckets)];
-			e = pre[l] & 0xffffu;
-			uint32_t e2 = pre[l] >> 16, back2 = (uint32_t)(p + 1 - e2) & 0xffffu;
-			cand2[l] = (e2 && back2) ? (uint32_t)(p + 1 - back2) : 0;
-		} else {
-			e = mf->table[mf_index(mf, v)];
-		}
+		uint32_t e = mf->table[mf_index(mf, v)];
 		/* the latest p' < p with p' + 1 == e (mod 2^16); for inputs <= 64 KiB
 		 * that is simply e */
 		uint32_t back = (uint32_t)(p + 1 - e) & 0xffffu;   /* 0 = exactly 2^16 back: stale */
@@ -196,36 +184,14 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 		size_t p = S + l;
 		if (p + keyb > n)
 			continue;
-		/* the kernel's lanes race for the slot and re-write until the largest
-		 * position of the step holds it: within a step the last lane wins */
-		if (mf->deep)       /* every lane stores (what it READ << 16) | itself: { newest before the step, last lane of the step } */
-			mf->bucket[HD_HASH_SLOT6(load32(in + p), in[p + 4] | (in[p + 5] << 8), nbuckets)] = (pre[l] << 16) | (uint16_t)(p + 1);
-		else
-			mf->table[mf_index(mf, load32(in + p))] = (uint16_t)(p + 1);
+		/* the lanes of a step that hash alike store to one entry in one instruction: the highest lane's
+		 * data stays (the device self-test probes it), i.e. within a step the last lane wins */
+		mf->table[mf_index(mf, load32(in + p))] = (uint16_t)(p + 1);
 	}
 	for (unsigned l = 0; l < lanes; l++) {          /* 3. verify */
 		size_t p = S + l;
 		if (p + keyb > n)
 			continue;
-		if (mf->deep) {
-			/* both positions of the bucket are verified over 16 bytes (what the lanes learn in parallel at these
-			 * levels); the older one is taken only when it is strictly longer */
-			unsigned room16 = n - p < 16 ? (unsigned)(n - p) : 16, best = 0;
-			for (int w = 0; w < 2; w++) {
-				uint32_t cw = w ? cand2[l] : cand[l];
-				if (cw == 0 || cw - 1 < lo || load32(in + cw - 1) != load32(in + p))
-					continue;
-				unsigned k = 4;
-				while (k < room16 && in[p + k] == in[cw - 1 + k])
-					k++;
-				if (k > best) {
-					best = k;
-					cand[l] = cw;
-				}
-			}
-			if (!best)
-				continue;
-		}
 		if (cand[l] == 0)
 			continue;
 		size_t c = cand[l] - 1;
@@ -233,25 +199,8 @@ static void parse_step(mf_t *mf, const uint8_t *in, size_t n, size_t S, unsigned
 			continue;
 		if (load32(in + c) != load32(in + p))
 			continue;
-		/* what the 64 lanes learn in parallel: the length up to 8 */
-		unsigned room = n - p < 8 ? (unsigned)(n - p) : 8, l8 = 4;
-		while (l8 < room && in[p + l8] == in[c + l8])
-			l8++;
-		if (l8 < minlen)
-			continue;
-		ok[l] = 1;
-		cap8[l] = (uint8_t)l8;
+		ok[l] = 1;                     /* four equal bytes: a candidate (the minimum match of levels 1 and 2) */
 		st->dist[l] = (uint32_t)(p - c);
-	}
-	if (lazy) {
-		/* one-lane lookahead: a candidate steps aside (becomes a literal) when
-		 * its right neighbour's match is longer, judged on the 8-byte lengths */
-		uint8_t defer[HD_WAVE];
-		for (unsigned l = 0; l < lanes; l++)
-			defer[l] = ok[l] && l + 1 < lanes && ok[l + 1] && cap8[l + 1] > cap8[l];
-		for (unsigned l = 0; l < lanes; l++)
-			if (defer[l])
-				ok[l] = 0;
 	}
 	unsigned E = carry;                             /* 4. greedy */
 	for (unsigned l = 0; l < lanes; l++) {
@@ -294,7 +243,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	 * "stored > static > dynamic" preference (deflate_compress.c:1820-1867) */
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + HD_STEP_MAX_BITS / 8 + 16 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0, 0, NULL };                /* level 1 is the speed level: no run candidates */
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, 0 };                /* level 1 is the speed level: no run candidates */
 	bw_t w = { tmp, 0 };
 	int use_static = 1;
 	step_t st;
@@ -310,7 +259,7 @@ static int deflate_static(uint8_t *dest, size_t *destLen, const uint8_t *in, siz
 	for (size_t S = 0; S < n && use_static; S += HD_WAVE) {
 		if (S == prime)
 			carry = 0;
-		parse_step(&mf, in, n, S, carry, HD_MIN_MATCH, 0, &st);
+		parse_step(&mf, in, n, S, carry, &st);
 		carry = st.carry_out;
 		if (S < prime)
 			continue;
@@ -651,15 +600,13 @@ static int write_stored(uint8_t *dest, size_t *destLen, const uint8_t *in, size_
  * its own (fresh table, fresh window, no match across the border: one wavefront each on the device), the tokens of all parts
  * then make ONE DEFLATE block with one code (the emit wavefront's) */
 static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, size_t n,
-			   unsigned win_bits, unsigned hash_bits, unsigned minlen, int lazy, unsigned intra, int flush, int deep,
-			   unsigned part, size_t segprime)
+			   unsigned win_bits, unsigned hash_bits, unsigned intra, int flush, unsigned part, size_t segprime)
 {
 	size_t cap = *destLen >= (flush ? 5u : 0u) ? *destLen - (flush ? 5u : 0u) : 0;
 	size_t stored = HD_STORED_SIZE(n);
 	size_t limit = cap < stored - 1 ? cap : stored - 1;
 	uint8_t *tmp = calloc(1, limit + 64 + 8);
-	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, intra, deep,
-		    deep ? calloc(HD_BUCKETS(win_bits, hash_bits), 4) : NULL };
+	mf_t mf = { calloc((size_t)1 << hash_bits, 2), hash_bits, 1u << win_bits, 0, intra };
 	dynblk_t b;
 	bw_t w = { tmp, 0 };
 	step_t st;
@@ -667,7 +614,6 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 
 	memset(&b, 0, sizeof(b));
 	b.tok = malloc((HD_DYN_BLOCK_TOKENS + 64) * 4);
-	const size_t nbk = deep ? HD_BUCKETS(win_bits, hash_bits) : 0;
 	if (part)
 		b.tok = realloc(b.tok, (n + HD_DYN_BLOCK_TOKENS + 64) * 4);     /* (never closed early: one block) */
 	for (size_t ps = 0; ps < n && alive; ps += part ? part : n) {
@@ -679,14 +625,12 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 		unsigned carry = 0;
 		if (ps) {
 			memset(mf.table, 0, ((size_t)1 << hash_bits) * 2);
-			if (deep)
-				memset(mf.bucket, 0, nbk * 4);
 			mf.filled = 0;
 		}
 		for (size_t S = 0; S < pn && alive; S += HD_WAVE) {
 			if (S == prime)
 				carry = 0;
-			parse_step(&mf, pin, pn, S, carry, minlen, lazy, &st);
+			parse_step(&mf, pin, pn, S, carry, &st);
 			carry = st.carry_out;
 			if (S < prime)
 				continue;
@@ -721,7 +665,6 @@ static int deflate_dynamic(uint8_t *dest, size_t *destLen, const uint8_t *in, si
 	}
 	free(b.tok);
 	free(mf.table);
-	free(mf.bucket);
 	free(tmp);
 	return ret;
 }
@@ -971,8 +914,7 @@ static int twin(uint8_t *dest, size_t *destLen, const uint8_t *source, size_t so
 	if (level == 1)
 		return deflate_static(dest, destLen, source, sourceLen, HD_L1_WIN_BITS, HD_L1_HASH_BITS, flush, prime);
 	if (level == 2)
-		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS,
-				       HD_L2_MIN_LEN, 0, HD_INTRA_DIST, flush, 0, part, prime);
+		return deflate_dynamic(dest, destLen, source, sourceLen, HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_INTRA_DIST, flush, part, prime);
 	return write_stored(dest, destLen, source, sourceLen, flush);   /* (not reached) */
 }
 
