@@ -1125,13 +1125,4 @@ __global__ __launch_bounds__(64) void k_inflate(InflateArgs a)
 	inflate_stream<INF_RING>(a, L);
 }
 
-// latency form (hip_inflate / hip_inflate_flush: a handful of streams, callers waiting): the same decoder with the whole
-// DEFLATE window -- a whole BGZF block -- in LDS.  One wavefront alone on its CU cannot hide a load of flushed output
-// behind other waves; here it never issues one (a match reaches back 32 KiB at most, the ring holds 64).
-__global__ __launch_bounds__(64) void k_inflate_lat(InflateArgs a)
-{
-	__shared__ InfLdsT<INF_RING_LAT> L;
-	inflate_stream<INF_RING_LAT>(a, L);
-}
-
 } // namespace hd
