@@ -2,6 +2,8 @@
 sets, cuts, spliced tails) of zlib's and our own encoders' output over tests/hdtest.corpus_fuzz blocks;
 the kernel's verdict code, bytes and CRC-32 must equal the oracle's (oracle/hd_inflate.c, itself pinned
 on libdeflate_inflate), in the strict and in the flushed-chunk mode.
+HD_FUZZ_PER_CALL=1: the same streams through hip_inflate / hip_inflate_flush from 32 threads instead -- the per-call boundary, i.e.
+the two-wavefront latency kernel (hd_inflate_lat.hpp), whose verdicts and bytes must be the batch kernel's, i.e. the oracle's.
 usage: python tools/big_fuzz_inflate.py [mutants_per_base] [seeds...]"""
 import importlib
 import os
@@ -52,7 +54,15 @@ for seed in seeds:
                     m += bytes(rng.integers(0, 256, int(rng.integers(0, 12)), dtype=np.uint8))
                 streams.append(bytes(m))
                 caps.append(max(0, n + int(rng.integers(-2, 3)) * 40))
-        outs, crc, st = pkg.batch_inflate(streams, caps, flushed=flushed)
+        if os.environ.get("HD_FUZZ_PER_CALL") == "1":
+            call = pkg.hip_inflate_flush if flushed else pkg.hip_inflate
+            with ThreadPoolExecutor(32) as ex:
+                got = list(ex.map(lambda a: call(a[0], a[1]), zip(streams, caps)))
+            st = [g[0] for g in got]
+            outs = [g[1] for g in got]
+            crc = [zlib.crc32(o) for o in outs]                # (the per-call decoder hands no CRC back)
+        else:
+            outs, crc, st = pkg.batch_inflate(streams, caps, flushed=flushed)
         fn = hdtest.oracle_inflate_flushed if flushed else hdtest.oracle_inflate
         with ThreadPoolExecutor(min(64, os.cpu_count() or 16)) as ex:
             want = list(ex.map(lambda a: fn(a[0], a[1]), zip(streams, caps)))

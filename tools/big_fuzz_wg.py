@@ -56,5 +56,6 @@ for level in (3, 4, 5, 6, 9):
                 bad += 1
                 print("MISMATCH %s level %d frame %d st %d" % (names[i], level, frame, st[i]), flush=True)
         print("level %d frame %d done, %d so far, %d bad, %.0f s" % (level, frame, total, bad, time.time() - t0), flush=True)
-print("BIG_FUZZ_WG %s: %d comparisons, %d bad" % ("OK" if bad == 0 else "FAILED", total, bad))
-sys.exit(1 if bad else 0)
+stalls = int(pkg.lib().hipdeflate_stall_count())
+print("BIG_FUZZ_WG %s: %d comparisons, %d bad, %d stalls" % ("OK" if bad == 0 and stalls == 0 else "FAILED", total, bad, stalls))
+sys.exit(1 if bad or stalls else 0)
