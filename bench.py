@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--gib", type=float, default=None,
                     help="input GiB per GPU (default: 16 at N = 1 = config 2; 32 at N > 1 = config 4's 256 GiB over 8 GPUs)")
     ap.add_argument("--tile-mib", type=int, default=64, help="host-generated tile replicated on the device")
+    ap.add_argument("--first-record", type=int, default=0,
+                    help="FASTQ-like data: the first record id (default: nine-digit ids, offset per tile; 1 = rounds 1-4's data, identical tiles)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="only the headline config (profiling runs)")
     ap.add_argument("--data", default="fastq", choices=["fastq", "text", "random"],
@@ -326,6 +328,8 @@ class Bench:
             tile_bytes = tile_bytes // block * block      # whole blocks per tile: a compressed tile repeats too
         r = self.rank
         first = 100_000_000 * (1 + r)                     # nine digits up to 999,999,999: 8 ranks x 512 tiles x ~205 k records fit
+        if args.first_record:
+            first = args.first_record                     # (--first-record 1: rounds 1-4's data -- ids from 1, identical tiles)
         if kind == "fastq":
             tile_np = self.synth.fastq_like(tile_bytes, seed=1234 + r, first_record=first)
         elif kind == "text":
@@ -342,6 +346,8 @@ class Bench:
             tb = tile_np.tobytes()
             pos = np.array([m.start(1) for m in re.finditer(rb"@SRR000001\.(\d{9}) \d{9}/1\n", tb)], dtype=np.int64)
             nrec = len(pos)
+            if nrec == 0 and args.first_record:
+                return tile_np, data, reps                   # ids not nine digits wide: identical tiles, as rounds 1-4 had them
             assert nrec > tile_bytes // 400 and tb[pos[0]:pos[0] + 9] == b"%d" % first
             dpos = torch.from_numpy(pos).cuda()
             ids0 = torch.arange(nrec, device="cuda", dtype=torch.int64) + first
