@@ -80,6 +80,11 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
 #define HD_INF_OWNER 0       // 1: short matches copied by their own lanes (measured: 146 GB/s against 160 with the lane groups --
                              // sixteen ds_write_b8 per window and half cost the LDS path more than the vector units gained); 0: lane groups
 #endif
+#ifndef HD_INF_ONEPERM
+#define HD_INF_ONEPERM 0     // 1: a lane-group pass pushes its owners' words with ONE ds_permute when no lane owns a match in both halves
+                             // (round 5, measured: 159.8 / 164.7 / 115.9 GB/s against 161.6 / 166.7 / 117.3 -- the test and the second
+                             // code path cost more than the permute and its five vector instructions: profiles/r05_inflate_cuts.txt)
+#endif
 #ifndef HD_INF_DEFER
 #define HD_INF_DEFER 1       // 1: the first lane-group pass of a window stays open across the scalar copies
 #endif
@@ -715,14 +720,24 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &a, InfLdsT<RIN
 					const uint32_t slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(own0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own0, 0));
 					const uint32_t slot1 = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(own1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)own1, 0));
 					const uint32_t sub = lane & (G - 1), lead = (lane & ~(G - 1)) << 2;
+					const bool both = (own0 & own1) != 0;
 					for (uint32_t base = 0; base < nt; base += NG) {
 						// an owner whose slot falls into this pass targets the first lane of group (slot - base); everybody
 						// else an odd lane (never a group's first): what arrives there is not looked at
-						const uint32_t d0 = sel(own0, slot0 - base, NG), d1 = sel(own1, slot1 - base, NG);
-						const uint32_t a0 = d0 < NG ? d0 * (4 * G) : ((lane | 1u) << 2), a1 = d1 < NG ? d1 * (4 * G) : ((lane | 1u) << 2);
-						const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < NG ? pk0 : 0u));
-						const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < NG ? pk1 : 0u));
-						const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)(g0 | g1));
+						uint32_t gg;
+						if (HD_INF_ONEPERM && !both) {
+							// (no lane owns a match in both halves -- nine windows in ten: one push instead of two)
+							const uint32_t d = sel(own0, slot0 - base, sel(own1, slot1 - base, NG));
+							const uint32_t ad = d < NG ? d * (4 * G) : ((lane | 1u) << 2);
+							gg = (uint32_t)__builtin_amdgcn_ds_permute((int)ad, (int)(d < NG ? sel(own0, pk0, pk1) : 0u));
+						} else {
+							const uint32_t d0 = sel(own0, slot0 - base, NG), d1 = sel(own1, slot1 - base, NG);
+							const uint32_t a0 = d0 < NG ? d0 * (4 * G) : ((lane | 1u) << 2), a1 = d1 < NG ? d1 * (4 * G) : ((lane | 1u) << 2);
+							const uint32_t g0 = (uint32_t)__builtin_amdgcn_ds_permute((int)a0, (int)(d0 < NG ? pk0 : 0u));
+							const uint32_t g1 = (uint32_t)__builtin_amdgcn_ds_permute((int)a1, (int)(d1 < NG ? pk1 : 0u));
+							gg = g0 | g1;
+						}
+						const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lead, (int)gg);
 						const uint32_t ml = (w >> 10) & 31;                        // 0: no match in this group
 						const uint32_t dp = pos + (w & 1023) + sub, sp = dp - (w >> 15);
 						const bool act = sub < ml;
