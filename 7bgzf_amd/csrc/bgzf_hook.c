@@ -77,6 +77,7 @@ struct hook_eng {
 	int active;                  /* callers inside the engine right now (atomic) */
 	int running;                 /* blocks of the batches that are closed and not yet done (under mu) */
 	int inflight;                /* under mu; read without by a leader in its window */
+	int64_t t_returned;          /* when the last batch came back from the device (atomic; 0 = none yet) */
 	int failed;
 	int level, frame;            /* level: the hook's (BGZF_METHOD; a codec engine's is its index); frame: HD_FRAME_BGZF, HD_FRAME_RAW or HD_FRAME_RAW_FLUSH */
 	int loud;                    /* the hook prints codec errors as the reference does (bgzf_compress.c:163-169) */
@@ -88,10 +89,19 @@ static pthread_once_t g_env_once = PTHREAD_ONCE_INIT, g_knobs_once = PTHREAD_ONC
 static long g_window_us = 60; /* a leader never waits longer than this for the batch to fill */
 static long g_linger_us = 8;  /* ... nor longer than this after the last caller joined */
 static long g_spin_us = 400;  /* a member spins this long for its batch before it sleeps */
-/* batches on the device at once.  Two run side by side at the price of one (hipdeflate_lat_run on 8 blocks, level 2: 152 us
- * alone, 173 us each for two), a third and fourth do not (266, 297 us each -- tools/hook_bench.c HOOK_PAR): while two are out,
- * the collecting batch stays open and grows */
+/* batches on the device at once.  Two run side by side at nearly the price of one at levels 1-2 (hipdeflate_lat_run on 8
+ * blocks, level 2: 152 us alone, 173 us each for two), a third and fourth do not (266, 297 us each -- tools/hook_bench.c
+ * HOOK_PAR): while two are out, the collecting batch stays open and grows.
+ * Round 5: that is the limit for FULL batches (more callers than a batch holds).  A batch that is merely COMPLETE -- every
+ * caller that is not on the device has joined -- waits while another is out (g_merge_inflight) and then for that batch's
+ * callers to come back (g_rejoin_us): sixteen callers had settled into two groups of eight that took turns, each paying for
+ * the other's launch (level 6: two batches of 8 side by side 227-240 us each, one of 16 alone 186: a call 280 -> 215 us) */
 static int g_max_inflight = 2;
+static int g_merge_inflight = 1;
+static int g_merge_callers = 16;  /* ... while at most this many callers are inside the engine; beyond, batches fill by themselves and
+                                   * two side by side win (64 callers, level 6: 403 us a call against 520 merged; 4 / 8 callers:
+                                   * 233 -> 191 / 224 -> 209 us; 16: 257 -> 250; tools/r05_hook_merge.sh, profiles/r05_hook_merge.txt) */
+static long g_rejoin_us = 30; /* after a batch has come back, the collecting one waits this long for the first of its callers */
 static int g_batch_target = HOOK_MAX_BATCH;
 static int g_ncpu = 1;
 /* HIPDEFLATE_HOOK_STATS=1: where the time of a call goes, printed at exit (ns sums; tools/hook_bench.c reads it) */
@@ -233,6 +243,17 @@ static void parse_knobs(void)
 	const char *fl = getenv("HIPDEFLATE_INFLIGHT");
 	if (fl && atoi(fl) >= 1)
 		g_max_inflight = atoi(fl);
+	const char *mg = getenv("HIPDEFLATE_MERGE_INFLIGHT");
+	if (mg && atoi(mg) >= 1)
+		g_merge_inflight = atoi(mg);
+	if (g_merge_inflight > g_max_inflight)
+		g_merge_inflight = g_max_inflight;
+	const char *mc = getenv("HIPDEFLATE_MERGE_CALLERS");
+	if (mc && *mc)
+		g_merge_callers = atoi(mc);
+	const char *rj = getenv("HIPDEFLATE_REJOIN_US");
+	if (rj && *rj)
+		g_rejoin_us = atol(rj);
 	const char *sp = getenv("HIPDEFLATE_SPIN_US");
 	if (sp && *sp)
 		g_spin_us = atol(sp);
@@ -366,7 +387,7 @@ static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen
 	 * (callers released together by the previous batch come back within microseconds of each other, and count
 	 * as inside while they copy their members out).  Or the batch is full. */
 	const int want = __atomic_load_n(&e->active, __ATOMIC_RELAXED) - e->running;
-	if (b->n >= HOOK_MAX_BATCH || ((b->n >= g_batch_target || b->n >= want) && e->inflight < g_max_inflight)) {
+	if (b->n >= HOOK_MAX_BATCH || (b->n >= g_batch_target && e->inflight < g_max_inflight) || (b->n >= want && e->inflight < (want + e->running <= g_merge_callers ? g_merge_inflight : g_max_inflight))) {
 		__atomic_store_n(&b->state, 2, __ATOMIC_RELEASE);
 		e->running += b->n;
 		__atomic_add_fetch(&e->inflight, 1, __ATOMIC_RELAXED);
@@ -397,9 +418,13 @@ static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen
 					seen = cur;
 					t_last = t;
 				}
-				/* (while g_max_inflight batches are out the window stays open -- 2 ms at most, should one hang) */
-				const int full = __atomic_load_n(&e->inflight, __ATOMIC_RELAXED) >= g_max_inflight;
-				if ((t >= deadline || t - t_last >= g_linger_us * 1000) && (!full || t >= hard))
+				/* (while g_merge_inflight batches are out the window stays open -- 2 ms at most, should one hang --, and
+				 * when one has come back its callers get g_rejoin_us to show up, then the linger counts from join to join) */
+				const int full = __atomic_load_n(&e->inflight, __ATOMIC_RELAXED) >= (cur >= g_batch_target || __atomic_load_n(&e->active, __ATOMIC_RELAXED) > g_merge_callers ? g_max_inflight : g_merge_inflight);
+				const int64_t tr = __atomic_load_n(&e->t_returned, __ATOMIC_RELAXED);
+				const int64_t quiet = tr > t_last ? tr + g_rejoin_us * 1000 : t_last + g_linger_us * 1000;
+				const int64_t dl = tr > t0 && tr + g_window_us * 1000 > deadline ? tr + g_window_us * 1000 : deadline;
+				if ((t >= dl || t >= quiet) && (!full || t >= hard))
 					break;
 				/* with every device slot taken and more callers than CPUs, the leaders in flight and the HIP runtime's
 				 * thread need this CPU more than a spinning window does */
@@ -423,6 +448,7 @@ static int eng_compress(struct hook_eng *e, int level, void *_dst, size_t *_dlen
 			cpu_relax();
 		const int64_t t_ready = g_stats ? now_ns() : 0;
 		b->rc = hipdeflate_lat_run(b->lat, b->len, (uint32_t)n);
+		__atomic_store_n(&e->t_returned, now_ns(), __ATOMIC_RELAXED);
 		pthread_mutex_lock(&e->mu);
 		e->running -= n;
 		__atomic_sub_fetch(&e->inflight, 1, __ATOMIC_RELAXED);

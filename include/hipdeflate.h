@@ -318,8 +318,10 @@ uint64_t hipdeflate_scratch_bytes(uint32_t nblocks, uint32_t max_block, int leve
  * environment keeps writing.  There is no CPU codec behind any name.  Calls from concurrent htslib worker threads
  * are micro-batched into latency-mode launches on pinned memory: a batch closes when every caller inside the hook
  * has joined, when nobody has joined for HIPDEFLATE_LINGER_US (8), or after HIPDEFLATE_BATCH_US (60); at most
- * HIPDEFLATE_INFLIGHT (2) batches are on a device at once; batch contexts are spread over the device list.
- * (HIPDEFLATE_HOOK_FORM=throughput: levels >= 3 in their throughput form -- 5 % fewer bytes, 2.8 x the time per call; an experiment.) */
+ * HIPDEFLATE_INFLIGHT (2) batches are on a device at once; batch contexts are spread over the device list.  With up to
+ * HIPDEFLATE_MERGE_CALLERS (16) callers a batch that is merely complete waits for the batch on the device (HIPDEFLATE_MERGE_INFLIGHT, 1)
+ * and then up to HIPDEFLATE_REJOIN_US (30) for that batch's callers, so that a handful of callers share ONE launch instead of
+ * taking turns in two.  Every level has one form behind this call (HD_FRAME_LATENCY above). */
 int bgzf_compress(void *dst, size_t *dlen, const void *src, size_t slen, int level);
 
 /* device self-test of the wave primitives (scan, CRC folding); 0 = pass */
