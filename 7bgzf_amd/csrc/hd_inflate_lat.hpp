@@ -17,6 +17,9 @@ namespace hd {
 // PIPE (k_inflate_lat: two wavefronts per stream): the dump slots are their own bytes -- the front wavefront parses a block
 // header in cl / pre_lens while the back one still places the window before it -- and the records the front hands the back
 constexpr uint32_t INF_PQ = 4;               // window records in flight between the two wavefronts
+constexpr uint32_t INF_SPEC_POS = 2048;      // bit positions whose speculative decode is kept: 32 chunks of 64
+constexpr uint32_t INF_SPEC_CHUNKS = INF_SPEC_POS / 64;
+constexpr uint32_t INF_LAT_THREADS = 192;    // front, back, spec
 template <uint32_t RING>
 struct InfLdsPipeT {
 	uint32_t lit[1u << INF_LT_BITS];
@@ -36,6 +39,10 @@ struct InfLdsPipeT {
 	uint32_t q_head, q_tail;
 	uint32_t q_hdr[INF_PQ][16];
 	uint32_t q_lane[INF_PQ][3][64];
+	// spec -> front: one word per BIT POSITION of the stream (position mod INF_SPEC_POS), chunks of 64 positions; the words
+	// that count chunks and pass the tables between the two (inflate_stream_pipe)
+	uint32_t spec[INF_SPEC_POS];
+	uint32_t sp_head, sp_tail, sp_stop, sp_ack, sp_go, sp_start;
 };
 
 // the decoder, for an output ring of RING bytes (one wavefront; L is the workgroup's LDS).
@@ -52,9 +59,13 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 {
 	constexpr uint32_t INF_NEAR = RING - 258 - 64;       // dist <= this: source is in the ring
 	const uint32_t lane = threadIdx.x & 63;
-	const bool back = threadIdx.x >= 64;
-	if (threadIdx.x == 0)
+	const uint32_t role = threadIdx.x >> 6;              // 0 front, 1 back, 2 spec
+	const bool back = role == 1;
+	if (threadIdx.x == 0) {
 		L.q_head = L.q_tail = 0;
+		L.sp_head = L.sp_tail = L.sp_ack = L.sp_go = L.sp_start = 0;
+		L.sp_stop = 1;                                   // the spec wavefront starts halted: there are no tables yet (epoch 1 = the first header's)
+	}
 	__syncthreads();
 #ifdef HD_INFLATE_STATS
 	// experiment build (tools/exp_inflate_pipe_stats.py): a wavefront's cycles in all, and those it waited for the other one
@@ -195,8 +206,6 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	// either wholly in the ring (wend - src <= RING - 64) or wholly flushed to HBM
 	constexpr uint32_t WIN_OUT_BUDGET = 704;
 	const uint32_t dw_safe = (mis + n) >> 2;      // dwords below this are whole
-	uint32_t lds_p0 = 0xfffffff0u;                // pieces lds_p0, lds_p0 + 1 are in L.comp
-	uint32_t pre_piece = 0, pre_idx = 0xfffffff0u; // piece pre_idx of the stream, requested ahead of its use
 
 	// ---- the scalar path's writers (PIPE: the back wavefront's) -----------------------------------------------------------------
 	auto copy_stored = [&](uint32_t ip, uint32_t len) {
@@ -485,6 +494,112 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 		}
 	}
 
+	// ---- PIPE, round 5 (second half): the SPEC wavefront.  What a window's lanes decode -- the token that WOULD start at each bit
+	// -- depends on the stream and the tables only, not on where the real chain runs: a third wavefront decodes EVERY bit
+	// position of the stream, in chunks of 64 aligned to nothing but the stream itself, and leaves one word per position in an
+	// LDS ring { bits of the token | stop flag << 6 | length or literal << 7 | distance << 16 } (distance 0: not a match).  The
+	// front reads the 128 words under its window and walks; its two table gathers and ~60 vector instructions per window -- a
+	// third of the front's time per window (profiles/r05_inflate_pipe_stats.txt) -- run beside it, ahead of it.
+	// The tables are the front's (it parses the headers): sp_stop = E asks the spec wavefront to halt (it answers sp_ack = E
+	// and touches nothing), sp_go = E with sp_start = the first chunk restarts it on the new tables; 0xffffffff ends it.
+	typedef volatile __attribute__((address_space(3))) uint32_t *spec_word_p;
+	if (role == 2) {
+		const spec_word_p stopw = (spec_word_p)&L.sp_stop, gow = (spec_word_p)&L.sp_go, tailw = (spec_word_p)&L.sp_tail;
+		uint32_t epoch = 0, c = 0;
+		uint32_t s_p0 = 0xfffffff0u, s_pre = 0, s_pre_idx = 0xfffffff0u;
+		const uint32_t c_end = (((mis + n) >> 2) >> 1) + 2;           // chunks from here on lie behind the stream's last whole dwords
+		for (;;) {
+			const uint32_t want = uniform(*stopw);
+			if (want != epoch) {
+				if (want == 0xffffffffu)
+					return;
+				if (lane == 0)
+					*(spec_word_p)&L.sp_ack = want;
+				uint32_t g;
+				while ((g = uniform(*gow)) != want) {
+					if (uniform(*stopw) == 0xffffffffu)
+						return;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				asm volatile("" ::: "memory");
+				epoch = want;
+				c = uniform(*(spec_word_p)&L.sp_start);
+				s_p0 = 0xfffffff0u;
+				continue;
+			}
+			// the ring holds INF_SPEC_CHUNKS chunks from the front's (its window reaches into the two behind its own)
+			if (c + 2 > uniform(*tailw) + (INF_SPEC_CHUNKS - 2) || c >= c_end) {
+				__builtin_amdgcn_s_sleep(1);
+				continue;
+			}
+			const uint32_t d0 = 2 * c;                      // the pair (c, c + 1): 128 positions from bit 64 c, dword 2 c
+			const uint32_t p0 = d0 >> 6;
+			if (p0 != s_p0) {
+				if (p0 == s_p0 + 1)
+					L.comp[lane] = L.comp[64 + lane];
+				else
+					L.comp[lane] = load_piece(p0);
+				L.comp[64 + lane] = s_pre_idx == p0 + 1 ? s_pre : load_piece(p0 + 1);
+				s_pre = load_piece(p0 + 2);
+				s_pre_idx = p0 + 2;
+				s_p0 = p0;
+			}
+			const uint32_t *wsp = &L.comp[(d0 & 63) + (lane >> 5)];
+			const uint32_t ws0 = wsp[0], ws1 = wsp[1], ws2 = wsp[2], ws3 = wsp[3], ws4 = wsp[4];
+			auto spec_word = [&](uint32_t bl, uint32_t lo, uint32_t mid, uint32_t hi) -> uint32_t {   // bl = bit offset from dword d0
+				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
+				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
+				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
+				const uint32_t len1 = e & 15, eb = (e >> 4) & 15;
+				// (a literal's entry has no extra bits: the sum is the literal then)
+				const uint32_t lenlit = (e >> 16) + __builtin_amdgcn_ubfe(a, len1, eb);
+				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
+				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
+				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
+				const uint32_t ddm = (e & 0x300) == (K_LEN << 8) ? dd : 0u;
+				const uint32_t dlen = ddm & 15, deb = (ddm >> 4) & 15;
+				const uint32_t offset = (ddm >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
+				const uint32_t tokbits = t1 + dlen + deb;
+				// bit 6 = the walk stops in front of this token: bit 9 of either entry (K_EOB and K_SLOW have it) moved down
+				const uint32_t tb1 = tokbits ? tokbits : 1u;
+				return tb1 | ((e >> 3) & 64u) | ((ddm >> 3) & 64u) | ((lenlit & 511u) << 7) | (offset << 16);
+			};
+			const uint32_t w0 = spec_word(lane, ws0, ws1, ws2), w1 = spec_word(lane + 64, ws2, ws3, ws4);
+			L.spec[(64 * c + lane) & (INF_SPEC_POS - 1)] = w0;
+			L.spec[(64 * c + 64 + lane) & (INF_SPEC_POS - 1)] = w1;
+			asm volatile("" ::: "memory");
+			c += 2;
+			if (lane == 0)
+				*(spec_word_p)&L.sp_head = c;
+			asm volatile("" ::: "memory");
+		}
+	}
+	// the front's side of it
+	uint32_t sp_epoch = 0;
+	auto spec_halt = [&]() {
+		sp_epoch++;
+		if (lane == 0)
+			*(spec_word_p)&L.sp_stop = sp_epoch;
+		while (uniform(*(spec_word_p)&L.sp_ack) != sp_epoch)
+			__builtin_amdgcn_s_sleep(1);
+		asm volatile("" ::: "memory");
+	};
+	auto spec_go = [&]() {
+		const uint32_t c0 = (((dw << 5) - bc) >> 6) & ~1u;           // the (even) chunk under the block's first token
+		asm volatile("" ::: "memory");
+		if (lane == 0) {
+			*(spec_word_p)&L.sp_start = c0;
+			*(spec_word_p)&L.sp_head = c0;
+			*(spec_word_p)&L.sp_tail = c0;
+			*(spec_word_p)&L.sp_go = sp_epoch;
+		}
+		asm volatile("" ::: "memory");
+	};
+	auto spec_end = [&]() {
+		if (lane == 0)
+			*(spec_word_p)&L.sp_stop = 0xffffffffu;
+	};
+
 	auto run_windows = [&](int32_t &st_out) -> uint32_t {
 		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
 		uint32_t result = 0;
@@ -496,67 +611,33 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			const uint32_t budget = cap - pos < WIN_OUT_BUDGET ? cap - pos : WIN_OUT_BUDGET;
 			if (!(d0 + 7 <= dw_safe && budget != 0))
 				break;
-			// the stream bits come from an LDS copy of the pieces around d0 (every lane
-			// reads its own dwords: no scalar gather)
-			// (piece p0 always sits in comp[0,64) and p0 + 1 in comp[64,128): the five dwords under a lane's two
-			// decodes are consecutive and never wrap -- one address, three LDS reads for both)
+			// the tokens that would start at the window's 128 bit positions: the spec wavefront's words (above)
 			PIPE_P0();
-			const uint32_t p0 = d0 >> 6;
-			if (p0 != lds_p0) {
-				if (p0 == lds_p0 + 1)
-					L.comp[lane] = L.comp[64 + lane];
-				else
-					L.comp[lane] = load_piece(p0);
-				// the piece behind was requested when the last one was put in: its load has had ~16 windows to arrive
-				if (HD_INF_PREFETCH) {
-					L.comp[64 + lane] = pre_idx == p0 + 1 ? pre_piece : load_piece(p0 + 1);
-					pre_piece = load_piece(p0 + 2);
-					pre_idx = p0 + 2;
-				} else {
-					L.comp[64 + lane] = load_piece(p0 + 1);
-				}
-				lds_p0 = p0;
+			{
+				const spec_word_p headw = (spec_word_p)&L.sp_head;
+				const uint32_t need = (B + 127) >> 6;
+				while (uniform(*headw) <= need)
+					__builtin_amdgcn_s_sleep(0);
+				asm volatile("" ::: "memory");
 			}
-			// A window is 128 bits: every lane decodes the token that would start at bit
-			// B + lane ("lo") and the one at B + 64 + lane ("hi").  Twice the tokens per
-			// window halve the scalar glue per token, which is what bounds this kernel.
 			struct Spec {
-				uint32_t e, length, offset, outlen, walk;
-				uint64_t is_len, is_lit;             // lane masks (one v_cmp each, used through sel())
+				uint32_t length, offset, outlen, walk;   // length: a match's, or a literal's byte
+				uint64_t is_len, is_lit;             // lane masks
 			};
-			// dwords w[0..4] under bit (B & 31) + lane: the "lo" decode reads w[0..2], the "hi" one (64 bits on) w[2..4]
-			const uint32_t bl0 = (B & 31) + lane;
-			const uint32_t *wsp = &L.comp[(d0 & 63) + (bl0 >> 5)];
-			const uint32_t ws0 = wsp[0], ws1 = wsp[1], ws2 = wsp[2], ws3 = wsp[3], ws4 = wsp[4];
-			auto spec = [&](uint32_t bl, uint32_t lo, uint32_t mid, uint32_t hi) -> Spec {   // bl = bit offset from dword d0
-				Spec r;
-				const uint32_t a = __builtin_amdgcn_alignbit(mid, lo, bl & 31);
-				const uint32_t bq = __builtin_amdgcn_alignbit(hi, mid, bl & 31);
-				const uint32_t e = L.lit[a & ((1u << INF_LT_BITS) - 1)];
-				const uint32_t len1 = e & 15, eb = (e >> 4) & 15;
-				r.e = e;
-				r.length = (e >> 16) + __builtin_amdgcn_ubfe(a, len1, eb);         // (one v_bfe_u32; width 0 gives 0)
-				const uint32_t t1 = len1 + eb;                 // <= 9 + 5
-				const uint32_t rest = __builtin_amdgcn_alignbit(bq, a, t1);
-				const uint32_t dd = L.off[rest & ((1u << INF_DT_BITS) - 1)];
-				const uint32_t kind2 = e & 0x300;
-				r.is_len = __ballot(kind2 == (K_LEN << 8));
-				r.is_lit = __ballot(kind2 == (K_LIT << 8));
-				// (the offset entry counts for a length only: masked here, its fields are zero elsewhere -- and so is
-				// eb in a literal's or an end-of-block's entry, so the token's bits are one sum)
-				const uint32_t ddm = sel(r.is_len, dd, 0u);
-				const uint32_t dlen = ddm & 15, deb = (ddm >> 4) & 15;
-				r.offset = (ddm >> 16) + __builtin_amdgcn_ubfe(rest, dlen, deb);
-				const uint32_t tokbits = t1 + dlen + deb;
-				r.outlen = sel(r.is_lit, 1u, sel(r.is_len, r.length, 0u));
-				// bit 6 = the walk stops in front of this token: bit 9 of either entry (K_EOB and K_SLOW have it)
-				// moved down.  (A zero-bit token cannot come out of a well-formed table; the max keeps the walk
-				// moving whatever the table holds.)
-				const uint32_t tb1 = tokbits ? tokbits : 1u;
-				r.walk = tb1 | ((e >> 3) & 64u) | ((ddm >> 3) & 64u);
-				return r;
-			};
-			const Spec s0 = spec(bl0, ws0, ws1, ws2), s1 = spec(bl0 + 64, ws2, ws3, ws4);
+			Spec s0, s1;
+			{
+				const uint32_t w0 = L.spec[(B + lane) & (INF_SPEC_POS - 1)], w1 = L.spec[(B + 64 + lane) & (INF_SPEC_POS - 1)];
+				asm volatile("" ::: "memory");
+				// (the words are in registers: the chunks in front of the window's are the spec wavefront's again)
+				if (lane == 0)
+					*(spec_word_p)&L.sp_tail = B >> 6;
+				s0.walk = w0 & 127u; s0.length = (w0 >> 7) & 511u; s0.offset = w0 >> 16;
+				s1.walk = w1 & 127u; s1.length = (w1 >> 7) & 511u; s1.offset = w1 >> 16;
+				s0.is_len = __ballot(s0.offset != 0); s0.is_lit = ~s0.is_len;    // (of the tokens the walk takes: it stops in front of the others)
+				s1.is_len = __ballot(s1.offset != 0); s1.is_lit = ~s1.is_len;
+				s0.outlen = sel(s0.is_len, s0.length, 1u);
+				s1.outlen = sel(s1.is_len, s1.length, 1u);
+			}
 
 			// The real chain from bit 0 of the window.  This walk is the hottest scalar
 			// code of the kernel (the CU has one scalar ALU) and the compiler spends ~20
@@ -566,7 +647,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			// the first token the window cannot take; that one goes to the scalar loop.
 			// (A lane select written by the SALU needs no wait states before v_readlane,
 			// only one written by the VALU does.)
-			PIPE_P(0);                                   // stream piece + speculative decode
+			PIPE_P(0);                                   // the wait for the spec wavefront's words, their fields
 			uint32_t b, wm;
 			uint64_t real0, real1;
 			asm volatile("s_mov_b32 %0, 0\n\t"
@@ -640,8 +721,8 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 				// the literals: they depend on nothing, and the ring is nobody's at these bytes until the record is out
 				// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
 				const uint64_t lit0 = real0 & s0.is_lit, lit1 = real1 & s1.is_lit;
-				L.ring[sel(lit0, opos0 & (RING - 1), RING + lane)] = (uint8_t)(s0.e >> 16);
-				L.ring[sel(lit1, opos1 & (RING - 1), RING + lane)] = (uint8_t)(s1.e >> 16);
+				L.ring[sel(lit0, opos0 & (RING - 1), RING + lane)] = (uint8_t)s0.length;
+				L.ring[sel(lit1, opos1 & (RING - 1), RING + lane)] = (uint8_t)s1.length;
 				// the matches, by the way the back wavefront copies them (hd_inflate.hpp's classes without the ring test:
 				// this ring holds every source).  "simple": source wholly in front of this window's output, at most 64 bytes
 				const uint64_t simple0 = match0 & __ballot(s0.offset >= rel0 + s0.length) & __ballot(s0.length <= 64);
@@ -697,7 +778,6 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 
 	for (;;) {
 		refill();
-		lds_p0 = 0xfffffff0u;                     // header parsing reuses the LDS behind L.comp
 		const uint32_t bfinal = (uint32_t)bb & 1;
 		const uint32_t btype = ((uint32_t)bb >> 1) & 3;
 		bb >>= 3;
@@ -724,6 +804,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			break;
 		} else {
 			uint32_t nlit = 288, noff = 32;
+			spec_halt();                              // the tables are about to change: the spec wavefront stands still
 			if (btype == 2) {
 				// ---- dynamic header: decompress_template.h:101-232 -------
 				refill();
@@ -796,6 +877,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			}
 
 			load_tables();
+			spec_go();                                // ... and starts on the new ones at the block's first token
 			// ---- symbol loop ----------------------------------------------
 			for (;;) {
 				{
@@ -861,6 +943,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	if (st == HD_OK && consumed_bits() > 8 * (int64_t)n)
 		st = HD_BAD_DATA;
 
+	spec_end();
 	pipe_push_small(PIPE_END, (uint32_t)st, 0);               // the back wavefront writes the tail and the verdict
 	PIPE_WFLUSH();
 }
@@ -868,7 +951,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 // latency form (hip_inflate / hip_inflate_flush: a handful of streams, callers waiting): the same decoder with the whole
 // DEFLATE window -- a whole BGZF block -- in LDS.  One wavefront alone on its CU cannot hide a load of flushed output
 // behind other waves; here it never issues one (a match reaches back 32 KiB at most, the ring holds 64).
-__global__ __launch_bounds__(128) void k_inflate_lat(InflateArgs a)
+__global__ __launch_bounds__(INF_LAT_THREADS) void k_inflate_lat(InflateArgs a)
 {
 	__shared__ InfLdsPipeT<INF_RING_LAT> L;
 	inflate_stream_pipe<INF_RING_LAT, InfLdsPipeT<INF_RING_LAT>>(a, L);
