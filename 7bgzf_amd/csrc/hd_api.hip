@@ -281,8 +281,21 @@ int ctx_init(Ctx &g, int device)
 		return 0;
 	if (g.failed)
 		return g.failed;
+	// HIPDEFLATE_INIT_TRACE=1: where the start-up goes, one line on stderr (profiles/r05_startup.txt)
+	const bool trace = getenv("HIPDEFLATE_INIT_TRACE") != nullptr;
+	double ts[8];
+	int nts = 0;
+	auto stamp = [&]() {
+		if (trace && nts < 8) {
+			struct timespec t;
+			clock_gettime(CLOCK_MONOTONIC, &t);
+			ts[nts++] = t.tv_sec * 1e3 + t.tv_nsec / 1e6;
+		}
+	};
+	stamp();
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
+	stamp();
 	if (e != hipSuccess || ndev == 0) {
 		fprintf(stderr, "hipdeflate: no HIP device (%s); there is no CPU fallback\n",
 			e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -304,14 +317,18 @@ int ctx_init(Ctx &g, int device)
 			prop.gcnArchName);
 		return g.failed = HD_E_NODEVICE;
 	}
+	stamp();
 	HD_CHECK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+	stamp();
 	CrcTables *h = (CrcTables *)malloc(sizeof(CrcTables));
 	build_crc_tables(h);
+	stamp();
 	HD_CHECK(hipMalloc((void **)&g.d_ct, sizeof(CrcTables)));
 	HD_CHECK(hipMemcpy(g.d_ct, h, sizeof(CrcTables), hipMemcpyHostToDevice));
 	free(h);
 	HD_CHECK(hipMalloc((void **)&g.d_stalls, 16));
 	HD_CHECK(hipMemset(g.d_stalls, 0, 16));
+	stamp();
 	// Several lanes' ds_write_b16 to one table entry in one instruction: the highest lane's data must stay (the parse
 	// kernels and their CPU twin lean on it, hd_deflate_static.hpp fetch()).  Probed once per context: on a device
 	// that arbitrates differently the streams would still be valid DEFLATE but not the twin's bytes, and ranks of one
@@ -327,6 +344,11 @@ int ctx_init(Ctx &g, int device)
 		g.stream = nullptr;
 		return g.failed = HD_E_NODEVICE;
 	}
+	stamp();
+	if (trace && nts == 7)
+		fprintf(stderr, "hipdeflate init (ms): runtime + device count %.1f, set device + properties %.1f, stream %.1f, CRC tables on the CPU %.1f, "
+			"first allocations + copy %.1f, first kernel (code object load + LDS order probe) %.1f; total %.1f\n",
+			ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[6] - ts[0]);
 	g.device = device;
 	snprintf(g.desc, sizeof(g.desc), "hipdeflate 0.2 on device %d: %s (%s), %d CUs, %.0f GiB", device, prop.name,
 		 prop.gcnArchName, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
@@ -1756,11 +1778,13 @@ int g_inf_active = 0, g_inf_running = 0;                      // callers inside 
 int g_inf_inflight = 0, g_inf_max_inflight = 2;               // closed batches not yet done / HIPDEFLATE_INFLATE_INFLIGHT
 long g_inf_window_ns = 400000, g_inf_linger_ns = 60000;       // HIPDEFLATE_INFLATE_WINDOW_US / _LINGER_US
 int g_inf_failed = 0;
-// "Everybody who is inside has joined" closes a batch only once it holds as many streams as the last batch that was closed
-// by the LINGER time did: the reference creates its -@N threads one after the other (applet/7bgzf.c:330-345), tens of
-// microseconds apart, and a batch that closes as soon as it is complete goes out with the first one or two of them -- sixteen
-// streams became five launches of 1.5 ms, one behind the other.  A lone caller pays the linger time once.
-int g_inf_expect = 0x7fffffff;
+// "Everybody who is inside has joined" is not enough to close a batch: the reference creates its -@N threads one after the
+// other (applet/7bgzf.c:330-345), tens of microseconds apart, and a batch that closes as soon as everybody INSIDE has joined
+// goes out with the first few of them -- `7bgzf -d -@16` ran 180 launches of 4..8 streams for 1030 blocks, two side by side,
+// where 65 launches of 16 do (profiles/r05_dec_trace.txt).  g_inf_peak remembers how many callers have been inside at once:
+// a batch is complete when it holds max(inside now, that peak) less those on the device; a batch the LINGER time closes
+// short of it takes the peak down a quarter at a time (callers have gone).  A lone caller never waits.
+int g_inf_peak = 0;
 // A batch is ~1.5 ms on the device whatever it holds (one wavefront per stream, the chip is empty), and the device runs two
 // launches side by side but hardly a third (measured on the latency contexts, DESIGN "Hook": 152 us alone, 173 us each for
 // two, 266+ for three): so at most two batches are out, and while they are the collecting batch stays open and grows.
@@ -1909,7 +1933,10 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	b->out_used += out_need;
 	__atomic_store_n(&b->n, idx + 1, __ATOMIC_RELAXED);
 	// everybody who could join has: the callers inside that are not in a closed batch are all here (or the batch is full)
-	if (b->n >= (int)INFB_SLOTS || (b->n >= g_inf_active - g_inf_running && b->n >= g_inf_expect && g_inf_inflight < g_inf_max_inflight)) {
+	int peak = __atomic_load_n(&g_inf_peak, __ATOMIC_RELAXED);
+	if (g_inf_active > peak)
+		__atomic_store_n(&g_inf_peak, peak = g_inf_active, __ATOMIC_RELAXED);
+	if (b->n >= (int)INFB_SLOTS || (b->n >= peak - g_inf_running && g_inf_inflight < g_inf_max_inflight)) {
 		__atomic_store_n(&b->state, 2u, __ATOMIC_RELEASE);
 		g_inf_running += b->n;
 		g_inf_inflight++;
@@ -1938,12 +1965,12 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 				const bool slot = __atomic_load_n(&g_inf_inflight, __ATOMIC_RELAXED) < g_inf_max_inflight;
 				// complete (every caller that is inside and not on the device has joined), or nobody came for the linger
 				// time, or the window is over -- and a launch slot is free (20 ms at most, should a batch hang)
-				const bool complete = now_n >= __atomic_load_n(&g_inf_active, __ATOMIC_RELAXED) - __atomic_load_n(&g_inf_running, __ATOMIC_RELAXED) &&
-						      now_n >= __atomic_load_n(&g_inf_expect, __ATOMIC_RELAXED);
+				const int running = __atomic_load_n(&g_inf_running, __ATOMIC_RELAXED), peak = __atomic_load_n(&g_inf_peak, __ATOMIC_RELAXED);
+				const bool complete = now_n >= std::max(__atomic_load_n(&g_inf_active, __ATOMIC_RELAXED), peak) - running;
 				const bool lingered = t >= deadline || t - t_last >= g_inf_linger_ns;
 				if (((complete || lingered) && slot) || t >= hard) {
-					if (lingered && slot)
-						__atomic_store_n(&g_inf_expect, now_n, __ATOMIC_RELAXED);    // what a batch of these callers holds
+					if (!complete && lingered && slot)       // callers have gone: the peak comes down, a quarter at a time
+						__atomic_store_n(&g_inf_peak, std::max(now_n + running, peak - std::max(1, peak / 4)), __ATOMIC_RELAXED);
 					break;
 				}
 				if (!slot && (++spins & 15) == 0)
