@@ -37,7 +37,7 @@ struct InfLdsPipeT {
 	uint32_t comp[128];
 	// front -> back: head / tail count records; hdr: { type, pos | x, cum | y, four lane masks }; per lane three dwords
 	uint32_t q_head, q_tail;
-	uint32_t q_hdr[INF_PQ][16];
+	uint32_t q_hdr[INF_PQ][12];             // (eleven words used; the struct stays within half a CU's LDS: tests/test_abi.py)
 	uint32_t q_lane[INF_PQ][3][64];
 	// spec -> front: one word per BIT POSITION of the stream (position mod INF_SPEC_POS), chunks of 64 positions; the words
 	// that count chunks and pass the tables between the two (inflate_stream_pipe)
@@ -460,7 +460,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 					W.pos = x;
 					W.cum = y;
 					// (the header's words in one load: word j in lane j)
-					const uint32_t hv = L.q_hdr[k][lane & 15];
+					const uint32_t hv = L.q_hdr[k][lane < 11 ? lane : 0];
 					W.simple0 = ((uint64_t)readlane(hv, 4) << 32) | readlane(hv, 3);
 					W.simple1 = ((uint64_t)readlane(hv, 6) << 32) | readlane(hv, 5);
 					W.g0 = ((uint64_t)readlane(hv, 8) << 32) | readlane(hv, 7);

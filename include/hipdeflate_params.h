@@ -14,13 +14,12 @@
  *   0      stored blocks only          (store_deflate, lib/zlibutil.c:302)
  *   1      greedy parse, static Huffman (BASELINE config 2, "level-1-like"), one wavefront's 4 KiB window
  *   2      greedy parse, dynamic Huffman, the same window (fast on DNA-like data)
- *   3..9   THROUGHPUT FORM (batches): the workgroup parse -- a 32 KiB window and a 64 KiB multi-way table shared by the
- *          sixteen wavefronts of a workgroup, block splitting ("WORKGROUP LEVELS" below; config 5, "level-6-like"):
- *          3 one way greedy, 4 one way lazy, 5 two ways, 6..9 four ways
- *   3..9   LATENCY FORM (one block per call, the hook; HD_FRAME_LATENCY): the one-wavefront geometries below, parsed in
- *          parts -- 3..4 greedy / lazy in an 8 KiB window, 5 lazy with a one-way table, 6..9 a six-byte key and two
- *          positions per bucket in the same 8 KiB geometry (the HD_L7.. / HD_L9.. sets are rounds 2-3's throughput levels,
- *          kept for the experiment builds)
+ *   3..9   the workgroup parse -- a 32 KiB window and a 64 KiB multi-way table shared by the sixteen wavefronts of a
+ *          workgroup, block splitting ("WORKGROUP LEVELS" below; config 5, "level-6-like"): 3 one way greedy, 4 one way
+ *          lazy, 5 two ways, 6..9 four ways (7..9 = 6: the plateau is measured).  ONE codec per level since
+ *          round 5: HD_FRAME_LATENCY (one block per call, the hook) changes the schedule of these levels -- more
+ *          wavefronts on one block -- not their bytes.  Levels 1..2 keep a latency FORM of their own (segments, parts:
+ *          HD_LAT_* below).
  */
 #ifndef HIPDEFLATE_PARAMS_H
 #define HIPDEFLATE_PARAMS_H
@@ -43,35 +42,8 @@
 #define HD_L2_WIN_BITS     12
 #define HD_L2_HASH_BITS    11
 #define HD_L2_MIN_LEN      4
-/* level 3: the same with an 8 KiB ring; tokens buffered in a per-wave scratch slab in HBM
- * between the parse and the emit pass */
-#define HD_L3_WIN_BITS     13
-#define HD_L3_HASH_BITS    11
-#define HD_L3_MIN_LEN      4
-/* level 4: level 3's geometry (11 parse waves per CU) with the lazy rule of the higher levels:
- * one-lane lookahead, minimum length 5 */
-#define HD_L4_WIN_BITS     13
-#define HD_L4_HASH_BITS    11
-#define HD_L4_MIN_LEN      5
-/* levels 5..6: lazy parse, dynamic Huffman, 8 KiB ring; level 5: 2560 one-way entries (10 parse waves per CU),
- * level 6: 2560 two-way buckets (8 waves) */
-#define HD_L5_WIN_BITS     13
-#define HD_L5_HASH_BITS    12
-#define HD_L5_MIN_LEN      5
-/* level 7: level 6's parse with a 16 KiB ring (5 parse waves per CU); level 8: the same with 4096 buckets (4 waves: round 2-3's
- * level 9) */
-#define HD_L7_WIN_BITS     14
-#define HD_L7_HASH_BITS    12
-#define HD_L7_MIN_LEN      5
-#define HD_L8_WIN_BITS     14
-#define HD_L8_HASH_BITS    13
-#define HD_L8_MIN_LEN      5
-/* level 9: the reference's window -- a 32 KiB ring -- and 6144 two-way buckets: 57 KiB of LDS, 2 waves per CU, about half of
- * level 7's speed for 2 % fewer bytes on text (16 KiB ring + 4096 buckets, rounds 2-3: 0.4135 -> 0.4057 on 0xff00-byte text
- * blocks, 0.3845 -> 0.3771 on 1 MiB ones; FASTQ-like unchanged: DNA repeats are nearer than 16 KiB or much farther than 32) */
-#define HD_L9_WIN_BITS     15
-#define HD_L9_HASH_BITS    13
-#define HD_L9_MIN_LEN      5
+/* (rounds 1-4 had one-wavefront geometries for levels 3..9 here -- 8 / 16 / 32 KiB rings, one- and two-way tables: HD_L3.. / HD_L9..;
+ * round 5 removed them with the last kernels that used them: those levels are the workgroup parse in every form, docs/rounds.md) */
 
 /* Hash of the four bytes v -> table slot, in 24-bit multiplies (full rate on CDNA; a 32-bit v_mul_lo is
  * quarter rate) and scaled to ANY table size without a power-of-two step:
@@ -119,7 +91,7 @@
 #define HD_TABLE_58(win_bits, hash_bits)      ((win_bits) == 13 && (hash_bits) == 12)
 #define HD_TABLE_ENTRIES(win_bits, hash_bits) (HD_TABLE_34(win_bits, hash_bits) ? (3u << ((hash_bits) - 2)) : HD_TABLE_58(win_bits, hash_bits) ? 2560u : (1u << (hash_bits)))
 
-/* WORKGROUP LEVELS (6..9 in the throughput form; the latency form of these levels keeps the two-way tables above): ONE
+/* WORKGROUP LEVELS (3..9, every form): ONE
  * WORKGROUP of HD_WG_WAVES wavefronts per block shares one window and one table in LDS (hd_deflate_wg.hpp) -- the role of
  * hc_matchfinder (lib/libdeflate/hc_matchfinder.h:183-338) and of deflate_compress_lazy_generic (deflate_compress.c:2606-2809)
  * with what a whole CU's LDS holds instead of one wavefront's share of it:
