@@ -2007,7 +2007,7 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 				a.crc = nullptr;
 				a.ct = cur().d_ct;
 				a.flags = b->flags;
-				hipLaunchKernelGGL(hd::k_inflate_lat, dim3((uint32_t)n), dim3(hd::INF_LAT_THREADS), 0, b->st, a);      // (three wavefronts per stream: hd_inflate_lat.hpp)
+				hipLaunchKernelGGL(hd::k_inflate_lat, dim3((uint32_t)n), dim3(hd::INF_LAT_THREADS), 0, b->st, a);      // (four wavefronts per stream: hd_inflate_lat.hpp)
 				if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->st) != hipSuccess) {
 					fprintf(stderr, "hipdeflate: hip_inflate: the latency kernel did not run\n");
 					rc = HD_E_NODEVICE;

@@ -1,25 +1,31 @@
 // hd_inflate_lat.hpp -- the LATENCY form of the decoder (hip_inflate / hip_inflate_flush: one stream per call, the callers
-// waiting -- lib/zlibutil.c:194-204 as applet/7bgzf.c:330-345 calls it, a thread per block): TWO wavefronts per stream.
+// waiting -- lib/zlibutil.c:194-204 as applet/7bgzf.c:330-345 calls it, a thread per block): FOUR wavefronts per stream.
 //
 // The same decoder as hd_inflate.hpp's inflate_stream -- same tables, same windows, same scalar path, the same verdicts -- with
-// its statements dealt to two wavefronts: the one that FINDS the tokens and the one that PLACES them (the comment at
-// inflate_stream_pipe).  It is a copy of that function, restructured, and not a template parameter of it: the throughput kernel
-// is bound by vector issue at six wavefronts per SIMD, three registers below the step that costs one, and the same restructure
-// applied to it in place -- placement behind a lambda, then inline again with only the scalar writers and the tail as lambdas --
-// cost it 6 % and 4 % on one box (profiles/r05_inflate_ab.txt).  And this copy is free to be what the latency kernel wants: its
-// ring holds the whole window of DEFLATE, so the "far" paths (sources that left the ring) are gone; the front wavefront stores
-// the literals and sorts the matches, the back one only copies.
+// its statements dealt to four wavefronts of one workgroup, each on a SIMD of its own (the comments at inflate_stream_pipe):
+//   spec   decodes the token that WOULD start at every bit position of the stream, ahead of everybody (an LDS ring of words)
+//   front  owns the bit reader, the headers and tables, every verdict: reads the words under its window, walks the real chain,
+//          sums the output positions -- what decides where the next window starts -- and hands the rest over
+//   sort   stores the window's literals, sorts its matches by the way they are copied, writes the record
+//   back   copies the matches, flushes the ring, folds the CRC, writes the verdict
+// It is a copy of that function, restructured, and not a template parameter of it: the throughput kernel is bound by vector
+// issue at six wavefronts per SIMD, three registers below the step that costs one, and the same restructure applied to it in
+// place -- placement behind a lambda, then inline again with only the scalar writers and the tail as lambdas -- cost it 6 % and
+// 4 % on one box (profiles/r05_inflate_ab.txt).  And this copy is free to be what the latency kernel wants: its ring holds the
+// whole window of DEFLATE, so the "far" paths (sources that left the ring) are gone.  A lone call of a 0xff00-byte block:
+// 1.56 ms as one wavefront (round 4), 1.12 as front + back, 1.00 with spec, 0.86 with sort.
 #pragma once
 #include "hd_inflate.hpp"
 
 namespace hd {
 
-// PIPE (k_inflate_lat: two wavefronts per stream): the dump slots are their own bytes -- the front wavefront parses a block
+// PIPE (k_inflate_lat): the dump slots are their own bytes -- the front wavefront parses a block
 // header in cl / pre_lens while the back one still places the window before it -- and the records the front hands the back
-constexpr uint32_t INF_PQ = 4;               // window records in flight between the two wavefronts
+constexpr uint32_t INF_PQ = 4;               // window records in flight between the sort and the back wavefront
 constexpr uint32_t INF_SPEC_POS = 2048;      // bit positions whose speculative decode is kept: 32 chunks of 64
 constexpr uint32_t INF_SPEC_CHUNKS = INF_SPEC_POS / 64;
-constexpr uint32_t INF_LAT_THREADS = 192;    // front, back, spec
+constexpr uint32_t INF_LAT_THREADS = 256;    // front, back, spec, sort
+constexpr uint32_t INF_FQ = 4;               // windows in flight between the front and the sort wavefront
 template <uint32_t RING>
 struct InfLdsPipeT {
 	uint32_t lit[1u << INF_LT_BITS];
@@ -43,10 +49,13 @@ struct InfLdsPipeT {
 	// that count chunks and pass the tables between the two (inflate_stream_pipe)
 	uint32_t spec[INF_SPEC_POS];
 	uint32_t sp_head, sp_tail, sp_stop, sp_ack, sp_go, sp_start;
+	// front -> sort: { type, x, y, B, the two masks of the tokens the walk took }
+	uint32_t fq_head, fq_tail;
+	uint32_t fq_hdr[INF_FQ][8];
 };
 
 // the decoder, for an output ring of RING bytes (one wavefront; L is the workgroup's LDS).
-// PIPE (the latency kernel): TWO wavefronts per stream.  One wavefront's decode of a stream is a chain of latencies -- table
+// PIPE (the latency kernel), first step: TWO wavefronts per stream (spec and sort came later, below).  One wavefront's decode of a stream is a chain of latencies -- table
 // gathers, the scalar walk, LDS permutes, ring round trips: 1.55 ms for a 0xff00-byte block however empty the chip -- of which
 // the part that FINDS the tokens (speculative decode, walk, prefix sum, the checks) needs nothing of the part that PLACES them
 // (literals, lane-group copies, match copies, flush, CRC).  So the front wavefront (threads 0..63) owns the bit reader, the
@@ -59,10 +68,11 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 {
 	constexpr uint32_t INF_NEAR = RING - 258 - 64;       // dist <= this: source is in the ring
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t role = threadIdx.x >> 6;              // 0 front, 1 back, 2 spec
+	const uint32_t role = threadIdx.x >> 6;              // 0 front, 1 back, 2 spec, 3 sort
 	const bool back = role == 1;
 	if (threadIdx.x == 0) {
 		L.q_head = L.q_tail = 0;
+		L.fq_head = L.fq_tail = 0;
 		L.sp_head = L.sp_tail = L.sp_ack = L.sp_go = L.sp_start = 0;
 		L.sp_stop = 1;                                   // the spec wavefront starts halted: there are no tables yet (epoch 1 = the first header's)
 	}
@@ -357,7 +367,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 		(void)wend;
 	};
 
-	// ---- PIPE: the records between the two wavefronts.  The LDS executes a wavefront's instructions in order, so the store of
+	// ---- PIPE: the records to the back wavefront.  The LDS executes a wavefront's instructions in order, so the store of
 	// q_head behind a record's stores publishes the record (the protocol of k_parse_wg's turns, hd_deflate_wg.hpp) ----------
 	typedef volatile __attribute__((address_space(3))) uint32_t *pipe_word_p;
 	uint32_t q_n = 0;                         // records this wavefront has pushed (front) / popped (back)
@@ -575,8 +585,13 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 		}
 	}
 	// the front's side of it
+	uint32_t fq_n = 0;                        // records the front has pushed to / the sort wavefront has popped from the queue between them (below)
 	uint32_t sp_epoch = 0;
 	auto spec_halt = [&]() {
+		// (the sort wavefront reads the OLD block's last words from the ring: it has to be through them before the spec
+		// wavefront is restarted on the chunk under the new block's first token, which may hold them)
+		while (uniform(*(spec_word_p)&L.fq_tail) != fq_n)
+			__builtin_amdgcn_s_sleep(1);
 		sp_epoch++;
 		if (lane == 0)
 			*(spec_word_p)&L.sp_stop = sp_epoch;
@@ -599,6 +614,88 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 		if (lane == 0)
 			*(spec_word_p)&L.sp_stop = 0xffffffffu;
 	};
+
+	// ---- PIPE, round 5 (third part): the SORT wavefront.  Of what the front did per window after the walk -- prefix sum, budget,
+	// distance check, the literals' stores, the matches' classes, the record for the back -- only the first three decide where
+	// the NEXT window starts and what the verdict is.  The rest goes to a fourth wavefront: the front hands it { B, the masks of
+	// the tokens the walk took, the window's first output byte and its length }, it reads the same words of the spec ring (so
+	// the ring's tail is ITS position now), repeats the prefix sum, stores the literals, sorts the matches and pushes the record
+	// the back wavefront copies from.  Scalar-path records (a literal, a match, a stored block, the end) pass through it in order.
+	auto fq_push = [&](uint32_t type, uint32_t x, uint32_t y, uint32_t Bw, uint64_t r0, uint64_t r1) {
+		const pipe_word_p tail = (pipe_word_p)&L.fq_tail;
+		PIPE_W0(t_wait);
+		while (fq_n - uniform(*tail) >= INF_FQ)
+			__builtin_amdgcn_s_sleep(0);
+		PIPE_W1(t_wait);
+		const uint32_t hw[8] = { type, x, y, Bw, (uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32) };
+		uint32_t v = 0;
+#pragma unroll
+		for (uint32_t j = 0; j < 8; j++)
+			v = lane == j ? hw[j] : v;
+		if (lane < 8)
+			L.fq_hdr[fq_n % INF_FQ][lane] = v;
+		asm volatile("" ::: "memory");
+		fq_n++;
+		if (lane == 0)
+			*(pipe_word_p)&L.fq_head = fq_n;
+		asm volatile("" ::: "memory");
+	};
+	if (role == 3) {
+		const pipe_word_p head = (pipe_word_p)&L.fq_head;
+		for (;;) {
+			while (uniform(*head) == fq_n)
+				__builtin_amdgcn_s_sleep(0);
+			asm volatile("" ::: "memory");
+			const uint32_t hv = L.fq_hdr[fq_n % INF_FQ][lane & 7];
+			const uint32_t type = readlane(hv, 0), x = readlane(hv, 1), y = readlane(hv, 2), Bw = readlane(hv, 3);
+			const uint64_t real0 = ((uint64_t)readlane(hv, 5) << 32) | readlane(hv, 4), real1 = ((uint64_t)readlane(hv, 7) << 32) | readlane(hv, 6);
+			asm volatile("" ::: "memory");
+			fq_n++;
+			if (type != PIPE_WINDOW) {
+				if (lane == 0)
+					*(pipe_word_p)&L.fq_tail = fq_n;
+				asm volatile("" ::: "memory");
+				pipe_push_small(type, x, y);
+				if (type == PIPE_END)
+					return;
+				continue;
+			}
+			const uint32_t wpos = x, cum = y;
+			const uint32_t w0 = L.spec[(Bw + lane) & (INF_SPEC_POS - 1)], w1 = L.spec[(Bw + 64 + lane) & (INF_SPEC_POS - 1)];
+			asm volatile("" ::: "memory");
+			// (the words are in registers: the chunks in front of the window's are the spec wavefront's again -- and only now is
+			// the record "popped": the front waits for that before it lets the spec wavefront restart on new tables)
+			if (lane == 0) {
+				*(spec_word_p)&L.sp_tail = Bw >> 6;
+				*(pipe_word_p)&L.fq_tail = fq_n;
+			}
+			asm volatile("" ::: "memory");
+			const uint32_t len0 = (w0 >> 7) & 511u, off0 = w0 >> 16, len1 = (w1 >> 7) & 511u, off1 = w1 >> 16;
+			const uint64_t is_len0 = __ballot(off0 != 0), is_len1 = __ballot(off1 != 0);
+			const uint32_t outlen0 = sel(is_len0, len0, 1u), outlen1 = sel(is_len1, len1, 1u);
+			const uint32_t scn = wave_incl_scan(sel(real0, outlen0, 0u) | (sel(real1, outlen1, 0u) << 16));
+			const uint32_t tot = readlane(scn, 63);
+			const uint32_t rel0 = (scn & 0xffff) - outlen0, rel1 = (scn >> 16) + (tot & 0xffff) - outlen1;   // valid on the real tokens
+			const uint32_t opos0 = wpos + rel0, opos1 = wpos + rel1;
+			const uint64_t match0 = real0 & is_len0, match1 = real1 & is_len1;
+			// the literals: they depend on nothing, and the ring is nobody's at these bytes until the record is out
+			// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
+			const uint64_t lit0 = real0 & ~is_len0, lit1 = real1 & ~is_len1;
+			L.ring[sel(lit0, opos0 & (RING - 1), RING + lane)] = (uint8_t)len0;
+			L.ring[sel(lit1, opos1 & (RING - 1), RING + lane)] = (uint8_t)len1;
+			// the matches, by the way the back wavefront copies them (hd_inflate.hpp's classes without the ring test:
+			// this ring holds every source).  "simple": source wholly in front of this window's output, at most 64 bytes
+			const uint64_t simple0 = match0 & __ballot(off0 >= rel0 + len0) & __ballot(len0 <= 64);
+			const uint64_t simple1 = match1 & __ballot(off1 >= rel1 + len1) & __ballot(len1 <= 64);
+			WinRec W;
+			W.lo0 = len0 | (off0 << 16);
+			W.lo1 = len1 | (off1 << 16);
+			W.rel0 = rel0; W.rel1 = rel1; W.pos = wpos; W.cum = cum;
+			W.simple0 = simple0; W.simple1 = simple1;
+			W.g0 = match0 & ~simple0; W.g1 = match1 & ~simple1;
+			pipe_push_window(W);
+		}
+	}
 
 	auto run_windows = [&](int32_t &st_out) -> uint32_t {
 		uint32_t B = (dw << 5) - bc;              // absolute bit position from src32
@@ -628,9 +725,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			{
 				const uint32_t w0 = L.spec[(B + lane) & (INF_SPEC_POS - 1)], w1 = L.spec[(B + 64 + lane) & (INF_SPEC_POS - 1)];
 				asm volatile("" ::: "memory");
-				// (the words are in registers: the chunks in front of the window's are the spec wavefront's again)
-				if (lane == 0)
-					*(spec_word_p)&L.sp_tail = B >> 6;
+				// (the ring's tail is the sort wavefront's position: it reads these words after us)
 				s0.walk = w0 & 127u; s0.length = (w0 >> 7) & 511u; s0.offset = w0 >> 16;
 				s1.walk = w1 & 127u; s1.length = (w1 >> 7) & 511u; s1.offset = w1 >> 16;
 				s0.is_len = __ballot(s0.offset != 0); s0.is_lit = ~s0.is_len;    // (of the tokens the walk takes: it stops in front of the others)
@@ -705,37 +800,26 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			if (real0 == 0) {
 				break;                                     // the token at B is not for a window: scalar loop
 			}
-			const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid on the real tokens
 			{
-				// offset > bytes out so far: decompress_template.h:724
-				const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
-				const uint64_t match0 = real0 & s0.is_len, match1 = real1 & s1.is_len;
-				uint64_t far0, far1;
-				asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far0) : "v"(opos0), "v"(s0.offset));
-				asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far1) : "v"(opos1), "v"(s1.offset));
-				if ((far0 & match0) | (far1 & match1)) {
-					st_out = HD_BAD_DATA;
-					result = 2;
-					break;
+				// offset > bytes out so far: decompress_template.h:724.  (No distance is longer than 32768: once that much is
+				// out the test cannot fire, and half the windows of a 64 KiB block skip its dozen instructions)
+				if (pos < 32768u) {
+					const uint32_t rel0 = incl0 - s0.outlen, rel1 = incl1 - s1.outlen;   // valid on the real tokens
+					const uint32_t opos0 = pos + rel0, opos1 = pos + rel1;
+					const uint64_t match0 = real0 & s0.is_len, match1 = real1 & s1.is_len;
+					uint64_t far0, far1;
+					asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far0) : "v"(opos0), "v"(s0.offset));
+					asm("v_cmp_lt_u32 %0, %1, %2" : "=s"(far1) : "v"(opos1), "v"(s1.offset));
+					if ((far0 & match0) | (far1 & match1)) {
+						st_out = HD_BAD_DATA;
+						result = 2;
+						break;
+					}
 				}
-				// the literals: they depend on nothing, and the ring is nobody's at these bytes until the record is out
-				// (lanes without a literal write to their dump slot: no exec juggling, no skip branches)
-				const uint64_t lit0 = real0 & s0.is_lit, lit1 = real1 & s1.is_lit;
-				L.ring[sel(lit0, opos0 & (RING - 1), RING + lane)] = (uint8_t)s0.length;
-				L.ring[sel(lit1, opos1 & (RING - 1), RING + lane)] = (uint8_t)s1.length;
-				// the matches, by the way the back wavefront copies them (hd_inflate.hpp's classes without the ring test:
-				// this ring holds every source).  "simple": source wholly in front of this window's output, at most 64 bytes
-				const uint64_t simple0 = match0 & __ballot(s0.offset >= rel0 + s0.length) & __ballot(s0.length <= 64);
-				const uint64_t simple1 = match1 & __ballot(s1.offset >= rel1 + s1.length) & __ballot(s1.length <= 64);
-				WinRec W;
-				W.lo0 = s0.length | (s0.offset << 16);
-				W.lo1 = s1.length | (s1.offset << 16);
-				W.rel0 = rel0; W.rel1 = rel1; W.pos = pos; W.cum = cum;
-				W.simple0 = simple0; W.simple1 = simple1;
-				W.g0 = match0 & ~simple0; W.g1 = match1 & ~simple1;
-				PIPE_P(3);                                   // check, literals, classes
-				pipe_push_window(W);
-				PIPE_P(4);                                   // the record (and the wait for its slot)
+				PIPE_P(3);                                   // the distance check
+				// the literals' stores, the matches' classes and the record are the sort wavefront's (above)
+				fq_push(PIPE_WINDOW, pos, cum, B, real0, real1);
+				PIPE_P(4);                                   // the hand-over (and the wait for its slot)
 			}
 			pos += cum;
 			B += b;
@@ -796,7 +880,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			if (len != (~nlen & 0xffff)) { st = HD_BAD_DATA; break; }
 			if (len > cap - pos) { st = HD_INSUFFICIENT_SPACE; break; }
 			if (len > n - ip) { st = HD_BAD_DATA; break; }
-			pipe_push_small(PIPE_STORED, ip, len);
+			fq_push(PIPE_STORED, ip, len, 0, 0, 0);
 			pos += len;
 			seek_byte(ip + len);
 		} else if (btype == 3) {
@@ -901,7 +985,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 				const uint32_t kind = (e >> 8) & 3;
 				if (kind == K_LIT) {
 					if (pos == cap) { st = HD_INSUFFICIENT_SPACE; break; }
-					pipe_push_small(PIPE_LITERAL, e >> 16, 0);
+					fq_push(PIPE_LITERAL, e >> 16, 0, 0, 0, 0);
 					pos++;
 					continue;
 				}
@@ -928,7 +1012,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 				bc -= deb;
 				if (offset > pos) { st = HD_BAD_DATA; break; }
 
-				pipe_push_small(PIPE_MATCH, length, offset);
+				fq_push(PIPE_MATCH, length, offset, 0, 0, 0);
 				pos += length;
 			}
 			if (st != HD_OK)
@@ -944,7 +1028,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 		st = HD_BAD_DATA;
 
 	spec_end();
-	pipe_push_small(PIPE_END, (uint32_t)st, 0);               // the back wavefront writes the tail and the verdict
+	fq_push(PIPE_END, (uint32_t)st, 0, 0, 0, 0);                // (through the sort wavefront) the back wavefront writes the tail and the verdict
 	PIPE_WFLUSH();
 }
 

@@ -205,7 +205,9 @@ def test_kernel_resource_budgets():
     (v,) = inf.values()
     assert v["VGPRs"] <= 80 and v["LDS Size"] <= 6400, v         # five LDS units (25 per CU), 6 waves per SIMD: 24 waves per CU
     (v,) = inf_lat.values()
-    assert v["VGPRs"] <= 128 and v["LDS Size"] <= 81920, v       # the whole window in LDS; two workgroups per CU
+    # the whole window in LDS + the queues and the spec ring of its four wavefronts: ONE workgroup per CU (a stream wants the CU's
+    # four SIMDs for its four wavefronts; a batch holds at most 64 streams and two batches are out at once: 128 workgroups, 256 CUs)
+    assert v["VGPRs"] <= 128 and 81920 < v["LDS Size"] <= 98304, v
     # k_parse_wg<WAYS, LAZY> (levels 3 / 4 / 5 / 6..9): one workgroup of 16 wavefronts per CU: four per SIMD (<= 128 VGPRs),
     # ring + table + state within a CU's 160 KiB
     for k, v in wg.items():

@@ -19,4 +19,4 @@ for name, z in (("zlib6", zlib.compress(blk, 6)[2:-4]), ("own_level1", pkg.hip_d
     ph = [(int(x) - y) / reps for x, y in zip(c, c0)]
     print({"stream": name, "cycles_per_call": {"front": round(t[6]), "front waiting for a free record": round(w[6]),
                                                "back": round(t[7]), "back waiting for a record": round(w[7])},
-           "front_window_loop": dict(zip(["wait for the spec words + fields", "walk", "prefix sum + budget", "check + literals + classes", "record (+ slot wait)"], [round(x) for x in ph[:5]]))})
+           "front_window_loop": dict(zip(["wait for the spec words + fields", "walk", "prefix sum + budget", "distance check", "hand-over to the sort wavefront (+ slot wait)"], [round(x) for x in ph[:5]]))})
