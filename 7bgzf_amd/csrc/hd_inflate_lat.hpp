@@ -13,7 +13,7 @@
 // place -- placement behind a lambda, then inline again with only the scalar writers and the tail as lambdas -- cost it 6 % and
 // 4 % on one box (profiles/r05_inflate_ab.txt).  And this copy is free to be what the latency kernel wants: its ring holds the
 // whole window of DEFLATE, so the "far" paths (sources that left the ring) are gone.  A lone call of a 0xff00-byte block:
-// 1.56 ms as one wavefront (round 4), 1.12 as front + back, 1.00 with spec, 0.86 with sort.
+// 1.56 ms as one wavefront (round 4), 1.12 as front + back, 1.00 with spec, 0.86-0.90 with sort.
 #pragma once
 #include "hd_inflate.hpp"
 
@@ -25,6 +25,9 @@ constexpr uint32_t INF_PQ = 4;               // window records in flight between
 constexpr uint32_t INF_SPEC_POS = 2048;      // bit positions whose speculative decode is kept: 32 chunks of 64
 constexpr uint32_t INF_SPEC_CHUNKS = INF_SPEC_POS / 64;
 constexpr uint32_t INF_LAT_THREADS = 256;    // front, back, spec, sort
+constexpr uint32_t INF_LAT_SPINS = 1u << 24;  // polls of a wait between the wavefronts before the stream is given up (~0.2 s; a wait is microseconds):
+                                             // never a hang -- hip_inflate answers HD_BAD_DATA, and no test has seen it happen.  (The guards and
+                                             // the skipped distance check measured neutral on one box: 898-904 us a lone call either way)
 constexpr uint32_t INF_FQ = 4;               // windows in flight between the front and the sort wavefront
 template <uint32_t RING>
 struct InfLdsPipeT {
@@ -52,6 +55,7 @@ struct InfLdsPipeT {
 	// front -> sort: { type, x, y, B, the two masks of the tokens the walk took }
 	uint32_t fq_head, fq_tail;
 	uint32_t fq_hdr[INF_FQ][8];
+	uint32_t abort;                          // a wait between the wavefronts did not end (INF_LAT_SPINS): everybody leaves, the verdict is an error
 };
 
 // the decoder, for an output ring of RING bytes (one wavefront; L is the workgroup's LDS).
@@ -73,10 +77,27 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	if (threadIdx.x == 0) {
 		L.q_head = L.q_tail = 0;
 		L.fq_head = L.fq_tail = 0;
+		L.abort = 0;
 		L.sp_head = L.sp_tail = L.sp_ack = L.sp_go = L.sp_start = 0;
 		L.sp_stop = 1;                                   // the spec wavefront starts halted: there are no tables yet (epoch 1 = the first header's)
 	}
 	__syncthreads();
+	// every wait of one wavefront for another goes through this: `pending()` true = keep waiting
+	typedef volatile __attribute__((address_space(3))) uint32_t *lat_word_p;
+	auto lat_wait = [&](auto &&pending, uint32_t nap) {
+		for (uint32_t spins = 0; pending(); spins++) {
+			// (looked at every 256th poll: the polls themselves must stay as short as they were)
+			if ((spins & 255u) == 255u && (spins > INF_LAT_SPINS || uniform(*(lat_word_p)&L.abort))) {
+				if (lane == 0)
+					*(lat_word_p)&L.abort = 1;
+				break;
+			}
+			if (nap)
+				__builtin_amdgcn_s_sleep(1);
+			else
+				__builtin_amdgcn_s_sleep(0);
+		}
+	};
 #ifdef HD_INFLATE_STATS
 	// experiment build (tools/exp_inflate_pipe_stats.py): a wavefront's cycles in all, and those it waited for the other one
 	unsigned long long pipe_wait = 0;
@@ -374,8 +395,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	auto pipe_slot_wait = [&]() {             // front: a free slot
 		const pipe_word_p tail = (pipe_word_p)&L.q_tail;
 		PIPE_W0(t_wait);
-		while (q_n - uniform(*tail) >= INF_PQ)
-			__builtin_amdgcn_s_sleep(0);
+		lat_wait([&]() { return q_n - uniform(*tail) >= INF_PQ; }, 0);
 		PIPE_W1(t_wait);                      // (stats build: the front's cycles waiting for a free record)
 	
 	};
@@ -454,9 +474,12 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			const pipe_word_p head = (pipe_word_p)&L.q_head;
 			for (;;) {
 				PIPE_W0(t_wait);
-				while (uniform(*head) == q_n)
-					__builtin_amdgcn_s_sleep(0);
+				lat_wait([&]() { return uniform(*head) == q_n; }, 0);
 				PIPE_W1(t_wait);                  // (stats build: the back's cycles waiting for a record)
+				if (uniform(*(lat_word_p)&L.abort)) {
+					finish(HD_BAD_DATA);              // (a wait did not end: see INF_LAT_SPINS)
+					return;
+				}
 				asm volatile("" ::: "memory");
 				const uint32_t k = q_n % INF_PQ;
 				const uint32_t type = uniform(L.q_hdr[k][0]), x = uniform(L.q_hdr[k][1]), y = uniform(L.q_hdr[k][2]);
@@ -527,7 +550,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 					*(spec_word_p)&L.sp_ack = want;
 				uint32_t g;
 				while ((g = uniform(*gow)) != want) {
-					if (uniform(*stopw) == 0xffffffffu)
+					if (uniform(*stopw) == 0xffffffffu || uniform(*(lat_word_p)&L.abort))
 						return;
 					__builtin_amdgcn_s_sleep(1);
 				}
@@ -539,6 +562,8 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			}
 			// the ring holds INF_SPEC_CHUNKS chunks from the front's (its window reaches into the two behind its own)
 			if (c + 2 > uniform(*tailw) + (INF_SPEC_CHUNKS - 2) || c >= c_end) {
+				if (uniform(*(lat_word_p)&L.abort))
+					return;
 				__builtin_amdgcn_s_sleep(1);
 				continue;
 			}
@@ -590,13 +615,11 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	auto spec_halt = [&]() {
 		// (the sort wavefront reads the OLD block's last words from the ring: it has to be through them before the spec
 		// wavefront is restarted on the chunk under the new block's first token, which may hold them)
-		while (uniform(*(spec_word_p)&L.fq_tail) != fq_n)
-			__builtin_amdgcn_s_sleep(1);
+		lat_wait([&]() { return uniform(*(spec_word_p)&L.fq_tail) != fq_n; }, 1);
 		sp_epoch++;
 		if (lane == 0)
 			*(spec_word_p)&L.sp_stop = sp_epoch;
-		while (uniform(*(spec_word_p)&L.sp_ack) != sp_epoch)
-			__builtin_amdgcn_s_sleep(1);
+		lat_wait([&]() { return uniform(*(spec_word_p)&L.sp_ack) != sp_epoch; }, 1);
 		asm volatile("" ::: "memory");
 	};
 	auto spec_go = [&]() {
@@ -624,8 +647,7 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	auto fq_push = [&](uint32_t type, uint32_t x, uint32_t y, uint32_t Bw, uint64_t r0, uint64_t r1) {
 		const pipe_word_p tail = (pipe_word_p)&L.fq_tail;
 		PIPE_W0(t_wait);
-		while (fq_n - uniform(*tail) >= INF_FQ)
-			__builtin_amdgcn_s_sleep(0);
+		lat_wait([&]() { return fq_n - uniform(*tail) >= INF_FQ; }, 0);
 		PIPE_W1(t_wait);
 		const uint32_t hw[8] = { type, x, y, Bw, (uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32) };
 		uint32_t v = 0;
@@ -643,8 +665,9 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 	if (role == 3) {
 		const pipe_word_p head = (pipe_word_p)&L.fq_head;
 		for (;;) {
-			while (uniform(*head) == fq_n)
-				__builtin_amdgcn_s_sleep(0);
+			lat_wait([&]() { return uniform(*head) == fq_n; }, 0);
+			if (uniform(*(lat_word_p)&L.abort))
+				return;
 			asm volatile("" ::: "memory");
 			const uint32_t hv = L.fq_hdr[fq_n % INF_FQ][lane & 7];
 			const uint32_t type = readlane(hv, 0), x = readlane(hv, 1), y = readlane(hv, 2), Bw = readlane(hv, 3);
@@ -713,8 +736,21 @@ __device__ __forceinline__ void inflate_stream_pipe(const InflateArgs &a, LDS &L
 			{
 				const spec_word_p headw = (spec_word_p)&L.sp_head;
 				const uint32_t need = (B + 127) >> 6;
-				while (uniform(*headw) <= need)
+				for (uint32_t spins = 0; uniform(*headw) <= need; spins++) {
+					if ((spins & 255u) == 255u && (spins > INF_LAT_SPINS || uniform(*(lat_word_p)&L.abort))) {
+						if (lane == 0)
+							*(lat_word_p)&L.abort = 1;
+						break;
+					}
+					// The ring's tail is where the sort wavefront reads -- but a run of scalar-path tokens (long codewords,
+					// one after the other) moves B on with no window for it to read, and the spec wavefront, held back by
+					// a tail some thirty chunks behind B, would never get to the chunk this window needs.  With the sort
+					// wavefront through everything handed to it, nobody reads in front of B: the tail is ours to move.
+					// (looked at every 16th poll: an ordinary wait here is a few polls long)
+					if ((spins & 15u) == 15u && uniform(*(spec_word_p)&L.fq_tail) == fq_n && lane == 0)
+						*(spec_word_p)&L.sp_tail = B >> 6;
 					__builtin_amdgcn_s_sleep(0);
+				}
 				asm volatile("" ::: "memory");
 			}
 			struct Spec {

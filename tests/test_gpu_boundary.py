@@ -73,6 +73,31 @@ def test_hip_inflate_from_16_threads_gives_the_batch_decoders_verdicts(pkg):
         assert got[i][0] != 0 and hdtest.oracle_inflate(zs[i], caps[i])[0] != 0
 
 
+@pytest.mark.timeout(120)
+def test_hip_inflate_runs_of_long_codewords_between_windows(pkg):
+    """The per-call kernel's wavefronts talk through rings whose tails move with the WINDOWS (hd_inflate_lat.hpp): a run of
+    tokens that only the scalar path takes -- codewords longer than the direct table's 9 bits, one after the other -- moves the
+    bit position on with no window in between, and the spec wavefront must still reach the chunk the next window needs (round 5:
+    the tail is moved by the front when the sort wavefront is through; before that this stream hung the kernel).  Streams: four
+    frequent bytes and 250 bytes that occur once in a row (Huffman-only: every one of them a 13..15-bit literal), runs of them at
+    the start, in the middle, at the end and back to back; through hip_inflate (a lone call and 8 threads) and the batch decoder."""
+    rare = bytes(range(5, 255))
+    body = b"abcd" * 6000
+    cases = [body + rare + body, rare + body, body + rare, body + rare + rare[::-1] + rare + body, rare * 3,
+             body[:999] + rare + body[:57] + rare[::-1] + body[:3] + rare + body]
+    zs = []
+    for d in cases:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        zs.append(co.compress(d) + co.flush())
+    for d, z in zip(cases, zs):
+        r, out = pkg.hip_inflate(z, len(d))
+        assert r == 0 and out == d
+        assert pkg.batch_inflate([z], [len(d)])[0][0] == d
+    with ThreadPoolExecutor(8) as ex:
+        for k, (r, out) in enumerate(ex.map(lambda k: pkg.hip_inflate(zs[k % len(zs)], len(cases[k % len(zs)])), range(64))):
+            assert r == 0 and out == cases[k % len(zs)]
+
+
 def test_hip_inflate_threads_full_blocks_flush_form_and_oversize(pkg):
     """64 threads x full 0xff00-byte blocks (zlib 1/6/9, our levels 1 and 6), the flush form side by side with the final
     form (separate batches), one byte of room less (3 = INSUFFICIENT_SPACE), and a 1 MiB member that is larger than a
