@@ -85,6 +85,11 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
                              // (round 5, measured: 159.8 / 164.7 / 115.9 GB/s against 161.6 / 166.7 / 117.3 -- the test and the second
                              // code path cost more than the permute and its five vector instructions: profiles/r05_inflate_cuts.txt)
 #endif
+#ifndef HD_INF_WALK5
+#define HD_INF_WALK5 1       // 1: five instructions and one branch per token -- the stop flag is bit 6 of the word that is ADDED to the position, so a
+                             // token the walk must stop in front of throws it out of the half by itself and the last token is taken back behind
+                             // the loop; 0: rounds 1-4's seven and two.  Round 5, ABAB on one box: 162.4 / 167.5 / 118.4 -> 164.5 / 169.4 / 119.6 GB/s
+#endif
 #ifndef HD_INF_DEFER
 #define HD_INF_DEFER 1       // 1: the first lane-group pass of a window stays open across the scalar copies
 #endif
@@ -496,6 +501,36 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &a, InfLdsT<RIN
 			// only one written by the VALU does.)
 			uint32_t b, wm;
 			uint64_t real0, real1;
+#if HD_INF_WALK5
+			asm volatile("s_mov_b32 %0, 0\n\t"
+				     "s_mov_b64 %1, 0\n\t"
+				     "s_mov_b64 %2, 0\n"
+				     "Lhd_walk0_%=:\n\t"
+				     "v_readlane_b32 %3, %4, %0\n\t"
+				     "s_bitset1_b64 %1, %0\n\t"
+				     "s_add_u32 %0, %0, %3\n\t"
+				     "s_cmp_lt_u32 %0, 64\n\t"
+				     "s_cbranch_scc1 Lhd_walk0_%=\n\t"
+				     "s_bitcmp1_b32 %3, 6\n\t"
+				     "s_cbranch_scc0 Lhd_walk1_%=\n\t"
+				     "s_sub_u32 %0, %0, %3\n\t"
+				     "s_bitset0_b64 %1, %0\n\t"
+				     "s_branch Lhd_walk_done_%=\n"
+				     "Lhd_walk1_%=:\n\t"
+				     "v_readlane_b32 %3, %5, %0\n\t"
+				     "s_bitset1_b64 %2, %0\n\t"
+				     "s_add_u32 %0, %0, %3\n\t"
+				     "s_cmp_lt_u32 %0, 128\n\t"
+				     "s_cbranch_scc1 Lhd_walk1_%=\n\t"
+				     "s_bitcmp1_b32 %3, 6\n\t"
+				     "s_cbranch_scc0 Lhd_walk_done_%=\n\t"
+				     "s_sub_u32 %0, %0, %3\n\t"
+				     "s_bitset0_b64 %2, %0\n"
+				     "Lhd_walk_done_%=:"
+				     : "=&s"(b), "=&s"(real0), "=&s"(real1), "=&s"(wm)
+				     : "v"(s0.walk), "v"(s1.walk)
+				     : "scc");
+#else
 			asm volatile("s_mov_b32 %0, 0\n\t"
 				     "s_mov_b64 %1, 0\n\t"
 				     "s_mov_b64 %2, 0\n"
@@ -519,6 +554,7 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &a, InfLdsT<RIN
 				     : "=&s"(b), "=&s"(real0), "=&s"(real1), "=&s"(wm)
 				     : "v"(s0.walk), "v"(s1.walk)
 				     : "scc");
+#endif
 			// output positions; cut in front of the first token that would overrun the budget.  (Conditions are
 			// 64-bit lane masks: the ballot of ONE compare each, combined in scalar code, back to the lanes
 			// through sel() -- hd_device.hpp "lane masks".)
