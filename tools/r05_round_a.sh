@@ -14,3 +14,7 @@ print(' cpu', j['cpu_baseline']['value'], j['cpu_baseline']['cores'], j['cpu_bas
 PY
 timeout -k 10 700 bash tools/prof_round.sh > $O/prof_round.log 2>&1 || tail -5 $O/prof_round.log
 echo prof_round done
+timeout -k 10 300 python3 bench.py --first-record 1 --no-extra --no-cpu > $O/bench_first_record_1.log 2>&1 || tail -5 $O/bench_first_record_1.log
+grep '^{' $O/bench_first_record_1.log > $O/bench_first_record_1.json
+python3 -c "
+import json; j=json.load(open('$O/bench_first_record_1.json')); print('first-record 1:', j['value'], j['config']['ratio'], j['roofline']['kernel_ms_avg'])"
