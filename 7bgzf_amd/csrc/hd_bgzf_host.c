@@ -811,6 +811,15 @@ int main(int argc, char **argv)
 			int ncpu = 0;
 			if (!sched_getaffinity(0, sizeof(set), &set))
 				ncpu = CPU_COUNT(&set);
+			/* (... and within the cgroup's quota: a 16-CPU container on a 256-core host reports 256 through the affinity mask --
+			 * round 5: -@16 was thirty-two I/O threads there) */
+			FILE *cf = fopen("/sys/fs/cgroup/cpu.max", "r");
+			if (cf) {
+				long long q = 0, per = 0;
+				if (fscanf(cf, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0 && (int)((q + per - 1) / per) < ncpu)
+					ncpu = (int)((q + per - 1) / per);
+				fclose(cf);
+			}
 			const int most = ncpu > 5 ? (ncpu - 2) / 2 : 2;
 			if (nthreads > most)
 				nthreads = most;

@@ -17,7 +17,8 @@ ls -la $D/in.bin
 : > $OUT/e2e_files.txt
 tm() { local t0=$(date +%s.%N); "${@:2}"; local t1=$(date +%s.%N); echo "$1: $(python3 -c "print('%.3f s  %.2f GB/s in' % ($t1-$t0, $3/($t1-$t0)/1e9))")" >> $OUT/e2e_files.txt; }
 SZ=$(stat -c %s $D/in.bin)
-run_files() { HD7BGZF_TIMING=1 ./7bgzf_amd/hd7bgzf -G$1 -@$2 -i $D/in.bin -o $D/out.bgz 2>> $OUT/e2e_stderr.txt; }
+# (the output is removed before every timed run: truncating the previous run's gigabytes in tmpfs was a quarter of a second of the next)
+run_files() { rm -f $D/out.bgz; HD7BGZF_TIMING=1 ./7bgzf_amd/hd7bgzf -G$1 -@$2 -i $D/in.bin -o $D/out.bgz 2>> $OUT/e2e_stderr.txt; }
 run_filter() { ./7bgzf_amd/hd7bgzf -G1 < $D/in.bin > $D/out2.bgz 2>> $OUT/e2e_stderr.txt; }
 run_ref() { ./oracle/_ref/cielbox_ref 7bgzf -l1 -@16 < $D/in1g.bin > $D/ref.bgz 2>> $OUT/e2e_stderr.txt; }
 for T in 4 8 16; do
@@ -29,6 +30,7 @@ done
 # decode, file to file (the level-1 file of the last run above is level 6's: make the level-1 one again)
 run_files 1 8
 for T in 4 16; do
+  rm -f $D/back.bin
   t0=$(date +%s.%N); ./7bgzf_amd/hd7bgzf -d -@$T -i $D/out.bgz -o $D/back.bin 2>> $OUT/e2e_stderr.txt; t1=$(date +%s.%N)
   python3 -c "print('hd7bgzf -d -@$T file-to-file: %.3f s  %.2f GB/s out' % ($t1-$t0, $SZ/($t1-$t0)/1e9))" >> $OUT/e2e_files.txt
 done
