@@ -20,10 +20,13 @@ __device__ __forceinline__ unsigned where()
 }
 // (the real kernels' registers count too: the emit-only kernel holds 121 -> 128 VGPRs, a parse wavefront 95 -> 96 and a SIMD has 512:
 // four parse wavefronts and ONE emit wavefront per SIMD fit, two emit wavefronts on one SIMD keep the parse workgroup off the CU)
+__device__ unsigned g_sgpr_pressure;          // != 0: both kernels hold ~100 scalar registers too, as the real pair does
 __global__ __launch_bounds__(192) void ka(unsigned *out, unsigned *arrived, volatile unsigned *release)
 {
 	extern __shared__ unsigned lds[];
 	asm volatile("v_mov_b32 v127, 0" ::: "v127");
+	if (g_sgpr_pressure)
+		asm volatile("s_mov_b32 s100, 0" ::: "s100");
 	lds[threadIdx.x] = threadIdx.x;
 	if ((threadIdx.x & 63) == 0) {
 		out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = where() | (((unsigned)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3) << 16);
@@ -38,6 +41,8 @@ __global__ __launch_bounds__(1024) void kb(unsigned *out, long long *t)
 {
 	extern __shared__ unsigned lds[];
 	asm volatile("v_mov_b32 v95, 0" ::: "v95");
+	if (g_sgpr_pressure)
+		asm volatile("s_mov_b32 s95, 0" ::: "s95");
 	lds[threadIdx.x] = threadIdx.x;
 	const long long t0 = wall_clock64();
 	if (threadIdx.x == 0)
@@ -47,10 +52,21 @@ __global__ __launch_bounds__(1024) void kb(unsigned *out, long long *t)
 	if (threadIdx.x == 0) { t[2 * blockIdx.x] = t0; t[2 * blockIdx.x + 1] = wall_clock64(); }
 	if (lds[threadIdx.x] == 12345678u) out[0] = 0;
 }
+// the gate of the real scheme: one wavefront on B's stream that waits for A's wavefronts on the DEVICE, B right behind it
+__global__ __launch_bounds__(64) void kgate(unsigned *arrived, unsigned want)
+{
+	for (unsigned spins = 0; spins < (1u << 16); spins++) {
+		if (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want)
+			break;
+		__builtin_amdgcn_s_sleep(16);
+	}
+}
 int main(int argc, char **argv)
 {
 	const int per = argc > 1 ? atoi(argv[1]) : 3, wpw = argc > 2 ? atoi(argv[2]) : 1;      // A: wavefronts per CU, wavefronts per workgroup
 	const int NA = 256 * per, NB = 512;
+	const int sg = argc > 3 ? atoi(argv[3]) : 0, gate = argc > 4 ? atoi(argv[4]) : 0;       // scalar-register pressure; B behind a device-side gate
+	{ unsigned v = (unsigned)sg; hipMemcpyToSymbol(HIP_SYMBOL(g_sgpr_pressure), &v, 4); }
 	unsigned *da, *db, *arrived, *release;
 	long long *dt;
 	hipMalloc(&da, NA * 4); hipMalloc(&db, NB * 4); hipMalloc(&dt, NB * 16);
@@ -61,9 +77,13 @@ int main(int argc, char **argv)
 	hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 131200);
 	hipLaunchKernelGGL(ka, dim3(NA / wpw), dim3(64 * wpw), 10240 * wpw, s1, da, arrived, release);
 	auto t0 = std::chrono::steady_clock::now();
-	while (*(volatile unsigned *)arrived < (unsigned)NA && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
-		;
-	printf("A: %u of %d wavefronts resident when B is launched\n", *(volatile unsigned *)arrived, NA);
+	if (gate) {
+		hipLaunchKernelGGL(kgate, dim3(1), dim3(64), 0, s2, arrived, (unsigned)NA);
+	} else {
+		while (*(volatile unsigned *)arrived < (unsigned)NA && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
+			;
+		printf("A: %u of %d wavefronts resident when B is launched\n", *(volatile unsigned *)arrived, NA);
+	}
 	auto tb0 = std::chrono::steady_clock::now();
 	hipLaunchKernelGGL(kb, dim3(NB), dim3(1024), 131200, s2, db, dt);
 	hipStreamSynchronize(s2);
