@@ -111,6 +111,7 @@ struct Ctx {
 	hipEvent_t ev_tok = nullptr;     // last launch that used d_tok: a launch on ANOTHER stream waits for it
 	hipStream_t st_tok = nullptr;
 	bool tok_used = false;
+	hd::WgBeside beside;             // the workgroup levels' emit kernel beside their parse (hd_deflate_wg.hpp), with d_tok
 	hipEvent_t ev_tiles = nullptr;   // the same for d_tiles
 	hipStream_t st_tiles = nullptr;
 	bool tiles_used = false;
@@ -528,6 +529,7 @@ void hipdeflate_shutdown(void)
 		if (g.ev_tiles)
 			(void)hipEventDestroy(g.ev_tiles);
 		g.ev_tok = g.ev_tiles = nullptr;
+		g.beside.release();
 		g.st_tok = g.st_tiles = nullptr;
 		g.tok_used = g.tiles_used = false;
 		g.d_ct = nullptr;
@@ -623,6 +625,8 @@ static int batch_deflate_dev_impl(const void *in, const void *in_off, const void
 			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
 		if (g.tok_used && g.st_tok != (hipStream_t)stream)          // same stream: already in order
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
+		if (level >= HD_WG_LEVEL && !a.lat && !getenv("HIPDEFLATE_NO_BESIDE") && g.beside.init() == 0)
+			a.beside = &g.beside;
 		r = launch_deflate(a, level, (hipStream_t)stream);
 		if (!r) {
 			HD_CHECK(hipEventRecord(g.ev_tok, (hipStream_t)stream));

@@ -59,7 +59,7 @@ inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max, bool lat 
 {
 	const uint32_t sub = wg_sub_batch(nblocks, split_max);
 	return (((uint64_t)nblocks * 4 + 15) & ~(uint64_t)15) + (uint64_t)sub * wg_layout(split_max).bytes + 16 +
-	       (lat && split_max <= 65536 ? (uint64_t)(sub < 128 ? sub : 128) * 65536 + 256 : 0);
+	       (lat && split_max <= 65536 ? (uint64_t)(sub < 128 ? sub : 128) * 65536 + 256 : ((uint64_t)sub + 1) * 128 + 512);
 }
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
@@ -529,13 +529,26 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		return;
 	}
 	const ClockStamp clk(HD_CLK_DYNAMIC);
+	if (EMIT && !PARTS && a.arrived && lane == 0)                // (beside the parse: this wavefront has its slice of a CU)
+		__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
 
-	for (uint32_t b = (EMIT ? a.first : 0u) + blockIdx.x; b < b_end; b += gridDim.x) {
+	// (beside the parse, hd_deflate_wg.hpp launch_wg: the blocks are handed out by a counter -- the resident wavefronts and the ones that
+	// follow the parse take from the same one --; elsewhere wavefront j has blocks j, j + grid, ...)
+	auto take = [&](uint32_t b_now, bool first_one) -> uint32_t {
+		if (EMIT && !PARTS && a.next) {
+			uint32_t t = 0;
+			if (lane == 0)
+				t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return a.first + uniform(t);
+		}
+		return first_one ? (EMIT ? a.first : 0u) + blockIdx.x : b_now + gridDim.x;
+	};
+	for (uint32_t b = take(0, true); b < b_end; b = take(b, false)) {
 		const uint8_t *src = a.in + a.in_off[b];
 		const uint32_t n = a.in_len[b];
-		if (PARTS ? false : EMIT ? a.split_ovf[b] != 0 : (a.skip_small && a.split_ovf[b] == 0))
+		if (PARTS ? false : EMIT ? (!a.wg && a.split_ovf[b] != 0) : (a.skip_small && a.split_ovf[b] == 0))
 			continue;                            // the other path's block
 		if (!EMIT && a.seg_limit && n > a.seg_limit)
 			continue;                            // coded in segments (hd_segment.hpp)
@@ -1240,11 +1253,32 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				const SplitLayout lay = wg_layout(a.split_max);
 				const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
 				const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
+				bool waited_out = false;
+				if (a.ready) {
+					// beside the parse (hd_deflate_wg.hpp launch_wg): the block's workgroup says when its records are complete.  The
+					// polls are RMWs (they execute at the device's coherence point: no XCD's L2 can answer them with an old copy), a
+					// flag per 128-byte line, ~60 us apart; behind the wait an acquire at agent scope makes this XCD's L2 forget its
+					// clean lines, and the records -- written through their XCD's L2 by the parse (sc1) -- are read from memory.
+					// Bounded (~2 s where a whole sub-batch's parse is tens of milliseconds): stored and counted, never a hang
+					uint32_t spins = 0;
+					while (__hip_atomic_fetch_add(&a.ready[32 * bi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+						if (++spins > (1u << 15)) {
+							waited_out = true;
+							break;
+						}
+#pragma unroll
+						for (int z = 0; z < 16; z++)
+							__builtin_amdgcn_s_sleep(127);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					if (waited_out && a.stalls && lane == 0)
+						atomicAdd(a.stalls, 1u);
+				}
 				wg_pieces = (const uint4 *)(rec + lay.off_ntok);
 				wg_base = 0xffffff00u;
 				tok = (uint32_t *)rec;
 				crcv = m[1];
-				if (m[0] != 0)                               // (the workgroup parse gave the block up, or refused it: stored)
+				if (m[0] != 0 || waited_out)
 					alive = false;
 				// (a refused block is longer than the slot its record was sized by: its pieces' counts are not there to be
 				// walked -- ADVICE r4: the walk below ran over n / 1024 records before it looked at `alive`)

@@ -90,6 +90,12 @@ struct DeflateArgs {
 	// a device word that counts the blocks the workgroup parse gave up on because a turn did not come (WG_SPIN_LIMIT;
 	// they are written stored): hipdeflate_stall_count()
 	uint32_t *stalls = nullptr;
+	// the workgroup levels' throughput form, emit BESIDE the parse (hd_deflate_wg.hpp launch_wg): ready[32 * i] != 0 once block
+	// first + i's records are complete (raised by its parse workgroup; the emit wavefront that has the block waits for it; a
+	// flag per 128-byte line), arrived counts the emit wavefronts that are resident (the parse is launched behind a gate on it)
+	uint32_t *ready = nullptr, *arrived = nullptr, *next = nullptr;     // (next: the counter the blocks are handed out by)
+	// host side only: a WgBeside (hd_deflate_wg.hpp) -- the second stream and the events of that scheme; nullptr = emit behind parse
+	void *beside = nullptr;
 };
 
 __device__ __forceinline__ uint32_t frame_hdr_bytes(int frame)

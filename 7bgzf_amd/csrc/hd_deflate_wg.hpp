@@ -131,10 +131,15 @@ __device__ __forceinline__ uint64_t wg_uniform64(uint64_t v)
 
 // WAYS: positions per bucket = candidates verified per position (1, 2 or 4); LAZY: the lazy rule (else greedy)
 template <int WAYS, int LAZY>
-__global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
+__global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_parse_wg(DeflateArgs a)
 {
 	static_assert(WAYS == 1 || WAYS == 2 || WAYS == 4, "a bucket is 2, 4 or 8 bytes");
-	__shared__ WgLds L;
+	// DYNAMIC shared memory, on purpose: with the 131 KB declared statically the compiler knows that one workgroup fills the CU
+	// and pads the kernel's register count from 95 to 97 (-> 104 allocated) "so that no fifth wavefront fits a SIMD" -- which also
+	// keeps anything ELSE off the SIMD that needs more than 96 registers (round 5: the emit-only kernel beside the parse,
+	// profiles/r05_wg_beside.txt).  Passed at launch (launch_wg), the size is not the compiler's business and 95 stays 96.
+	extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds_raw[];
+	WgLds &L = *(WgLds *)wg_lds_raw;
 	const uint32_t lane = threadIdx.x & 63, w = uniform(threadIdx.x >> 6);      // (the compiler must know that w is one value per wavefront)
 	// a.wg_split workgroups share a block's parse (latency launches): workgroup q of SP takes the pieces [pfirst, plast) and,
 	// to have the table the pieces in front of them leave, REPLAYS those pieces' table turns first (hashes + bucket stores,
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 	// goes through whenever its stream fits, as libdeflate_deflate's does, lib/zlibutil.c:179-192; rounds 4 refused it), the
 	// slot where only the device knows them (hipdeflate_batch_deflate_dev: there a block longer than its slot is refused)
 	const bool refused = n > a.split_max;
+	const bool beside = a.ready != nullptr;          // the emit kernel runs beside this one and reads the records as the flags go up (launch_wg)
 	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
 	const uint32_t pfirst = npieces * q / SP, plast = npieces * (q + 1) / SP;    // (SP == 1: all of them)
 
@@ -492,37 +498,140 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) void k_parse_wg(DeflateArgs a)
 					uint32_t *const at = ptok + cnt + rank;
 					// (the store under exec = starts: the mask goes to exec as it is, not through a compare per lane)
 					uint64_t saved;
-					asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0"
-						     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
+					// (beside: the reader sits behind another XCD's L2 -- the store goes through this one's, sc1)
+					if (beside)
+						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off sc1\n\ts_mov_b64 exec, %0"
+							     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
+					else
+						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0"
+							     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
 				}
 				cnt += (uint32_t)__popcll(starts);
 				c_lit += (uint32_t)__popcll(starts & ~take);
 				c_long += (uint32_t)__popcll(starts & take & long9);
 			}
-			if (lane == 0)
-				rec_piece[j] = make_uint4(cnt, c_lit, cnt - c_lit - c_long, c_long);
+			if (lane == 0) {
+				if (beside) {
+					uint32_t *rp = (uint32_t *)&rec_piece[j];
+					__hip_atomic_store(rp + 0, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(rp + 1, c_lit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(rp + 2, cnt - c_lit - c_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(rp + 3, c_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				} else {
+					rec_piece[j] = make_uint4(cnt, c_lit, cnt - c_lit - c_long, c_long);
+				}
+			}
 		}
 	}
+	// (beside: every wavefront's stores -- written through this XCD's L2, sc1 -- have been acknowledged before the barrier)
+	if (beside)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (w == WG_NP && lane == 0) {
 		uint32_t *m = (uint32_t *)(rec + lay.off_rec);
 		const bool stalled = uniform(*vfail) != 0;
 		if (q == 0) {
-			m[0] = (stalled || refused) ? 0xffffffffu : 0u;
-			m[1] = crcv;
+			if (beside) {
+				__hip_atomic_store(&m[0], (stalled || refused) ? 0xffffffffu : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&m[1], crcv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			} else {
+				m[0] = (stalled || refused) ? 0xffffffffu : 0u;
+				m[1] = crcv;
+			}
 			a.split_ovf[b] = 0;
 		}
 		((uint8_t *)&m[2])[q & 3] = stalled ? 1 : 0;       // (a.wg_split > 1: the emit kernel looks at every sharer's byte)
 		if (stalled && a.stalls)
 			atomicAdd(a.stalls, 1u);
+		if (beside) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__hip_atomic_exchange(&a.ready[32 * bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+// the gate in front of a parse that runs BESIDE its emit kernel (launch_wg): one wavefront that waits until `want` emit
+// wavefronts have said they are resident -- they take their slices of the CUs' LDS and registers first, the parse workgroups fit in
+// what is left.  Bounded (~30 ms): a gate that gives up only costs the placement.
+__global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want)
+{
+	for (uint32_t spins = 0; spins < (1u << 14); spins++) {
+		if (__hip_atomic_fetch_add(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
+			break;
+		__builtin_amdgcn_s_sleep(64);
 	}
 }
 
 void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hpp
 
+// BESIDE (round 5, its last hours).  The parse holds a CU with ONE workgroup (131 KB of its 160 KB of LDS, sixteen wavefronts of 80
+// registers); the emit-only kernel is one wavefront per member with 9.6 KB of LDS and 121 registers.  One behind the other, the emit
+// kernel was a quarter of these levels' time on its own.  Now the emit kernel of a sub-batch is launched FIRST, on a second stream, with
+// 768 wavefronts that stay (three to a CU -- what a parse workgroup leaves of a CU's LDS and of a SIMD's registers holds:
+// tools/coresidency_probe.hip, tools/coresidency_real.hip); a one-wavefront gate on the caller's stream waits until they are resident;
+// the parse follows.  Every parse workgroup writes its records THROUGH its XCD's L2 (sc1 stores: the reader sits behind another
+// XCD's L2; a release fence instead writes the whole L2 back, a million times per sub-batch of BGZF blocks) and raises the block's flag
+// (an RMW, a flag per 128-byte line) once its stores are acknowledged; emit wavefronts take blocks from a counter, wait for the block's
+// flag with sparse RMW polls (never a cached copy), forget their XCD's clean L2 lines (an acquire at agent scope) and write the
+// member.  Behind the parse the same kernel runs once more at full occupancy for whatever has not been taken.  The bytes do not depend
+// on any of this.  What it needed, found the hard way (profiles/r05_wg_beside.txt): the parse's LDS passed at LAUNCH -- declared
+// statically, the compiler pads the kernel's registers so that nothing else fits the SIMD.
+// Gain: BGZF-sized blocks at level 6 +6.5 % (the parse runs 25 % slower beside the emit wavefronts, the emit kernel's own time is
+// gone); 1 MiB members gain nothing -- one wavefront needs 5 ms for a member, so the last members' emit sticks out behind the parse
+// by as much as the overlap saved -- and take the old order.
+struct WgBeside {
+	hipStream_t side = nullptr;
+	hipEvent_t ready = nullptr, done = nullptr;
+	int init()
+	{
+		if (side)
+			return 0;
+		// A stream of its OWN priority class: the runtime keeps a pool of hardware queues per priority, and streams of one class
+		// share queues once there are more of them than queues (four by default) -- two kernels in one hardware queue run one
+		// behind the other, and this scheme NEEDS its two kernels to run at the same time (seen in the GPU suite, with the pipes'
+		// and contexts' streams of earlier tests alive: the parse queued behind the emit kernel that was waiting for it, 2 s per
+		// wait, members stored).  The callers' streams and every stream this library makes are of the default class.
+		int lo = 0, hi = 0;
+		if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi ||
+		    hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) {
+			side = nullptr;
+			return -1;                                     // (no second class of queues: the emit kernel follows the parse as ever)
+		}
+		if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) {
+			release();
+			return -1;
+		}
+		return 0;
+	}
+	void release()
+	{
+		if (ready) (void)hipEventDestroy(ready);
+		if (done) (void)hipEventDestroy(done);
+		if (side) (void)hipStreamDestroy(side);
+		ready = done = nullptr;
+		side = nullptr;
+	}
+};
+constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU
+constexpr uint32_t WG_BESIDE_MIN = 512;          // blocks in a sub-batch below which the emit kernel simply follows the parse
+constexpr uint32_t WG_BESIDE_MAX_BLOCK = 131072; // ... and the longest block it is worth it for (see above)
+
 // blocks [first, first + count) of a sub-batch: the workgroup parse, then the emit-only kernel over its records
 inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 {
+	{
+		// (more than 64 KB of dynamic LDS has to be asked for, once per device and kernel)
+		static bool asked[64];
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		if (dev >= 0 && dev < 64 && !asked[dev]) {
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			asked[dev] = true;
+		}
+	}
 	const uint32_t sub = wg_sub_batch(a.nblocks, a.split_max);
 	DeflateArgs s = a;
 	// scratch: [ overflow flags, one u32 per block (always 0: nothing stands behind this path) | records of one sub-batch ]
@@ -543,18 +652,46 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			hipLaunchKernelGGL(k_stage_in, dim3(s.count), dim3(1024), 0, st, s, stage);
 			s.stage_in = stage;
 		}
+		WgBeside *bs = (!a.lat && s.count >= WG_BESIDE_MIN && a.split_max <= WG_BESIDE_MAX_BLOCK) ? (WgBeside *)a.beside : nullptr;
+		s.ready = s.arrived = s.next = nullptr;
+		if (bs) {
+			// (a flag line per block, the arrival counter and the hand-out counter lie behind the records: wg_scratch_bytes)
+			uint32_t *flags = (uint32_t *)(((uintptr_t)(s.scratch + (uint64_t)sub * wg_layout(a.split_max).bytes) + 255) & ~(uintptr_t)255);
+			const uint32_t eg = s.count < WG_BESIDE_WAVES ? s.count : WG_BESIDE_WAVES;
+			if (hipMemsetAsync(flags, 0, ((size_t)s.count + 1) * 128, st) != hipSuccess || hipEventRecord(bs->ready, st) != hipSuccess ||
+			    hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
+				bs = nullptr;
+			} else {
+				s.ready = flags;
+				s.arrived = flags + 32 * (size_t)s.count;
+				s.next = s.arrived + 16;
+				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0, bs->side, s);
+				(void)hipEventRecord(bs->done, bs->side);
+				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg);
+			}
+		}
 		const dim3 grid(s.count * s.wg_split), block(64 * HD_WG_WAVES);
 		if (HD_WG_WAYS(level) == 4)
-			hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, 0, st, s);
+			hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, sizeof(WgLds), st, s);
 		else if (HD_WG_WAYS(level) == 2)
-			hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, 0, st, s);
+			hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, sizeof(WgLds), st, s);
 		else if (HD_WG_LAZY(level))
-			hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, 0, st, s);
+			hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, sizeof(WgLds), st, s);
 		else
-			hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, 0, st, s);
+			hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, sizeof(WgLds), st, s);
 		if (a.lat) {
 			// the per-block boundary (HD_FRAME_LATENCY, blocks up to 64 KiB): the member written by a workgroup, the same bytes
 			launch_emit_wg(s, st);
+			continue;
+		}
+		if (bs) {
+			// ... and behind the parse the same kernel once more, at full occupancy, for what the resident wavefronts have not
+			// taken yet (every flag is up by then): where the emit work outweighs the parse (level 3) they are the tail
+			DeflateArgs h = s;
+			h.arrived = nullptr;
+			const uint32_t hg = s.count < 256u * 16u ? s.count : 256u * 16u;
+			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(hg), dim3(64), 0, st, h);
+			(void)hipStreamWaitEvent(st, bs->done, 0);           // the caller's stream carries on behind the sub-batch's members
 			continue;
 		}
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;

@@ -959,6 +959,48 @@ print("ok")
         assert p.returncode == 0 and "ok" in p.stdout, (method, p.stdout[-300:], p.stderr[-600:])
 
 
+def test_workgroup_levels_emit_beside_parse_is_the_twin(pkg):
+    """Launches of 512 BGZF-sized blocks and more at levels 3..9 run the emit-only kernel BESIDE the parse (hd_deflate_wg.hpp BESIDE:
+    resident emit wavefronts, a flag per block raised by its parse workgroup, the records written through the L2): the bytes are the
+    twin's whatever the schedule, no block is given up (stall counter), and HIPDEFLATE_NO_BESIDE -- the old order -- writes the same.
+    1,300 ragged blocks (the last sub-batch is not a multiple of anything) x levels 3 / 6, both frames of the batch API."""
+    synth = hdtest.synth()
+    rng = np.random.default_rng(77)
+    fq = bytes(synth.fastq_like(6 << 20, seed=41))
+    tx = bytes(synth.text_like(6 << 20, seed=42))
+    blocks = []
+    for i in range(1300):
+        src = fq if i % 3 else tx
+        n = int(rng.integers(1, 65281)) if i % 5 == 0 else 65280
+        o = int(rng.integers(0, len(src) - n))
+        blocks.append(src[o:o + n])
+    blob, offs = bytearray(), []
+    for b in blocks:
+        blob += bytes(-len(blob) % 16)
+        offs.append(len(blob))
+        blob += b
+    lens = [len(b) for b in blocks]
+    s0 = int(pkg.lib().hipdeflate_stall_count())
+    from concurrent.futures import ThreadPoolExecutor
+    for level in (3, 6):
+        slot = int(pkg.lib().hipdeflate_bound(65280, level))
+        members, crc, st = pkg.batch_deflate(bytes(blob), offs, lens, level, pkg.FRAME_RAW, slot=slot)
+        with ThreadPoolExecutor(16) as ex:
+            twins = list(ex.map(lambda b: hdtest.codec_twin(b, level, cap=slot), blocks))
+        for i, b in enumerate(blocks):
+            assert st[i] == 0 and twins[i][0] == 0 and members[i] == twins[i][1] and int(crc[i]) == zlib.crc32(b), (level, i, len(b))
+        m2, c2, s2 = pkg.batch_deflate(bytes(blob), offs, lens, level, pkg.FRAME_BGZF, slot=65536)
+        back = pkg.batch_inflate([m[18:-8] for m in m2], lens)[0]
+        assert all(x == y for x, y in zip(back, blocks))
+        os.environ["HIPDEFLATE_NO_BESIDE"] = "1"                     # (read at every call)
+        try:
+            m3, c3, s3 = pkg.batch_deflate(bytes(blob), offs, lens, level, pkg.FRAME_RAW, slot=slot)
+        finally:
+            del os.environ["HIPDEFLATE_NO_BESIDE"]
+        assert m3 == members and list(c3) == list(crc)
+    assert int(pkg.lib().hipdeflate_stall_count()) == s0
+
+
 def test_workgroup_parse_stalls_are_counted(pkg):
     """The one timing-dependent byte path: a workgroup whose table turn does not come within
     WG_SPIN_LIMIT polls gives the block up and it is written STORED with status 0 -- valid, but not the twin's bytes.  It is

@@ -1,12 +1,12 @@
-# round 5: the workgroup levels' emit kernel BESIDE the parse (hd_deflate_wg.hpp WgBeside; HIPDEFLATE_BESIDE=1): A/B on one box at full size
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:?}
-O=gpurun_out/r05_beside; mkdir -p $O; : > $O/ab.txt
+O=gpurun_out/r05_beside3; mkdir -p $O; : > $O/ab.txt
 line() { python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', j['value'], 'GB/s, ms/step', j['ms_per_step'], 'ratio', j['config'].get('ratio'), 'stalls', j['verified'].get('stalls'))"; }
-for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export HIPDEFLATE_BESIDE=1; else unset HIPDEFLATE_BESIDE; fi
-  echo "== HIPDEFLATE_BESIDE=${HIPDEFLATE_BESIDE:-unset}" | tee -a $O/ab.txt
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -x --timeout 150 -k "beside or wg or workgroup or migz or twin" > $O/pytest0.log 2>&1 || { tail -8 $O/pytest0.log; exit 1; }
+tail -1 $O/pytest0.log
+for rep in 1 2; do
   timeout -k 10 120 python3 bench.py --level 6 --no-cpu --steps 3 --warmup 1 --no-extra 2>$O/err.log | line bgzf_l6 | tee -a $O/ab.txt || { tail -3 $O/err.log; exit 1; }
   timeout -k 10 120 python3 bench.py --level 6 --data text --block-kib 1024 --no-cpu --steps 3 --warmup 1 --no-extra 2>$O/err.log | line migz_l6_text | tee -a $O/ab.txt || { tail -3 $O/err.log; exit 1; }
   timeout -k 10 120 python3 bench.py --level 3 --data text --block-kib 1024 --no-cpu --steps 3 --warmup 1 --no-extra 2>$O/err.log | line migz_l3_text | tee -a $O/ab.txt || { tail -3 $O/err.log; exit 1; }
+  timeout -k 10 120 python3 bench.py --level 3 --no-cpu --steps 3 --warmup 1 --no-extra 2>$O/err.log | line bgzf_l3 | tee -a $O/ab.txt || { tail -3 $O/err.log; exit 1; }
 done
