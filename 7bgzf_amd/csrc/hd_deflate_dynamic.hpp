@@ -468,9 +468,12 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // PARTS (EMIT only): the tokens of a block lie in PARTS records, one per parse part (hipdeflate_params.h HD_LAT_PARTS)
 // ... and the workgroup has a SECOND wavefront that builds the offset code while the first builds the litlen code (an emit
 // wavefront of a latency batch is alone on its CU: the two constructions one behind the other were 30 of its 55 us)
-template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0, int PARTS = 0>
+// BESIDE (EMIT only, the workgroup levels): the instantiation that runs beside the parse (hd_deflate_wg.hpp launch_wg) -- blocks handed out
+// by a counter, a wait for the block's flag, an acquire behind it; BESIDE = 0 is the kernel of rounds 4-5 to the instruction
+template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0, int PARTS = 0, int BESIDE = 0>
 __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArgs a)
 {
+	static_assert(!BESIDE || (EMIT && !PARTS), "beside the parse runs the emit-only kernel of the workgroup levels");
 	static_assert(!PARTS || EMIT, "parts are a matter of the emit-only kernel");
 	constexpr uint32_t W = 1u << WIN_BITS;
 	constexpr uint32_t W4M = W / 4 - 1;
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		return;
 	}
 	const ClockStamp clk(HD_CLK_DYNAMIC);
-	if (EMIT && !PARTS && a.arrived && lane == 0)                // (beside the parse: this wavefront has its slice of a CU)
+	if (BESIDE && a.arrived && lane == 0)                        // (beside the parse: this wavefront has its slice of a CU)
 		__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
@@ -537,13 +540,14 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 	// (beside the parse, hd_deflate_wg.hpp launch_wg: the blocks are handed out by a counter -- the resident wavefronts and the ones that
 	// follow the parse take from the same one --; elsewhere wavefront j has blocks j, j + grid, ...)
 	auto take = [&](uint32_t b_now, bool first_one) -> uint32_t {
-		if (EMIT && !PARTS && a.next) {
+		if constexpr (BESIDE != 0) {
 			uint32_t t = 0;
 			if (lane == 0)
 				t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return a.first + uniform(t);
+		} else {
+			return first_one ? (EMIT ? a.first : 0u) + blockIdx.x : b_now + gridDim.x;
 		}
-		return first_one ? (EMIT ? a.first : 0u) + blockIdx.x : b_now + gridDim.x;
 	};
 	for (uint32_t b = take(0, true); b < b_end; b = take(b, false)) {
 		const uint8_t *src = a.in + a.in_off[b];
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
 				const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
 				bool waited_out = false;
-				if (a.ready) {
+				if constexpr (BESIDE != 0) {
 					// beside the parse (hd_deflate_wg.hpp launch_wg): the block's workgroup says when its records are complete.  The
 					// polls are RMWs (they execute at the device's coherence point: no XCD's L2 can answer them with an old copy), a
 					// flag per 128-byte line, ~60 us apart; behind the wait an acquire at agent scope makes this XCD's L2 forget its

@@ -130,16 +130,25 @@ __device__ __forceinline__ uint64_t wg_uniform64(uint64_t v)
 }
 
 // WAYS: positions per bucket = candidates verified per position (1, 2 or 4); LAZY: the lazy rule (else greedy)
-template <int WAYS, int LAZY>
-__global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_parse_wg(DeflateArgs a)
+// BESIDE: the instantiation that runs with the emit kernel resident beside it (launch_wg): its LDS is passed at launch, its records go
+// through the L2, its blocks raise flags; BESIDE = 0 is the kernel of rounds 4-5 to the instruction
+template <int WAYS, int LAZY, int BESIDE = 0>
+__global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4, BESIDE ? 5 : 4))) void k_parse_wg(DeflateArgs a)
 {
 	static_assert(WAYS == 1 || WAYS == 2 || WAYS == 4, "a bucket is 2, 4 or 8 bytes");
-	// DYNAMIC shared memory, on purpose: with the 131 KB declared statically the compiler knows that one workgroup fills the CU
+	// BESIDE: DYNAMIC shared memory, on purpose: with the 131 KB declared statically the compiler knows that one workgroup fills the CU
 	// and pads the kernel's register count from 95 to 97 (-> 104 allocated) "so that no fifth wavefront fits a SIMD" -- which also
 	// keeps anything ELSE off the SIMD that needs more than 96 registers (round 5: the emit-only kernel beside the parse,
 	// profiles/r05_wg_beside.txt).  Passed at launch (launch_wg), the size is not the compiler's business and 95 stays 96.
-	extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds_raw[];
-	WgLds &L = *(WgLds *)wg_lds_raw;
+	WgLds *Lraw;
+	if constexpr (BESIDE) {
+		extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds_raw[];
+		Lraw = (WgLds *)wg_lds_raw;
+	} else {
+		__shared__ WgLds Ls;
+		Lraw = &Ls;
+	}
+	WgLds &L = *Lraw;
 	const uint32_t lane = threadIdx.x & 63, w = uniform(threadIdx.x >> 6);      // (the compiler must know that w is one value per wavefront)
 	// a.wg_split workgroups share a block's parse (latency launches): workgroup q of SP takes the pieces [pfirst, plast) and,
 	// to have the table the pieces in front of them leave, REPLAYS those pieces' table turns first (hashes + bucket stores,
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 	// goes through whenever its stream fits, as libdeflate_deflate's does, lib/zlibutil.c:179-192; rounds 4 refused it), the
 	// slot where only the device knows them (hipdeflate_batch_deflate_dev: there a block longer than its slot is refused)
 	const bool refused = n > a.split_max;
-	const bool beside = a.ready != nullptr;          // the emit kernel runs beside this one and reads the records as the flags go up (launch_wg)
+	const bool beside = BESIDE != 0;                 // the emit kernel runs beside this one and reads the records as the flags go up (launch_wg)
 	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
 	const uint32_t pfirst = npieces * q / SP, plast = npieces * (q + 1) / SP;    // (SP == 1: all of them)
 
@@ -625,10 +634,10 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 		int dev = 0;
 		(void)hipGetDevice(&dev);
 		if (dev >= 0 && dev < 64 && !asked[dev]) {
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
 			asked[dev] = true;
 		}
 	}
@@ -665,20 +674,40 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				s.ready = flags;
 				s.arrived = flags + 32 * (size_t)s.count;
 				s.next = s.arrived + 16;
-				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(eg), dim3(64), 0, bs->side, s);
+				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(eg), dim3(64), 0, bs->side, s);
 				(void)hipEventRecord(bs->done, bs->side);
 				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg);
 			}
 		}
 		const dim3 grid(s.count * s.wg_split), block(64 * HD_WG_WAVES);
 		if (HD_WG_WAYS(level) == 4)
-			hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, sizeof(WgLds), st, s);
+			{
+			if (bs)
+				hipLaunchKernelGGL((k_parse_wg<4, 1, 1>), grid, block, sizeof(WgLds), st, s);
+			else
+				hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, 0, st, s);
+		}
 		else if (HD_WG_WAYS(level) == 2)
-			hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, sizeof(WgLds), st, s);
+			{
+			if (bs)
+				hipLaunchKernelGGL((k_parse_wg<2, 1, 1>), grid, block, sizeof(WgLds), st, s);
+			else
+				hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, 0, st, s);
+		}
 		else if (HD_WG_LAZY(level))
-			hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, sizeof(WgLds), st, s);
+			{
+			if (bs)
+				hipLaunchKernelGGL((k_parse_wg<1, 1, 1>), grid, block, sizeof(WgLds), st, s);
+			else
+				hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, 0, st, s);
+		}
 		else
-			hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, sizeof(WgLds), st, s);
+			{
+			if (bs)
+				hipLaunchKernelGGL((k_parse_wg<1, 0, 1>), grid, block, sizeof(WgLds), st, s);
+			else
+				hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, 0, st, s);
+		}
 		if (a.lat) {
 			// the per-block boundary (HD_FRAME_LATENCY, blocks up to 64 KiB): the member written by a workgroup, the same bytes
 			launch_emit_wg(s, st);
@@ -690,7 +719,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			DeflateArgs h = s;
 			h.arrived = nullptr;
 			const uint32_t hg = s.count < 256u * 16u ? s.count : 256u * 16u;
-			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1>), dim3(hg), dim3(64), 0, st, h);
+			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(hg), dim3(64), 0, st, h);
 			(void)hipStreamWaitEvent(st, bs->done, 0);           // the caller's stream carries on behind the sub-batch's members
 			continue;
 		}

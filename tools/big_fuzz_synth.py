@@ -42,4 +42,6 @@ for seed in seeds:
                             bad += 1
                             print("MISMATCH seed %d %s block %d size %d level %d frame %d" % (seed, kind, i, bs, level, frame), flush=True)
             print("seed %d %s block size %d done, %d comparisons so far, %d bad, %.0f s" % (seed, kind, bs, total, bad, time.time() - t0), flush=True)
-print("BIG_FUZZ_SYNTH %s: %d comparisons, %d bad" % ("OK" if bad == 0 else "FAILED", total, bad))
+stalls = int(pkg.lib().hipdeflate_stall_count())
+print("BIG_FUZZ_SYNTH %s: %d comparisons, %d bad, %d stalls" % ("OK" if bad == 0 and stalls == 0 else "FAILED", total, bad, stalls))
+sys.exit(1 if bad or stalls else 0)
