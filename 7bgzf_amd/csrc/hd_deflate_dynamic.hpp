@@ -54,12 +54,26 @@ inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
 		sub = 1;
 	return sub < nblocks ? (uint32_t)sub : nblocks;
 }
+// the emit kernel beside the parse (hd_deflate_wg.hpp launch_wg): behind the first records a SECOND buffer of them when the launch is more
+// than one sub-batch, a flag line per block of the launch, a counter per sub-batch, the arrival and hand-out counters
+constexpr uint32_t WG_BESIDE_FLAG_BLOCKS = 1u << 22;      // launches beyond this many blocks (512 MB of flag lines) run one sub-batch at a time
+inline bool wg_beside_span(uint32_t nblocks, uint32_t split_max)
+{
+	return nblocks > wg_sub_batch(nblocks, split_max) && nblocks <= WG_BESIDE_FLAG_BLOCKS;
+}
+inline uint64_t wg_beside_bytes(uint32_t nblocks, uint32_t split_max)
+{
+	const uint32_t sub = wg_sub_batch(nblocks, split_max);
+	const bool span = wg_beside_span(nblocks, split_max);
+	const uint64_t flagged = span ? nblocks : sub;
+	return 256 + (span ? (uint64_t)sub * wg_layout(split_max).bytes + 256 : 0) + (flagged + 1) * 128 + ((uint64_t)(nblocks / sub + 2) * 4 + 255 & ~(uint64_t)255) + 512;
+}
 // lat: a latency launch of blocks up to 64 KiB -- room for their staged copies behind the records (hd_deflate_wg.hpp k_stage_in)
 inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max, bool lat = false)
 {
 	const uint32_t sub = wg_sub_batch(nblocks, split_max);
 	return (((uint64_t)nblocks * 4 + 15) & ~(uint64_t)15) + (uint64_t)sub * wg_layout(split_max).bytes + 16 +
-	       (lat && split_max <= 65536 ? (uint64_t)(sub < 128 ? sub : 128) * 65536 + 256 : ((uint64_t)sub + 1) * 128 + 512);
+	       (lat && split_max <= 65536 ? (uint64_t)(sub < 128 ? sub : 128) * 65536 + 256 : wg_beside_bytes(nblocks, split_max));
 }
 
 inline uint32_t dynamic_grid(uint32_t nblocks, int level)
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 	__shared__ uint32_t tokq[EMIT ? 1 : TOKQ];
 	const uint8_t *ring8 = (const uint8_t *)ring32;
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t b_end = EMIT ? (a.first + a.count < a.nblocks ? a.first + a.count : a.nblocks) : a.nblocks;
+	const uint32_t b_end = (BESIDE && a.span_sub) ? a.nblocks : EMIT ? (a.first + a.count < a.nblocks ? a.first + a.count : a.nblocks) : a.nblocks;
 	__shared__ typename std::conditional<(PARTS > 0), HuffScratch, uint32_t>::type hs2;   // the second wavefront's construction scratch
 	if (PARTS && threadIdx.x >= 64) {
 		// PARTS: the second wavefront.  It walks the same blocks as the first and meets it at two barriers per block -- the
@@ -542,9 +556,13 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 	auto take = [&](uint32_t b_now, bool first_one) -> uint32_t {
 		if constexpr (BESIDE != 0) {
 			uint32_t t = 0;
-			if (lane == 0)
+			if (lane == 0) {
+				// (SPAN: the member of b_now is done -- every read of its records has returned: the sub-batch's count)
+				if (!first_one && a.span_sub)
+					__hip_atomic_fetch_add(&a.emitted[b_now / a.span_sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			return a.first + uniform(t);
+			}
+			return (a.span_sub ? 0u : a.first) + uniform(t);
 		} else {
 			return first_one ? (EMIT ? a.first : 0u) + blockIdx.x : b_now + gridDim.x;
 		}
@@ -1216,7 +1234,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		}
 		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 		} else {
-			const uint32_t bi = b - a.first;
+			const uint32_t bi = (BESIDE && a.span_sub) ? b % a.span_sub : b - a.first;
 			if (PARTS) {
 				// the parse has been done in parts, one wavefront each (k_deflate_static, `parted`): ONE DEFLATE block
 				// of all their tokens, its histograms the sums, its CRC from crc(A || B) = crc(A) x^(8 |B|) ^ crc(B)
@@ -1255,7 +1273,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				// boundary once a block holds HD_DYN_BLOCK_TOKENS tokens or when the token mix has shifted (the twin's
 				// wg_split_check; deflate_compress.c:2141-2218) --, their symbols counted, and each is closed as ever
 				const SplitLayout lay = wg_layout(a.split_max);
-				const uint8_t *rec = a.scratch + (uint64_t)bi * lay.bytes;
+				const uint8_t *rec = ((BESIDE && a.span_sub && ((b / a.span_sub) & 1)) ? a.scratch_b : a.scratch) + (uint64_t)bi * lay.bytes;
 				const uint32_t *m = (const uint32_t *)(rec + lay.off_rec);
 				bool waited_out = false;
 				if constexpr (BESIDE != 0) {
@@ -1265,7 +1283,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 					// clean lines, and the records -- written through their XCD's L2 by the parse (sc1) -- are read from memory.
 					// Bounded (~2 s where a whole sub-batch's parse is tens of milliseconds): stored and counted, never a hang
 					uint32_t spins = 0;
-					while (__hip_atomic_fetch_add(&a.ready[32 * bi], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+					while (__hip_atomic_fetch_add(&a.ready[32 * (size_t)(a.span_sub ? b : bi)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
 						if (++spins > (1u << 15)) {
 							waited_out = true;
 							break;

@@ -94,6 +94,12 @@ struct DeflateArgs {
 	// first + i's records are complete (raised by its parse workgroup; the emit wavefront that has the block waits for it; a
 	// flag per 128-byte line), arrived counts the emit wavefronts that are resident (the parse is launched behind a gate on it)
 	uint32_t *ready = nullptr, *arrived = nullptr, *next = nullptr;     // (next: the counter the blocks are handed out by)
+	// ... SPAN: the emit kernel serves the WHOLE launch -- sub-batch k = blocks [k * span_sub, ...) has its records in `scratch` (k even)
+	// or `scratch_b` (k odd), its flag at ready[32 * b] for the launch's block b, and emitted[k] counts its members as they are done
+	// (the parse of sub-batch k + 2, which overwrites the records, is launched behind a gate on it)
+	uint32_t span_sub = 0;
+	uint8_t *scratch_b = nullptr;
+	uint32_t *emitted = nullptr;
 	// host side only: a WgBeside (hd_deflate_wg.hpp) -- the second stream and the events of that scheme; nullptr = emit behind parse
 	void *beside = nullptr;
 };

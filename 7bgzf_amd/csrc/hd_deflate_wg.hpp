@@ -554,7 +554,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 			atomicAdd(a.stalls, 1u);
 		if (beside) {
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			__hip_atomic_exchange(&a.ready[32 * bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_exchange(&a.ready[32 * (size_t)(a.span_sub ? b : bi)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 // the gate in front of a parse that runs BESIDE its emit kernel (launch_wg): one wavefront that waits until `want` emit
 // wavefronts have said they are resident -- they take their slices of the CUs' LDS and registers first, the parse workgroups fit in
 // what is left.  Bounded (~30 ms): a gate that gives up only costs the placement.
-__global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want)
+__global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want, uint32_t max_spins)
 {
-	for (uint32_t spins = 0; spins < (1u << 14); spins++) {
+	for (uint32_t spins = 0; spins < max_spins; spins++) {
 		if (__hip_atomic_fetch_add(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
 			break;
 		__builtin_amdgcn_s_sleep(64);
@@ -623,7 +623,7 @@ struct WgBeside {
 };
 constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU
 constexpr uint32_t WG_BESIDE_MIN = 512;          // blocks in a sub-batch below which the emit kernel simply follows the parse
-constexpr uint32_t WG_BESIDE_MAX_BLOCK = 131072; // ... and the longest block it is worth it for (see above)
+constexpr uint32_t WG_BESIDE_MAX_BLOCK = 2097152; // ... and the longest block it is worth it for (see above)
 
 // blocks [first, first + count) of a sub-batch: the workgroup parse, then the emit-only kernel over its records
 inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
@@ -647,6 +647,8 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 	s.split_ovf = (uint32_t *)a.scratch;
 	s.scratch = a.scratch + (((uint64_t)a.nblocks * 4 + 15) & ~(uint64_t)15);
 	s.wg = 1;
+	uint8_t *const records = s.scratch;
+	bool beside_off = false;                                 // (its set-up failed once: the launch goes on in the old order)
 	for (uint32_t first = 0; first < a.nblocks; first += sub) {
 		s.first = first;
 		s.count = a.nblocks - first < sub ? a.nblocks - first : sub;
@@ -661,22 +663,58 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			hipLaunchKernelGGL(k_stage_in, dim3(s.count), dim3(1024), 0, st, s, stage);
 			s.stage_in = stage;
 		}
-		WgBeside *bs = (!a.lat && s.count >= WG_BESIDE_MIN && a.split_max <= WG_BESIDE_MAX_BLOCK) ? (WgBeside *)a.beside : nullptr;
-		s.ready = s.arrived = s.next = nullptr;
+		WgBeside *bs = (!beside_off && !a.lat && a.nblocks >= WG_BESIDE_MIN && a.split_max <= WG_BESIDE_MAX_BLOCK) ? (WgBeside *)a.beside : nullptr;
+		s.ready = s.arrived = s.next = s.emitted = nullptr;
+		s.span_sub = 0;
+		s.scratch_b = nullptr;
+		const uint32_t k = first / sub;                          // the sub-batch
 		if (bs) {
-			// (a flag line per block, the arrival counter and the hand-out counter lie behind the records: wg_scratch_bytes)
-			uint32_t *flags = (uint32_t *)(((uintptr_t)(s.scratch + (uint64_t)sub * wg_layout(a.split_max).bytes) + 255) & ~(uintptr_t)255);
-			const uint32_t eg = s.count < WG_BESIDE_WAVES ? s.count : WG_BESIDE_WAVES;
-			if (hipMemsetAsync(flags, 0, ((size_t)s.count + 1) * 128, st) != hipSuccess || hipEventRecord(bs->ready, st) != hipSuccess ||
-			    hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
-				bs = nullptr;
-			} else {
-				s.ready = flags;
-				s.arrived = flags + 32 * (size_t)s.count;
-				s.next = s.arrived + 16;
-				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(eg), dim3(64), 0, bs->side, s);
-				(void)hipEventRecord(bs->done, bs->side);
-				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg);
+			// behind the first records (wg_beside_bytes): [ a second buffer of records, when the launch is more than one sub-batch: SPAN ]
+			// [ a flag line per block of the launch (SPAN) or of the sub-batch ] [ a counter per sub-batch ] [ arrival, hand-out ]
+			const bool span = wg_beside_span(a.nblocks, a.split_max);
+			const uint64_t rec_all = (uint64_t)sub * wg_layout(a.split_max).bytes;
+			uint8_t *const rec_a = records;
+			uint8_t *const rec_b = span ? (uint8_t *)(((uintptr_t)(rec_a + rec_all) + 255) & ~(uintptr_t)255) : nullptr;
+			uint32_t *const flags = (uint32_t *)(((uintptr_t)((span ? rec_b : rec_a) + rec_all) + 255) & ~(uintptr_t)255);
+			const uint64_t flagged = span ? a.nblocks : sub;
+			uint32_t *const emitted = flags + 32 * (flagged + 1);
+			uint32_t *const counters = emitted + (((size_t)(a.nblocks / sub + 2) + 63) & ~(size_t)63);
+			const uint32_t eg = WG_BESIDE_WAVES;
+			s.ready = flags;
+			s.arrived = counters;
+			s.next = counters + 16;
+			if (span) {
+				s.span_sub = sub;
+				s.scratch_b = rec_b;
+				s.emitted = emitted;
+				s.scratch = (k & 1) ? rec_b : rec_a;
+			}
+			if (!span || k == 0) {
+				// the emit wavefronts of this sub-batch -- SPAN: of the whole launch -- go first, on the side stream
+				DeflateArgs e = s;
+				if (span) {
+					e.first = 0;
+					e.count = a.nblocks;
+					e.scratch = rec_a;
+				}
+				const size_t zero = (size_t)((uint8_t *)(counters + 64) - (uint8_t *)flags);
+				if (hipMemsetAsync(flags, 0, zero, st) != hipSuccess || hipEventRecord(bs->ready, st) != hipSuccess ||
+				    hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
+					bs = nullptr;
+					beside_off = true;
+					s.ready = s.arrived = s.next = s.emitted = nullptr;
+					s.span_sub = 0;
+					s.scratch = records;
+				} else {
+					hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(eg), dim3(64), 0, bs->side, e);
+					(void)hipEventRecord(bs->done, bs->side);
+					hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg < (span ? a.nblocks : s.count) ? eg : (span ? a.nblocks : s.count), 1u << 14);
+				}
+			} else if (k >= 2) {
+				// SPAN: this parse overwrites the records of sub-batch k - 2: behind a gate on that sub-batch's members (an emit
+				// wavefront gives a block up after 2 s at the latest, so the gate's ~8 s are never the first limit to run out)
+				const uint32_t before = (k - 2) * sub, cnt = a.nblocks - before < sub ? a.nblocks - before : sub;
+				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, emitted + (k - 2), cnt, 1u << 22);
 			}
 		}
 		const dim3 grid(s.count * s.wg_split), block(64 * HD_WG_WAVES);
@@ -714,13 +752,22 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			continue;
 		}
 		if (bs) {
-			// ... and behind the parse the same kernel once more, at full occupancy, for what the resident wavefronts have not
+			if (s.span_sub && first + sub < a.nblocks) {
+				continue;                                    // SPAN: the next sub-batch's parse follows at once, into the other buffer
+			}
+			// ... and behind the (last) parse the same kernel once more, at full occupancy, for what the resident wavefronts have not
 			// taken yet (every flag is up by then): where the emit work outweighs the parse (level 3) they are the tail
 			DeflateArgs h = s;
 			h.arrived = nullptr;
-			const uint32_t hg = s.count < 256u * 16u ? s.count : 256u * 16u;
+			if (s.span_sub) {
+				h.first = 0;
+				h.count = a.nblocks;
+				h.scratch = records;
+			}
+			const uint32_t hn = s.span_sub ? a.nblocks : s.count;
+			const uint32_t hg = hn < 256u * 16u ? hn : 256u * 16u;
 			hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(hg), dim3(64), 0, st, h);
-			(void)hipStreamWaitEvent(st, bs->done, 0);           // the caller's stream carries on behind the sub-batch's members
+			(void)hipStreamWaitEvent(st, bs->done, 0);           // the caller's stream carries on behind the members
 			continue;
 		}
 		const uint32_t eg = s.count < 256u * 16u ? s.count : 256u * 16u;

@@ -177,7 +177,9 @@ def test_kernel_resource_budgets():
     (v,) = emit_wg.values()
     assert v["VGPRs"] <= 128 and v["LDS Size"] <= 163840, v      # sixteen wavefronts, one workgroup per CU
     for k, v in kernels.items():
-        assert v["ScratchSize"] == 0, (k, v)
+        # (the one exception: the emit-only kernel's BESIDE instantiation spills a few of its ~230 scalar values past the VGPR lanes --
+        # 32 bytes per lane, touched at block boundaries; it must stay within 128 registers to fit beside the parse, see below)
+        assert v["ScratchSize"] == 0 or (k.endswith("ELi0ELi1EEEvNS_11DeflateArgsE") and "k_deflate_dynamic" in k and v["ScratchSize"] <= 64), (k, v)
     for k, v in dyn.items():
         assert v["VGPRs"] <= 168, (k, v)
         # LDS is granted in 1280-byte units (measured: 10 waves of 15584 B do not fit a CU, of 15328 B do)

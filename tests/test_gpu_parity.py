@@ -998,6 +998,16 @@ def test_workgroup_levels_emit_beside_parse_is_the_twin(pkg):
         finally:
             del os.environ["HIPDEFLATE_NO_BESIDE"]
         assert m3 == members and list(c3) == list(crc)
+    # ... and members of MiGz size: 520 of 300,000 bytes (one sub-batch, every member several DEFLATE blocks), level 6
+    big = fq * 13 + tx * 13
+    n2, bs2 = 520, 300000
+    offs2 = [i * bs2 for i in range(n2)]
+    slot2 = int(pkg.lib().hipdeflate_bound(bs2, 6))
+    members, crc, st = pkg.batch_deflate(big[:n2 * bs2], offs2, [bs2] * n2, 6, pkg.FRAME_RAW, slot=slot2)
+    with ThreadPoolExecutor(16) as ex:
+        twins = list(ex.map(lambda i: hdtest.oracle_twin(big[offs2[i]:offs2[i] + bs2], 6), range(n2)))
+    for i in range(n2):
+        assert st[i] == 0 and twins[i][0] == 0 and members[i] == twins[i][1], ("migz-sized", i)
     assert int(pkg.lib().hipdeflate_stall_count()) == s0
 
 

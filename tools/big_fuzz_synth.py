@@ -1,6 +1,6 @@
 """One-off wide run on the GPU box over the BENCH data kinds: FASTQ-like and enwik-like text from many seeds, cut in
 0xff00-byte BGZF blocks and 1 MiB MiGz blocks, every level 1..9, plain and latency frames: kernel bytes == twin bytes,
-zlib reads them back.  usage: [HD_FUZZ_BLOCKS=65280,1048576] python tools/big_fuzz_synth.py [MiB_per_seed] [seeds...]"""
+zlib reads them back.  usage: [HD_FUZZ_BLOCKS=65280,1048576] [HD_FUZZ_LEVELS=3,6] python tools/big_fuzz_synth.py [MiB_per_seed] [seeds...]"""
 import importlib
 import os
 import sys
@@ -25,7 +25,7 @@ for seed in seeds:
             offs = list(range(0, len(data), bs))
             lens = [min(bs, len(data) - o) for o in offs]
             blocks = [data[o:o + n] for o, n in zip(offs, lens)]
-            for level in range(1, 10):
+            for level in [int(x) for x in os.environ.get("HD_FUZZ_LEVELS", "1,2,3,4,5,6,7,8,9").split(",")]:
                 frames = [(pkg.FRAME_RAW, hdtest.oracle_twin)]
                 if bs <= 0x10000:
                     frames.append((pkg.FRAME_RAW | pkg.FRAME_LATENCY, hdtest.codec_twin))
