@@ -56,6 +56,7 @@ inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
 }
 // the emit kernel beside the parse (hd_deflate_wg.hpp launch_wg): behind the first records a SECOND buffer of them when the launch is more
 // than one sub-batch, a flag line per block of the launch, a counter per sub-batch, the arrival and hand-out counters
+constexpr uint32_t WG_BESIDE_COUNTER_WORDS = 64 + 4096 + 4 * 4096;      // arrival, hand-out | emit wavefronts per CU | per SIMD
 constexpr uint32_t WG_BESIDE_FLAG_BLOCKS = 1u << 22;      // launches beyond this many blocks (512 MB of flag lines) run one sub-batch at a time
 inline bool wg_beside_span(uint32_t nblocks, uint32_t split_max)
 {
@@ -66,7 +67,8 @@ inline uint64_t wg_beside_bytes(uint32_t nblocks, uint32_t split_max)
 	const uint32_t sub = wg_sub_batch(nblocks, split_max);
 	const bool span = wg_beside_span(nblocks, split_max);
 	const uint64_t flagged = span ? nblocks : sub;
-	return 256 + (span ? (uint64_t)sub * wg_layout(split_max).bytes + 256 : 0) + (flagged + 1) * 128 + ((uint64_t)(nblocks / sub + 2) * 4 + 255 & ~(uint64_t)255) + 512;
+	return 256 + (span ? (uint64_t)sub * wg_layout(split_max).bytes + 256 : 0) + (flagged + 1) * 128 + ((uint64_t)(nblocks / sub + 2) * 4 + 255 & ~(uint64_t)255) +
+	       WG_BESIDE_COUNTER_WORDS * 4 + 512;
 }
 // lat: a latency launch of blocks up to 64 KiB -- room for their staged copies behind the records (hd_deflate_wg.hpp k_stage_in)
 inline uint64_t wg_scratch_bytes(uint32_t nblocks, uint32_t split_max, bool lat = false)
@@ -546,8 +548,33 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		return;
 	}
 	const ClockStamp clk(HD_CLK_DYNAMIC);
-	if (BESIDE && a.arrived && lane == 0)                        // (beside the parse: this wavefront has its slice of a CU)
-		__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if constexpr (BESIDE != 0) {
+		if (a.arrived) {
+			// A candidate for a place beside the parse.  A parse workgroup fits a CU whose LDS is free from 30 KB up and whose SIMDs hold at
+			// most ONE of us each (4 x 96 registers + ours of a SIMD's 512).  More candidates than places are launched -- other kernels
+			// are about when this one starts (the caller's gather of the pass before), and 768 wavefronts simply trusted to land three
+			// to a CU did not always: a parse a quarter slower, on and off -- and a candidate STAYS if its LDS block is one of the three
+			// lowest of its CU (HW_REG_LDS_ALLOC: base in 256-byte units in the low bits, size in [20:12]; tools/beside_filter_probe.hip) and
+			// no other has its SIMD; the others leave at once, and what they free lies ABOVE the ones that stay (kept by order of
+			// arrival instead, the leavers left holes and the parse's 131 KB did not fit: measured, three times slower).  The blocks
+			// are handed out by a counter, so nobody is missed.  (a.arrived counts everybody who has decided: the gate waits for it.)
+			bool stay = true;
+			if (lane == 0) {
+				unsigned hw, xcc, la;
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+				// cu: xcc_id [3:0] | se_id [15:13] | sh_id [12] | cu_id [11:8] of HW_ID -- 12 bits; simd_id [5:4]
+				const uint32_t cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+				uint32_t *const places = a.arrived + 64;
+				stay = (la & 0xfffu) < 3u * ((la >> 12) & 0x1ffu) &&
+				       __hip_atomic_fetch_add(&places[4096 + 4 * cu + ((hw >> 4) & 3u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+				__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (!uniform((uint32_t)stay))
+				return;
+		}
+	}
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;
 	const CrcTables *ct = a.ct;
 

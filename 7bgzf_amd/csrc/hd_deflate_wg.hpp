@@ -621,7 +621,8 @@ struct WgBeside {
 		side = nullptr;
 	}
 };
-constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU
+constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU ...
+constexpr uint32_t WG_BESIDE_CANDIDATES = 1536;  // ... kept from this many that are launched (k_deflate_dynamic<..., BESIDE>: every CU keeps its first three)
 constexpr uint32_t WG_BESIDE_MIN = 512;          // blocks in a sub-batch below which the emit kernel simply follows the parse
 constexpr uint32_t WG_BESIDE_MAX_BLOCK = 2097152; // ... and the longest block it is worth it for (see above)
 
@@ -679,7 +680,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			const uint64_t flagged = span ? a.nblocks : sub;
 			uint32_t *const emitted = flags + 32 * (flagged + 1);
 			uint32_t *const counters = emitted + (((size_t)(a.nblocks / sub + 2) + 63) & ~(size_t)63);
-			const uint32_t eg = WG_BESIDE_WAVES;
+			const uint32_t eg = WG_BESIDE_CANDIDATES;
 			s.ready = flags;
 			s.arrived = counters;
 			s.next = counters + 16;
@@ -697,7 +698,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 					e.count = a.nblocks;
 					e.scratch = rec_a;
 				}
-				const size_t zero = (size_t)((uint8_t *)(counters + 64) - (uint8_t *)flags);
+				const size_t zero = (size_t)((uint8_t *)(counters + WG_BESIDE_COUNTER_WORDS) - (uint8_t *)flags);
 				if (hipMemsetAsync(flags, 0, zero, st) != hipSuccess || hipEventRecord(bs->ready, st) != hipSuccess ||
 				    hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
 					bs = nullptr;
@@ -708,7 +709,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				} else {
 					hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(eg), dim3(64), 0, bs->side, e);
 					(void)hipEventRecord(bs->done, bs->side);
-					hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg < (span ? a.nblocks : s.count) ? eg : (span ? a.nblocks : s.count), 1u << 14);
+					hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg, 1u << 14);
 				}
 			} else if (k >= 2) {
 				// SPAN: this parse overwrites the records of sub-batch k - 2: behind a gate on that sub-batch's members (an emit
