@@ -94,7 +94,7 @@ const char *hipdeflate_version(void);
 /* Workgroups of the parse kernel (levels >= 3) that have given a block up since the contexts were made, over all contexts: a
  * table turn that did not come within ~40 ms of polling (a preempted or single-stepped device) -- such a block is written
  * STORED: valid, status 0, but not the bytes an undisturbed run writes.  Also counted: an emit wavefront that waited 2 s for a block's
- * parse where the emit kernel runs beside the parse (launches of 512 and more blocks of up to 128 KiB at levels >= 3: the two kernels
+ * parse where the emit kernel runs beside the parse (launches of 512 and more blocks of up to 2 MiB at levels >= 3: the two kernels
  * need to run at the same time, on a stream of the lowest priority class the library makes for it; HIPDEFLATE_NO_BESIDE=1 turns the
  * scheme off) -- the same consequence.  0 in every healthy run; bench.py, the GPU tests and the fuzz tools assert it.
  * (Synchronises the devices.) */
