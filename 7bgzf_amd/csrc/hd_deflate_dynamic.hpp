@@ -486,6 +486,12 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // wavefront of a latency batch is alone on its CU: the two constructions one behind the other were 30 of its 55 us)
 // BESIDE (EMIT only, the workgroup levels): the instantiation that runs beside the parse (hd_deflate_wg.hpp launch_wg) -- blocks handed out
 // by a counter, a wait for the block's flag, an acquire behind it; BESIDE = 0 is the kernel of rounds 4-5 to the instruction
+#ifndef HD_BESIDE_KEEP
+#define HD_BESIDE_KEEP 3                         // emit wavefronts a CU keeps beside a parse workgroup (k_deflate_dynamic<..., BESIDE>)
+#endif
+#ifndef HD_BESIDE_EMIT_PRIO
+#define HD_BESIDE_EMIT_PRIO 0
+#endif
 template <int WIN_BITS, int HASH_BITS, int MINLEN, int LAZY, int EMIT, int INTRA = 0, int DEEP = 0, int PARTS = 0, int BESIDE = 0>
 __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArgs a)
 {
@@ -567,12 +573,15 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				// cu: xcc_id [3:0] | se_id [15:13] | sh_id [12] | cu_id [11:8] of HW_ID -- 12 bits; simd_id [5:4]
 				const uint32_t cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
 				uint32_t *const places = a.arrived + 64;
-				stay = (la & 0xfffu) < 3u * ((la >> 12) & 0x1ffu) &&
+				stay = (la & 0xfffu) < (uint32_t)HD_BESIDE_KEEP * ((la >> 12) & 0x1ffu) &&
 				       __hip_atomic_fetch_add(&places[4096 + 4 * cu + ((hw >> 4) & 3u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 				__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			if (!uniform((uint32_t)stay))
 				return;
+#if HD_BESIDE_EMIT_PRIO
+			__builtin_amdgcn_s_setprio(HD_BESIDE_EMIT_PRIO);
+#endif
 		}
 	}
 	uint32_t *tok = (uint32_t *)a.scratch + (uint64_t)blockIdx.x * DYN_SLAB_TOKENS;

@@ -172,6 +172,10 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 	// slot where only the device knows them (hipdeflate_batch_deflate_dev: there a block longer than its slot is refused)
 	const bool refused = n > a.split_max;
 	const bool beside = BESIDE != 0;                 // the emit kernel runs beside this one and reads the records as the flags go up (launch_wg)
+#if HD_BESIDE_PARSE_PRIO
+	if constexpr (BESIDE != 0)
+		__builtin_amdgcn_s_setprio(HD_BESIDE_PARSE_PRIO);
+#endif
 	const uint32_t npieces = refused ? 0u : (n + HD_WG_CUT - 1) / HD_WG_CUT;
 	const uint32_t pfirst = npieces * q / SP, plast = npieces * (q + 1) / SP;    // (SP == 1: all of them)
 
@@ -621,6 +625,9 @@ struct WgBeside {
 		side = nullptr;
 	}
 };
+#ifndef HD_BESIDE_PARSE_PRIO
+#define HD_BESIDE_PARSE_PRIO 0                   // experiment switches of tools/r05_prio.sh (issue priority of the two kernels' wavefronts, emit wavefronts kept per CU)
+#endif
 constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU ...
 constexpr uint32_t WG_BESIDE_CANDIDATES = 1536;  // ... kept from this many that are launched (k_deflate_dynamic<..., BESIDE>: every CU keeps its first three)
 constexpr uint32_t WG_BESIDE_MIN = 512;          // blocks in a sub-batch below which the emit kernel simply follows the parse
