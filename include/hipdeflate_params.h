@@ -31,8 +31,10 @@
 #define HD_LOOKAHEAD       384         /* >= 64 + 258 + 8, bytes past S     */
 
 /* level 1: static Huffman, streaming emit (no token buffer) */
+#ifndef HD_L1_WIN_BITS                 /* (overridable for tools/r05_l1_geometry.sh: what a wider window would cost and buy) */
 #define HD_L1_WIN_BITS     12          /* 4 KiB LDS ring window (occupancy)  */
 #define HD_L1_HASH_BITS    11          /* hash bits; 1536 x u16 entries kept (HD_TABLE_ENTRIES) */
+#endif
 
 /* level 2: greedy parse, dynamic Huffman, in the level-1 geometry (4 KiB ring, 2^11 table).
  * On DNA-like data the window size hardly matters (same ratio as level 3), and the small LDS
