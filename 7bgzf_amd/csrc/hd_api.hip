@@ -565,6 +565,22 @@ uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
 /* ---- device-pointer API ---------------------------------------------------- */
 
 // max_in: the longest block of the batch where the host knows the lengths (0: only the device does)
+// The emit kernel BESIDE the parse (hd_deflate_wg.hpp launch_wg) needs its two kernels on the device at the same time.  Where the
+// process says that kernels run one at a time -- the runtime's launch-blocking and serialising switches, a profiler collecting
+// hardware counters (rocprofv3 --pmc dispatches one kernel at a time and exports these variables to its child) -- the emit kernel
+// follows the parse as in round 4: the same bytes, and no resident wavefronts waiting (bounded, ~2 s a block) for a parse that
+// cannot start.  HIPDEFLATE_NO_BESIDE=1 says the same by hand.
+static bool beside_allowed()
+{
+	auto on = [](const char *name) {
+		const char *v = getenv(name);
+		return v && *v && strcmp(v, "0") != 0;
+	};
+	// (read at every launch -- a launch is >= 512 blocks --, so a test can switch it)
+	return !on("HIPDEFLATE_NO_BESIDE") && !on("HIP_LAUNCH_BLOCKING") && !on("AMD_SERIALIZE_KERNEL") && !on("ROCPROF_COUNTER_COLLECTION") &&
+	       !getenv("ROCPROF_COUNTERS");
+}
+
 static int batch_deflate_dev_impl(const void *in, const void *in_off, const void *in_len, uint32_t nblocks, int level,
 				  int frame, void *out, uint64_t out_stride, uint32_t out_cap, void *out_len,
 				  void *crc32, void *status, void *stream, uint32_t max_in)
@@ -625,7 +641,7 @@ static int batch_deflate_dev_impl(const void *in, const void *in_off, const void
 			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
 		if (g.tok_used && g.st_tok != (hipStream_t)stream)          // same stream: already in order
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
-		if (level >= HD_WG_LEVEL && !a.lat && !getenv("HIPDEFLATE_NO_BESIDE") && g.beside.init() == 0)
+		if (level >= HD_WG_LEVEL && !a.lat && beside_allowed() && g.beside.init() == 0)
 			a.beside = &g.beside;
 		r = launch_deflate(a, level, (hipStream_t)stream);
 		if (!r) {

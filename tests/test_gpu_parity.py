@@ -1011,6 +1011,41 @@ def test_workgroup_levels_emit_beside_parse_is_the_twin(pkg):
     assert int(pkg.lib().hipdeflate_stall_count()) == s0
 
 
+def test_workgroup_levels_where_kernels_run_one_at_a_time(pkg):
+    """The emit kernel beside the parse needs both kernels on the device at once.  A process whose kernels run one at a time
+    (HIP_LAUNCH_BLOCKING=1; rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION) must get the old order -- the same bytes, no
+    stalls, and no resident wavefronts waiting two seconds a block for a parse that cannot start (hd_api.hip beside_allowed)."""
+    import subprocess
+    import sys
+    import time
+    prog = r'''
+import sys, zlib, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hdtest
+pkg = hdtest.pkg()
+fq = bytes(hdtest.synth().fastq_like(4 << 20, seed=43))
+n, bs = 600, 65280
+offs = [(i * 6007) %% (len(fq) - bs) & ~15 for i in range(n)]
+slot = int(pkg.lib().hipdeflate_bound(bs, 6))
+t0 = time.time()
+members, crc, st = pkg.batch_deflate(fq, offs, [bs] * n, 6, pkg.FRAME_RAW, slot=slot)
+dt = time.time() - t0
+for i in (0, 1, 299, 599):
+    rc, tw = hdtest.codec_twin(fq[offs[i]:offs[i] + bs], 6, cap=slot)
+    assert rc == 0 and st[i] == 0 and members[i] == tw, i
+assert all(int(x) == 0 for x in st) and pkg.lib().hipdeflate_stall_count() == 0
+back = pkg.batch_inflate(members, [bs] * n)[0]
+assert all(back[i] == fq[offs[i]:offs[i] + bs] for i in range(n))
+print("ok %%.2f" %% dt)
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for var in ("HIP_LAUNCH_BLOCKING", "ROCPROF_COUNTER_COLLECTION"):
+        env = dict(os.environ)
+        env[var] = "1"
+        p = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and p.stdout.startswith("ok"), (var, p.stdout[-300:], p.stderr[-600:])
+        assert float(p.stdout.split()[1]) < 20.0, (var, p.stdout)          # (first call: context + tables; a waiting emit kernel would take minutes)
+
+
 def test_workgroup_parse_stalls_are_counted(pkg):
     """The one timing-dependent byte path (VERDICT r4 item 6): a workgroup whose table turn does not come within
     WG_SPIN_LIMIT polls gives the block up and it is written STORED with status 0 -- valid, but not the twin's bytes.  It is
