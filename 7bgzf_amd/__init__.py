@@ -46,7 +46,7 @@ EXPORTS = [
     "hipdeflate_compact_dev", "hipdeflate_scratch_bytes", "bgzf_compress", "hipdeflate_selftest",
     "hipdeflate_pipe_open", "hipdeflate_pipe_input", "hipdeflate_pipe_submit", "hipdeflate_pipe_result",
     "hipdeflate_pipe_close", "hipdeflate_unpipe_open", "hipdeflate_unpipe_input", "hipdeflate_unpipe_submit",
-    "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths",
+    "hipdeflate_unpipe_result", "hipdeflate_unpipe_close", "hipdeflate_test_build_lengths", "hipdeflate_test_beside",
     "hip_inflate_flush", "hipdeflate_batch_inflate_flush", "hipdeflate_batch_inflate_flush_dev", "hipdeflate_bound",
     "hipdeflate_compact_span_dev",
     "hipdeflate_init_devices", "hipdeflate_device_count", "hipdeflate_use_device",
@@ -151,6 +151,8 @@ def lib():
     L.hipdeflate_lat_close.restype = None
     L.hipdeflate_lat_close.argtypes = [_vp]
     L.hipdeflate_test_build_lengths.argtypes = [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp]
+    L.hipdeflate_test_beside.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    L.hipdeflate_test_beside.restype = None
     _lib = L
     return L
 

@@ -570,6 +570,7 @@ uint64_t hipdeflate_bound(uint64_t block_bytes, int level)
 // hardware counters (rocprofv3 --pmc dispatches one kernel at a time and exports these variables to its child) -- the emit kernel
 // follows the parse as in round 4: the same bytes, and no resident wavefronts waiting (bounded, ~2 s a block) for a parse that
 // cannot start.  HIPDEFLATE_NO_BESIDE=1 says the same by hand.
+static uint32_t g_test_beside_keep = 3;     // hipdeflate_test_beside
 static bool beside_allowed()
 {
 	auto on = [](const char *name) {
@@ -641,8 +642,10 @@ static int batch_deflate_dev_impl(const void *in, const void *in_off, const void
 			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
 		if (g.tok_used && g.st_tok != (hipStream_t)stream)          // same stream: already in order
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
-		if (level >= HD_WG_LEVEL && !a.lat && beside_allowed() && g.beside.init() == 0)
+		if (level >= HD_WG_LEVEL && !a.lat && beside_allowed() && g.beside.init() == 0) {
 			a.beside = &g.beside;
+			a.beside_keep = g_test_beside_keep;
+		}
 		r = launch_deflate(a, level, (hipStream_t)stream);
 		if (!r) {
 			HD_CHECK(hipEventRecord(g.ev_tok, (hipStream_t)stream));
@@ -2080,6 +2083,12 @@ static int inflate_one(unsigned char *dest, size_t *destLen, const unsigned char
 	}
 	lk.unlock();
 	return ret;
+}
+
+void hipdeflate_test_beside(int keep, uint32_t sub_cap)
+{
+	g_test_beside_keep = keep < 0 ? 0u : keep > 3 ? 3u : (uint32_t)keep;
+	hd::wg_sub_test() = sub_cap;
 }
 
 #ifdef HD_EMIT_STATS

@@ -45,11 +45,18 @@ __host__ __device__ inline SplitLayout wg_layout(uint32_t max_block)
 	l.bytes = l.off_hist;
 	return l;
 }
+inline uint32_t &wg_sub_test()                 // tests (hipdeflate_test_beside): a cap on the blocks of a sub-batch, so that a launch of a few
+{                                              // thousand blocks walks the SPAN path (two record buffers, the gates) that 16 GiB walk in the bench
+	static uint32_t cap = 0;
+	return cap;
+}
 inline uint32_t wg_sub_batch(uint32_t nblocks, uint32_t split_max)
 {
 	uint64_t sub = SPLIT_SCRATCH_BUDGET_WG / wg_layout(split_max).bytes;
 	if (sub > 65536)
 		sub = 65536;
+	if (wg_sub_test() && sub > wg_sub_test())
+		sub = wg_sub_test();
 	if (sub < 1)
 		sub = 1;
 	return sub < nblocks ? (uint32_t)sub : nblocks;
@@ -486,6 +493,18 @@ __constant__ uint8_t k_perm19[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 // wavefront of a latency batch is alone on its CU: the two constructions one behind the other were 30 of its 55 us)
 // BESIDE (EMIT only, the workgroup levels): the instantiation that runs beside the parse (hd_deflate_wg.hpp launch_wg) -- blocks handed out
 // by a counter, a wait for the block's flag, an acquire behind it; BESIDE = 0 is the kernel of rounds 4-5 to the instruction
+// CRC-32 of a whole block by one wavefront (the rare paths of the workgroup levels' emit kernel: a block its parse workgroup gave up --
+// a stall, a poisoned gate -- is written stored, and the parse's own CRC stopped where its filler did)
+__device__ __noinline__ uint32_t crc_of_block(const CrcTables *ct, const uint8_t *src, uint32_t n, uint32_t lane)
+{
+	const bool aligned = (((uintptr_t)src) & 15) == 0;
+	CrcLanes crc;
+	crc.init(lane, n);
+	const uint32_t np = (n + HD_PIECE - 1) / HD_PIECE;
+	for (uint32_t k = 0; k < np; k++)
+		crc.fold<true>(ct, k, k * HD_PIECE + 16 * lane + 16 <= n, load_slot(src, n, k, lane, aligned));      // (the chained form: few registers -- this is a call from a kernel at its budget)
+	return crc.finish(ct, lane, n, src + (n & ~15u));
+}
 #ifndef HD_BESIDE_KEEP
 #define HD_BESIDE_KEEP 3                         // emit wavefronts a CU keeps beside a parse workgroup (k_deflate_dynamic<..., BESIDE>)
 #endif
@@ -573,7 +592,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				// cu: xcc_id [3:0] | se_id [15:13] | sh_id [12] | cu_id [11:8] of HW_ID -- 12 bits; simd_id [5:4]
 				const uint32_t cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
 				uint32_t *const places = a.arrived + 64;
-				stay = (la & 0xfffu) < (uint32_t)HD_BESIDE_KEEP * ((la >> 12) & 0x1ffu) &&
+				stay = (la & 0xfffu) < (a.beside_keep < (uint32_t)HD_BESIDE_KEEP ? a.beside_keep : (uint32_t)HD_BESIDE_KEEP) * ((la >> 12) & 0x1ffu) &&
 				       __hip_atomic_fetch_add(&places[4096 + 4 * cu + ((hw >> 4) & 3u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 				__hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
@@ -596,7 +615,22 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				// (SPAN: the member of b_now is done -- every read of its records has returned: the sub-batch's count)
 				if (!first_one && a.span_sub)
 					__hip_atomic_fetch_add(&a.emitted[b_now / a.span_sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (a.take_limit) {
+					// (the launch in front of a SPAN gate: blocks below the limit only -- an index taken by fetch_add could not be given back)
+					uint32_t v = __hip_atomic_load(a.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					for (;;) {
+						if (v >= a.take_limit) {
+							t = 0xffffffffu;
+							break;
+						}
+						if (__hip_atomic_compare_exchange_strong(a.next, &v, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+							t = v;
+							break;
+						}
+					}
+				} else {
+					t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 			return (a.span_sub ? 0u : a.first) + uniform(t);
 		} else {
@@ -1336,8 +1370,11 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				wg_base = 0xffffff00u;
 				tok = (uint32_t *)rec;
 				crcv = m[1];
-				if (m[0] != 0 || waited_out)
+				if (m[0] != 0 || waited_out) {
 					alive = false;
+					if (n <= a.split_max)                        // (given up, not refused: the member is written stored, with the CRC of all of it)
+						crcv = crc_of_block(ct, src, n, lane);
+				}
 				// (a refused block is longer than the slot its record was sized by: its pieces' counts are not there to be
 				// walked -- ADVICE r4: the walk below ran over n / 1024 records before it looked at `alive`)
 				wg_np = alive ? (n + HD_WG_CUT - 1) / HD_WG_CUT : 0u;

@@ -206,14 +206,18 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 			}
 	}
 	if (threadIdx.x == 0) {
-		L.turn = L.fail = L.next = 0;
+		L.turn = L.next = 0;
+		// (beside, SPAN: a gate in front of this parse gave up -- the records this block would overwrite may still be wanted: it is given
+		// up like a block whose turn did not come, before a token is written)
+		L.fail = (BESIDE != 0 && a.poison && __hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1u : 0u;
 		L.filled = bulk ? npieces : 0u;
 		L.table[WG_TABLE_BYTES / 4] = L.table[WG_TABLE_BYTES / 4 + 1] = 0;
 	}
 	__syncthreads();
+	const bool poisoned = BESIDE != 0 && uniform(L.fail) != 0;      // (nothing is read, nothing written: the emit kernel stores the block)
 
 	uint32_t crcv = 0;
-	if (w == WG_NP) {
+	if (w == WG_NP && !poisoned) {
 		// ================= the filler =====================================================================================
 		CrcLanes crc;
 		crc.init(lane, n);
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 		}
 		crcv = crc.finish(ct, lane, n, src + (n & ~15u));
 	}
-	if (w != WG_NP || bulk) {
+	if ((w != WG_NP || bulk) && !poisoned) {
 		// ================= a parser (bulk: the filler too, once its CRC is folded) =====================================
 		HashConsts6 hk;
 		hk.init(WG_TABLE_BYTES / 4);               // byte offset of a bucket of 2 WAYS bytes: (2 WAYS) * slot, below 64 KiB
@@ -566,13 +570,16 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 // the gate in front of a parse that runs BESIDE its emit kernel (launch_wg): one wavefront that waits until `want` emit
 // wavefronts have said they are resident -- they take their slices of the CUs' LDS and registers first, the parse workgroups fit in
 // what is left.  Bounded (~30 ms): a gate that gives up only costs the placement.
-__global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want, uint32_t max_spins)
+__global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want, uint32_t max_spins, uint32_t *poison)
 {
 	for (uint32_t spins = 0; spins < max_spins; spins++) {
 		if (__hip_atomic_fetch_add(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want)
-			break;
+			return;
 		__builtin_amdgcn_s_sleep(64);
 	}
+	// (SPAN: the gate in front of a parse that overwrites records -- giving up there must not go unnoticed: DeflateArgs::poison)
+	if (poison && threadIdx.x == 0)
+		__hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hpp
@@ -672,7 +679,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			s.stage_in = stage;
 		}
 		WgBeside *bs = (!beside_off && !a.lat && a.nblocks >= WG_BESIDE_MIN && a.split_max <= WG_BESIDE_MAX_BLOCK) ? (WgBeside *)a.beside : nullptr;
-		s.ready = s.arrived = s.next = s.emitted = nullptr;
+		s.ready = s.arrived = s.next = s.emitted = s.poison = nullptr;
 		s.span_sub = 0;
 		s.scratch_b = nullptr;
 		const uint32_t k = first / sub;                          // the sub-batch
@@ -691,6 +698,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			s.ready = flags;
 			s.arrived = counters;
 			s.next = counters + 16;
+			s.poison = counters + 32;
 			if (span) {
 				s.span_sub = sub;
 				s.scratch_b = rec_b;
@@ -710,19 +718,30 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				    hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
 					bs = nullptr;
 					beside_off = true;
-					s.ready = s.arrived = s.next = s.emitted = nullptr;
+					s.ready = s.arrived = s.next = s.emitted = s.poison = nullptr;
 					s.span_sub = 0;
 					s.scratch = records;
 				} else {
 					hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(eg), dim3(64), 0, bs->side, e);
 					(void)hipEventRecord(bs->done, bs->side);
-					hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg, 1u << 14);
+					hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, s.arrived, eg, 1u << 14, (uint32_t *)nullptr);
 				}
 			} else if (k >= 2) {
-				// SPAN: this parse overwrites the records of sub-batch k - 2: behind a gate on that sub-batch's members (an emit
-				// wavefront gives a block up after 2 s at the latest, so the gate's ~8 s are never the first limit to run out)
+				// SPAN: this parse overwrites the records of sub-batch k - 2: behind a gate on that sub-batch's members.  The resident
+				// wavefronts have normally written them long ago; but how many of them there are is the dispatcher's business (none, with
+				// another process's residents in the CUs' low LDS), so in front of the gate the emit kernel is launched for what is LEFT of
+				// sub-batch k - 2 -- at full occupancy, blocks below (k - 1) * sub only: nothing to do as a rule, the old order at worst --
+				// and the gate then waits for takers that are all alive.  If it gives up all the same, the parses behind it are told (poison)
 				const uint32_t before = (k - 2) * sub, cnt = a.nblocks - before < sub ? a.nblocks - before : sub;
-				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, emitted + (k - 2), cnt, 1u << 22);
+				DeflateArgs h = s;
+				h.arrived = nullptr;
+				h.first = 0;
+				h.count = a.nblocks;
+				h.scratch = rec_a;
+				h.take_limit = before + cnt;
+				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(cnt < 256u * 16u ? cnt : 256u * 16u), dim3(64), 0,
+						   st, h);
+				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, emitted + (k - 2), cnt, 1u << 22, s.poison);
 			}
 		}
 		const dim3 grid(s.count * s.wg_split), block(64 * HD_WG_WAVES);

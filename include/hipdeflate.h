@@ -333,6 +333,12 @@ int hipdeflate_selftest(void);
  * (2..288) symbols each under a length limit of maxbits (1..15); lens_out[nvec * nsyms] */
 int hipdeflate_test_build_lengths(const uint32_t *freq, uint32_t nvec, uint32_t nsyms, uint32_t maxbits,
 				  uint8_t *lens_out);
+/* test entry: the schedule of the workgroup levels' throughput form (levels >= 3, launches of 512 blocks and more) --
+ * keep = the emit wavefronts a CU keeps resident beside the parse (0..3; 0: none stay, the launches that follow the parses do all
+ * the emit work), sub_cap = a cap on the blocks of a sub-batch (0 = none: 17 GiB of records), so that a launch of a few thousand blocks
+ * walks the path of a 16 GiB one (two record buffers, the gates between sub-batches).  The bytes do not depend on either.  Process-wide;
+ * (3, 0) restores the defaults. */
+void hipdeflate_test_beside(int keep, uint32_t sub_cap);
 
 #ifdef __cplusplus
 }

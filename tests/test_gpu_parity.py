@@ -1011,6 +1011,64 @@ def test_workgroup_levels_emit_beside_parse_is_the_twin(pkg):
     assert int(pkg.lib().hipdeflate_stall_count()) == s0
 
 
+def test_workgroup_levels_span_of_sub_batches_whoever_stays(pkg):
+    """A launch of more than one sub-batch (16 GiB in the bench) keeps ONE emit kernel resident across all of them: the records
+    alternate between two buffers and the parse of sub-batch k + 2 overwrites those of sub-batch k -- behind a launch of the emit
+    kernel for what is left of k and a gate on its members (hd_deflate_wg.hpp launch_wg).  How many emit wavefronts stay resident is
+    the dispatcher's business (none, with another process's in the CUs' low LDS): with three, one or NONE per CU the bytes are the
+    twin's, nothing is given up, and nobody waits for the gate's limit.  hipdeflate_test_beside caps the sub-batch so that 2,600
+    blocks walk the path."""
+    import time
+    synth = hdtest.synth()
+    rng = np.random.default_rng(78)
+    fq = bytes(synth.fastq_like(6 << 20, seed=44))
+    tx = bytes(synth.text_like(6 << 20, seed=45))
+    blocks = []
+    for i in range(2600):
+        src = fq if i % 4 else tx
+        n = int(rng.integers(1, 65281)) if i % 7 == 0 else 65280
+        o = int(rng.integers(0, len(src) - n))
+        blocks.append(src[o:o + n])
+    blob, offs = bytearray(), []
+    for b in blocks:
+        blob += bytes(-len(blob) % 16)
+        offs.append(len(blob))
+        blob += b
+    blob = bytes(blob)
+    lens = [len(b) for b in blocks]
+    slot = int(pkg.lib().hipdeflate_bound(65280, 6))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(16) as ex:
+        twins = list(ex.map(lambda b: hdtest.codec_twin(b, 6, cap=slot), blocks))
+    s0 = int(pkg.lib().hipdeflate_stall_count())
+    big = fq * 20 + tx * 20
+    n2, bs2 = 700, 300000
+    offs2 = [i * bs2 for i in range(n2)]
+    slot2 = int(pkg.lib().hipdeflate_bound(bs2, 5))
+    want2 = None
+    try:
+        for keep in (3, 0, 1):
+            pkg.lib().hipdeflate_test_beside(keep, 600)
+            t0 = time.time()
+            members, crc, st = pkg.batch_deflate(blob, offs, lens, 6, pkg.FRAME_RAW, slot=slot)
+            dt = time.time() - t0
+            for i, b in enumerate(blocks):
+                assert st[i] == 0 and twins[i][0] == 0 and members[i] == twins[i][1] and int(crc[i]) == zlib.crc32(b), (keep, i, len(b))
+            assert dt < 6.0, (keep, dt)                # (a gate that waited for its limit would take ~8 s per sub-batch)
+            # ... and members of several DEFLATE blocks, 150 to a sub-batch, level 5
+            pkg.lib().hipdeflate_test_beside(keep, 150)
+            m2, c2, s2 = pkg.batch_deflate(big[:n2 * bs2], offs2, [bs2] * n2, 5, pkg.FRAME_RAW, slot=slot2)
+            assert all(int(x) == 0 for x in s2)
+            if want2 is None:
+                with ThreadPoolExecutor(16) as ex:
+                    want2 = list(ex.map(lambda i: hdtest.oracle_twin(big[offs2[i]:offs2[i] + bs2], 5), range(n2)))
+            for i in range(n2):
+                assert want2[i][0] == 0 and m2[i] == want2[i][1], ("several blocks a member", keep, i)
+    finally:
+        pkg.lib().hipdeflate_test_beside(3, 0)
+    assert int(pkg.lib().hipdeflate_stall_count()) == s0
+
+
 def test_workgroup_levels_where_kernels_run_one_at_a_time(pkg):
     """The emit kernel beside the parse needs both kernels on the device at once.  A process whose kernels run one at a time
     (HIP_LAUNCH_BLOCKING=1; rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION) must get the old order -- the same bytes, no
