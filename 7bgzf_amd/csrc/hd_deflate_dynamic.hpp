@@ -74,7 +74,7 @@ inline uint64_t wg_beside_bytes(uint32_t nblocks, uint32_t split_max)
 	const uint32_t sub = wg_sub_batch(nblocks, split_max);
 	const bool span = wg_beside_span(nblocks, split_max);
 	const uint64_t flagged = span ? nblocks : sub;
-	return 256 + (span ? (uint64_t)sub * wg_layout(split_max).bytes + 256 : 0) + (flagged + 1) * 128 + ((uint64_t)(nblocks / sub + 2) * 4 + 255 & ~(uint64_t)255) +
+	return 256 + (span ? (uint64_t)sub * wg_layout(split_max).bytes + 256 : 0) + (flagged + 1) * 128 + 2 * ((uint64_t)(nblocks / sub + 2) * 4 + 255 & ~(uint64_t)255) +
 	       WG_BESIDE_COUNTER_WORDS * 4 + 512;
 }
 // lat: a latency launch of blocks up to 64 KiB -- room for their staged copies behind the records (hd_deflate_wg.hpp k_stage_in)
@@ -505,6 +505,15 @@ __device__ __noinline__ uint32_t crc_of_block(const CrcTables *ct, const uint8_t
 		crc.fold<true>(ct, k, k * HD_PIECE + 16 * lane + 16 <= n, load_slot(src, n, k, lane, aligned));      // (the chained form: few registers -- this is a call from a kernel at its budget)
 	return crc.finish(ct, lane, n, src + (n & ~15u));
 }
+// (a pointer known to be to device memory: the records' loads are global_load, not flat_load -- a flat load counts as an LDS access too,
+// and every wait for the LDS in the token loops would wait for the tokens requested ahead)
+typedef const __attribute__((address_space(1))) uint32_t *hd_global_u32p;
+#ifndef HD_BESIDE_SC1_LOADS
+#define HD_BESIDE_SC1_LOADS 1
+#endif
+#ifndef HD_EXP_NO_COUNT
+#define HD_EXP_NO_COUNT 0
+#endif
 #ifndef HD_BESIDE_KEEP
 #define HD_BESIDE_KEEP 3                         // emit wavefronts a CU keeps beside a parse workgroup (k_deflate_dynamic<..., BESIDE>)
 #endif
@@ -608,6 +617,7 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 
 	// (beside the parse, hd_deflate_wg.hpp launch_wg: the blocks are handed out by a counter -- the resident wavefronts and the ones that
 	// follow the parse take from the same one --; elsewhere wavefront j has blocks j, j + grid, ...)
+	uint32_t cur_sub = (BESIDE && a.take_sub) ? a.take_sub - 1 : 0u;      // (SPAN: the sub-batch this wavefront is taking blocks of)
 	auto take = [&](uint32_t b_now, bool first_one) -> uint32_t {
 		if constexpr (BESIDE != 0) {
 			uint32_t t = 0;
@@ -615,23 +625,30 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				// (SPAN: the member of b_now is done -- every read of its records has returned: the sub-batch's count)
 				if (!first_one && a.span_sub)
 					__hip_atomic_fetch_add(&a.emitted[b_now / a.span_sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (a.take_limit) {
-					// (the launch in front of a SPAN gate: blocks below the limit only -- an index taken by fetch_add could not be given back)
-					uint32_t v = __hip_atomic_load(a.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					for (;;) {
-						if (v >= a.take_limit) {
-							t = 0xffffffffu;
+				if (a.span_sub) {
+					// SPAN: a hand-out counter per sub-batch, taken in order.  A counter that has run past its sub-batch's blocks sends the
+					// wavefront on to the next one (what it added there is lost on nobody: there is no such block) -- so the launch in front
+					// of a gate (take_sub: the ONE sub-batch it serves) takes what is left of its sub-batch with one fetch_add per wavefront
+					// and cannot take a block of another (a shared counter bounded by compare-and-swap was tried: 4096 wavefronts that find
+					// something left retry against each other, 25 ms)
+					uint32_t k = cur_sub;
+					const uint32_t k_end = a.take_sub ? a.take_sub : (a.nblocks + a.span_sub - 1) / a.span_sub;
+					t = 0xffffffffu;
+					while (k < k_end) {
+						const uint32_t left = a.nblocks - k * a.span_sub, cntk = left < a.span_sub ? left : a.span_sub;
+						const uint32_t v = __hip_atomic_fetch_add(&a.next[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (v < cntk) {
+							t = k * a.span_sub + v;
 							break;
 						}
-						if (__hip_atomic_compare_exchange_strong(a.next, &v, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-							t = v;
-							break;
-						}
+						k++;
 					}
+					cur_sub = k;
 				} else {
 					t = __hip_atomic_fetch_add(a.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			}
+			cur_sub = uniform(cur_sub);
 			return (a.span_sub ? 0u : a.first) + uniform(t);
 		} else {
 			return first_one ? (EMIT ? a.first : 0u) + blockIdx.x : b_now + gridDim.x;
@@ -796,6 +813,18 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 		auto wg_piece_load = [&](uint32_t k) {
 			if (k - wg_base >= 64) {
 				wg_base = k & ~63u;
+				if (BESIDE && HD_BESIDE_SC1_LOADS) {
+					// (beside the parse: what its workgroups wrote is read by loads that are coherent at the device's level themselves -- sc1 --
+					// instead of behind an invalidate of this XCD's L2 per block; see the wait below)
+					wg_pv = make_uint4(0, 0, 0, 0);
+					if (wg_base + lane < wg_np) {
+						const hd_global_u32p pp = (hd_global_u32p)(const uint32_t *)&wg_pieces[wg_base + lane];
+						wg_pv.x = __hip_atomic_load(pp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						wg_pv.y = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						wg_pv.z = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						wg_pv.w = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				} else
 				wg_pv = wg_base + lane < wg_np ? wg_pieces[wg_base + lane] : make_uint4(0, 0, 0, 0);
 			}
 		};
@@ -814,6 +843,9 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 				v = 0;
 				if (k < wg_k1) {
 					nv = c - base < 64 ? c - base : 64;
+					if (BESIDE && HD_BESIDE_SC1_LOADS)
+						v = lane < nv ? __hip_atomic_load((hd_global_u32p)tok + (k * HD_WG_CUT + base + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+					else
 					v = lane < nv ? tok[k * HD_WG_CUT + base + lane] : 0u;
 					base += 64;
 					if (base >= c) {
@@ -1362,15 +1394,26 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 						for (int z = 0; z < 16; z++)
 							__builtin_amdgcn_s_sleep(127);
 					}
+#if HD_BESIDE_SC1_LOADS
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // (order only: the records are read by sc1 loads)
+#else
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 					if (waited_out && a.stalls && lane == 0)
 						atomicAdd(a.stalls, 1u);
 				}
 				wg_pieces = (const uint4 *)(rec + lay.off_ntok);
 				wg_base = 0xffffff00u;
 				tok = (uint32_t *)rec;
-				crcv = m[1];
-				if (m[0] != 0 || waited_out) {
+				uint32_t m0;
+				if (BESIDE && HD_BESIDE_SC1_LOADS) {
+					m0 = __hip_atomic_load((hd_global_u32p)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					crcv = __hip_atomic_load((hd_global_u32p)m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				} else {
+					m0 = m[0];
+					crcv = m[1];
+				}
+				if (m0 != 0 || waited_out) {
 					alive = false;
 					if (n <= a.split_max)                        // (given up, not refused: the member is written stored, with the CRC of all of it)
 						crcv = crc_of_block(ct, src, n, lane);
@@ -1437,18 +1480,25 @@ __global__ __launch_bounds__(PARTS ? 128 : 64) void k_deflate_dynamic(DeflateArg
 						w |= ls << (8 * q);
 					}
 					((uint32_t *)lsym)[lane] = w;
+#if HD_EXP_NO_COUNT != 2                      /* experiment (tools/r05_nocount.sh, timing only: with no counts every block gets the static code -- valid, larger) */
 					wg_for_tokens([&](uint32_t tk, uint32_t nv) {
 						const bool is_match = (tk & HD_TOKEN_MATCH) != 0;
 						const uint32_t idx = (tk >> 16) & 0x1ffu;                // literal, or 256 + (length - 3)
 						const uint32_t sym = is_match ? 257u + lsym[idx & 0xffu] : idx;
 						uint32_t ds, eb, ev;
 						off_slot((tk & 0xffff) + 1, ds, eb, ev);
+#if HD_EXP_NO_COUNT == 1
+						if (lane < nv && sym + ds == 0xffffffffu)     // (never: the arithmetic stays, the atomics go)
+							atomicAdd(&L.lf[0], 1u);
+#else
 						if (lane < nv) {
 							atomicAdd(&L.lf[sym], 1u);
 							if (is_match)
 								atomicAdd(&L.df[ds], 1u);
 						}
+#endif
 					});
+#endif
 				}
 					EMIT_T(5);
 					ntok_slab = blk_tok;

@@ -100,11 +100,12 @@ struct DeflateArgs {
 	uint32_t span_sub = 0;
 	uint8_t *scratch_b = nullptr;
 	uint32_t *emitted = nullptr;
-	// ... and in front of that gate a launch of the emit kernel that takes what is left of sub-batch k, blocks below take_limit, and
-	// nothing beyond (a compare-and-swap on `next`): whatever became of the resident wavefronts, every block of sub-batch k has a live
-	// taker before the gate waits.  Should the gate give up all the same (~8 s: a device in trouble), it sets *poison and the parses
-	// behind it leave the records alone -- their blocks are written stored and counted as stalls, valid streams, not the twin's bytes
-	uint32_t take_limit = 0;
+	// ... and in front of that gate a launch of the emit kernel that takes what is left of sub-batch k and of no other (take_sub = k + 1;
+	// SPAN hands the blocks out by a counter per sub-batch, next[k]): whatever became of the resident wavefronts, every block of
+	// sub-batch k has a live taker before the gate waits.  Should the gate give up all the same (~8 s: a device in trouble), it sets
+	// *poison and the parses behind it leave the records alone -- their blocks are written stored and counted as stalls, valid
+	// streams, not the twin's bytes
+	uint32_t take_sub = 0;
 	uint32_t *poison = nullptr;
 	uint32_t beside_keep = 3;                    // emit wavefronts a CU keeps (tests: hipdeflate_test_beside(keep = 0): nobody stays)
 	// host side only: a WgBeside (hd_deflate_wg.hpp) -- the second stream and the events of that scheme; nullptr = emit behind parse

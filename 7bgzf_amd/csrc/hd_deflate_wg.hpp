@@ -693,7 +693,9 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 			uint32_t *const flags = (uint32_t *)(((uintptr_t)((span ? rec_b : rec_a) + rec_all) + 255) & ~(uintptr_t)255);
 			const uint64_t flagged = span ? a.nblocks : sub;
 			uint32_t *const emitted = flags + 32 * (flagged + 1);
-			uint32_t *const counters = emitted + (((size_t)(a.nblocks / sub + 2) + 63) & ~(size_t)63);
+			const size_t per_sub = ((size_t)(a.nblocks / sub + 2) + 63) & ~(size_t)63;
+			uint32_t *const taken = emitted + per_sub;               // SPAN: the hand-out counter of every sub-batch
+			uint32_t *const counters = taken + per_sub;
 			const uint32_t eg = WG_BESIDE_CANDIDATES;
 			s.ready = flags;
 			s.arrived = counters;
@@ -703,6 +705,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				s.span_sub = sub;
 				s.scratch_b = rec_b;
 				s.emitted = emitted;
+				s.next = taken;
 				s.scratch = (k & 1) ? rec_b : rec_a;
 			}
 			if (!span || k == 0) {
@@ -730,7 +733,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				// SPAN: this parse overwrites the records of sub-batch k - 2: behind a gate on that sub-batch's members.  The resident
 				// wavefronts have normally written them long ago; but how many of them there are is the dispatcher's business (none, with
 				// another process's residents in the CUs' low LDS), so in front of the gate the emit kernel is launched for what is LEFT of
-				// sub-batch k - 2 -- at full occupancy, blocks below (k - 1) * sub only: nothing to do as a rule, the old order at worst --
+				// sub-batch k - 2 -- at full occupancy, that sub-batch's hand-out counter only: nothing to do as a rule, the old order at worst --
 				// and the gate then waits for takers that are all alive.  If it gives up all the same, the parses behind it are told (poison)
 				const uint32_t before = (k - 2) * sub, cnt = a.nblocks - before < sub ? a.nblocks - before : sub;
 				DeflateArgs h = s;
@@ -738,7 +741,7 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 				h.first = 0;
 				h.count = a.nblocks;
 				h.scratch = rec_a;
-				h.take_limit = before + cnt;
+				h.take_sub = k - 1;                          // (sub-batch k - 2, plus one)
 				hipLaunchKernelGGL((k_deflate_dynamic<HD_L2_WIN_BITS, HD_L2_HASH_BITS, HD_L2_MIN_LEN, 0, 1, 0, 0, 0, 1>), dim3(cnt < 256u * 16u ? cnt : 256u * 16u), dim3(64), 0,
 						   st, h);
 				hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, emitted + (k - 2), cnt, 1u << 22, s.poison);

@@ -1135,9 +1135,19 @@ for frame in (0, 0x100):                                     # the throughput fo
     stored = 0
     for i in range(nb):
         m = bytes(out[i * 65536:i * 65536 + olen[i]])
-        assert zlib.decompress(m, -15) == bytes(data[i * blk:(i + 1) * blk]), i
+        assert zlib.decompress(m, -15) == bytes(data[i * blk:(i + 1) * blk]) and int(crc[i]) == zlib.crc32(bytes(data[i * blk:(i + 1) * blk])), i
         stored += len(m) > blk
     print("STORED", frame, stored)
+# ... and members longer than the ring (their filler stops with the parsers: the CRC of a given-up member is the emit kernel's own)
+nb2, blk2, slot2 = 6, 300000, 301056
+off2 = (np.arange(nb2, dtype=np.uint64) * blk2); ln2 = np.full(nb2, blk2, dtype=np.uint32)
+data2 = np.frombuffer(bytes(hdtest.synth().text_like(nb2 * blk2, seed=6)), dtype=np.uint8).copy()
+out2 = np.zeros(nb2 * slot2, dtype=np.uint8)
+r = L.hipdeflate_batch_deflate(p(data2), p(off2), p(ln2), nb2, 6, 0, p(out2), ctypes.c_uint64(slot2), slot2, p(olen), p(crc), p(st))
+assert r == 0 and not st[:nb2].any(), (r, st)
+for i in range(nb2):
+    m = bytes(out2[i * slot2:i * slot2 + olen[i]])
+    assert zlib.decompress(m, -15) == bytes(data2[i * blk2:(i + 1) * blk2]) and int(crc[i]) == zlib.crc32(bytes(data2[i * blk2:(i + 1) * blk2])), ("long", i)
 print("STALLS", L.hipdeflate_stall_count())
 ''' % (hdtest.ROOT, os.path.join(hdtest.ROOT, "tests"), so)
     p = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600)
