@@ -33,6 +33,12 @@
 
 namespace hd {
 
+#ifndef HD_WG_LDS_AT_ZERO
+#define HD_WG_LDS_AT_ZERO 1
+#endif
+#ifndef HD_WG_LDS_AT_ZERO_BASE
+#define HD_WG_LDS_AT_ZERO_BASE 16                /* (not 0: address 0 cast to a pointer is the null pointer to the compiler, and what is reached through it is dead code) */
+#endif
 constexpr uint32_t WG_NW = HD_WG_WAVES;
 constexpr uint32_t WG_NP = WG_NW - 1;            // parsers
 constexpr uint32_t WG_STEPS = HD_WG_CUT / 64;
@@ -143,7 +149,15 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 	WgLds *Lraw;
 	if constexpr (BESIDE) {
 		extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds_raw[];
+#if HD_WG_LDS_AT_ZERO
+		// (the kernel has no static LDS, so what it is given at launch starts at offset 0 of the workgroup's allocation, and the launch asks for
+		// HD_WG_LDS_AT_ZERO_BASE bytes more than the structure: it lies at that CONSTANT offset.  Through the symbol every address is
+		// `v_add_u32 v, 0, v` first -- the 0 being the symbol's value, which arrives too late to be folded: five vector instructions per step)
+		(void)wg_lds_raw;
+		Lraw = (WgLds *)(WG_LDS WgLds *)(uintptr_t)HD_WG_LDS_AT_ZERO_BASE;
+#else
 		Lraw = (WgLds *)wg_lds_raw;
+#endif
 	} else {
 		__shared__ WgLds Ls;
 		Lraw = &Ls;
@@ -599,6 +613,7 @@ void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hp
 // Gain: BGZF-sized blocks at level 6 +6.5 % (the parse runs 25 % slower beside the emit wavefronts, the emit kernel's own time is
 // gone); 1 MiB members gain nothing -- one wavefront needs 5 ms for a member, so the last members' emit sticks out behind the parse
 // by as much as the overlap saved -- and take the old order.
+constexpr size_t WG_LDS_DYNAMIC = sizeof(WgLds) + (HD_WG_LDS_AT_ZERO ? HD_WG_LDS_AT_ZERO_BASE : 0);     // what a BESIDE parse is launched with
 struct WgBeside {
 	hipStream_t side = nullptr;
 	hipEvent_t ready = nullptr, done = nullptr;
@@ -649,10 +664,10 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 		int dev = 0;
 		(void)hipGetDevice(&dev);
 		if (dev >= 0 && dev < 64 && !asked[dev]) {
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
-			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WgLds));
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_DYNAMIC);
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_DYNAMIC);
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_DYNAMIC);
+			(void)hipFuncSetAttribute((const void *)k_parse_wg<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_DYNAMIC);
 			asked[dev] = true;
 		}
 	}
@@ -751,28 +766,28 @@ inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
 		if (HD_WG_WAYS(level) == 4)
 			{
 			if (bs)
-				hipLaunchKernelGGL((k_parse_wg<4, 1, 1>), grid, block, sizeof(WgLds), st, s);
+				hipLaunchKernelGGL((k_parse_wg<4, 1, 1>), grid, block, WG_LDS_DYNAMIC, st, s);
 			else
 				hipLaunchKernelGGL((k_parse_wg<4, 1>), grid, block, 0, st, s);
 		}
 		else if (HD_WG_WAYS(level) == 2)
 			{
 			if (bs)
-				hipLaunchKernelGGL((k_parse_wg<2, 1, 1>), grid, block, sizeof(WgLds), st, s);
+				hipLaunchKernelGGL((k_parse_wg<2, 1, 1>), grid, block, WG_LDS_DYNAMIC, st, s);
 			else
 				hipLaunchKernelGGL((k_parse_wg<2, 1>), grid, block, 0, st, s);
 		}
 		else if (HD_WG_LAZY(level))
 			{
 			if (bs)
-				hipLaunchKernelGGL((k_parse_wg<1, 1, 1>), grid, block, sizeof(WgLds), st, s);
+				hipLaunchKernelGGL((k_parse_wg<1, 1, 1>), grid, block, WG_LDS_DYNAMIC, st, s);
 			else
 				hipLaunchKernelGGL((k_parse_wg<1, 1>), grid, block, 0, st, s);
 		}
 		else
 			{
 			if (bs)
-				hipLaunchKernelGGL((k_parse_wg<1, 0, 1>), grid, block, sizeof(WgLds), st, s);
+				hipLaunchKernelGGL((k_parse_wg<1, 0, 1>), grid, block, WG_LDS_DYNAMIC, st, s);
 			else
 				hipLaunchKernelGGL((k_parse_wg<1, 0>), grid, block, 0, st, s);
 		}
