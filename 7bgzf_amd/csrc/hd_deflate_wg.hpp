@@ -33,6 +33,11 @@
 
 namespace hd {
 
+#ifndef HD_WG_UNALIGNED_LDS
+#define HD_WG_UNALIGNED_LDS 0                    /* own and candidate bytes by ONE ds_read_b128 at a byte address (gfx950 reads LDS unaligned) instead of five dwords + four v_alignbyte */
+#endif
+struct __attribute__((packed, aligned(1))) wg_u4u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) wg_u2u { uint32_t x, y; };
 #ifndef HD_WG_LDS_AT_ZERO
 #define HD_WG_LDS_AT_ZERO 1
 #endif
@@ -326,9 +331,14 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 #pragma unroll
 			for (int t = 0; t < (int)WG_STEPS; t++) {
 				const uint32_t p = P0 + 64 * t + lane;
+#if HD_WG_UNALIGNED_LDS
+				const wg_u2u kv = *(const wg_u2u *)((const uint8_t *)L.ring32 + (p & (HD_WG_RING - 1)));
+				const uint32_t v = kv.x, vh = kv.y;
+#else
 				const uint32_t *q = L.ring32 + ((p & (HD_WG_RING - 1)) >> 2);
 				const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
 				const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, p), vh = __builtin_amdgcn_alignbyte(d2, d1, p);   // (v_alignbyte_b32 reads bits [1:0] of its shift: tools/isa_probe.hip)
+#endif
 				ha[t] = hash_slot_addr6(v, vh, hk);
 			}
 			// ---- the turn: 16 steps of buckets, in order --------------------------------------------------------------
@@ -392,11 +402,16 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				const uint32_t lanes = pend - S < 64 ? pend - S : 64;
 				const uint64_t lanem = lanes == 64 ? ~0ull : (1ull << lanes) - 1;
 				// own 16 bytes
+#if HD_WG_UNALIGNED_LDS
+				const wg_u4u ov = *(const wg_u4u *)((const uint8_t *)L.ring32 + (p & (HD_WG_RING - 1)));
+				const uint32_t o0 = ov.x, o1 = ov.y, o2 = ov.z, o3 = ov.w;
+#else
 				const uint32_t *q = L.ring32 + ((p & (HD_WG_RING - 1)) >> 2);
 				const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
 				const uint32_t sh = p;                           // (v_alignbyte_b32 reads bits [1:0] only)
 				const uint32_t o0 = __builtin_amdgcn_alignbyte(d1, d0, sh), o1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
 					       o2 = __builtin_amdgcn_alignbyte(d3, d2, sh), o3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+#endif
 				const uint64_t keyed = __ballot(p + HD_LAZY_KEY_BYTES <= n);
 				const uint32_t room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;  // in bits (keyed lanes: p < pend)
 				const uint32_t lim = min(p, (uint32_t)HD_WG_WINDOW);
@@ -425,11 +440,22 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 						asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(ea) : "v"(cw), "v"(kfffc));
 					}
 					const uint64_t ok = __ballot(bm1 < lim) & keyed;
+#if HD_WG_UNALIGNED_LDS
+					uint32_t eb;                                          // the entry as it is: a byte offset in the ring
+					if (k & 1)
+						asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(eb) : "v"(cw));
+					else
+						asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(eb) : "v"(cw));
+					(void)ea;
+					const wg_u4u cv = *(const wg_u4u *)((const uint8_t *)L.ring32 + eb);
+					const uint32_t x0 = cv.x ^ o0, x1 = cv.y ^ o1, x2 = cv.z ^ o2, x3 = cv.w ^ o3;
+#else
 					const uint32_t *c = (const uint32_t *)((const uint8_t *)L.ring32 + ea);
 					const uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
 					const uint32_t cs = (k & 1) ? cw >> 16 : cw;          // (v_alignbyte_b32 reads bits [1:0] of its shift)
 					const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, cs) ^ o0, x1 = __builtin_amdgcn_alignbyte(c2, c1, cs) ^ o1,
 						       x2 = __builtin_amdgcn_alignbyte(c3, c2, cs) ^ o2, x3 = __builtin_amdgcn_alignbyte(c4, c3, cs) ^ o3;
+#endif
 					const uint32_t m = wg_common_bits(x0, x1, x2, x3, room8, k96) >> 3;
 					const uint64_t better = __ballot(m > best) & ok;
 					best = sel(better, m, best);
