@@ -80,6 +80,9 @@ __device__ unsigned long long g_inf_cycles[8];       // [0] block headers + tabl
 #define HD_INF_OWNER 0       // 1: short matches copied by their own lanes (measured: 146 GB/s against 160 with the lane groups --
                              // sixteen ds_write_b8 per window and half cost the LDS path more than the vector units gained); 0: lane groups
 #endif
+#ifndef HD_INF_SPLIT_SRC
+#define HD_INF_SPLIT_SRC 1      // the lane-group passes read "ring byte, or flushed byte" as two typed loads (ds_read_u8 + a rare global_load_ubyte), not one flat load: +1.3 %
+#endif
 #ifndef HD_INF_ONEPERM
 #define HD_INF_ONEPERM 0     // 1: a lane-group pass pushes its owners' words with ONE ds_permute when no lane owns a match in both halves
                              // (round 5, measured: 159.8 / 164.7 / 115.9 GB/s against 161.6 / 166.7 / 117.3 -- the test and the second
@@ -779,9 +782,17 @@ __device__ __forceinline__ void inflate_stream(const InflateArgs &a, InfLdsT<RIN
 						const bool act = sub < ml;
 						// (the whole source in the ring or the whole source flushed: the same test as inr above)
 						const bool ringsrc = wend - (sp - sub) <= RING - 64;
+#if HD_INF_SPLIT_SRC
+						// (said with the address spaces: left generic, the compiler turns "ring byte, or the flushed byte where the source is far"
+						// into ONE flat_load_ubyte from a selected address -- every pass then goes through the flat path, LDS and memory counters both)
+						uint32_t v = *((const __attribute__((address_space(3))) uint8_t *)&L.ring[0] + (sp & (RING - 1)));
+						if (act && !ringsrc)
+							v = *((const __attribute__((address_space(1))) uint8_t *)dst + sp);
+#else
 						uint32_t v = L.ring[sp & (RING - 1)];
 						if (act && !ringsrc)
 							v = dst[sp];
+#endif
 						const uint32_t di = act ? (dp & (RING - 1)) : RING + lane;
 						if (HD_INF_DEFER && !pend) {
 							pend = true;
