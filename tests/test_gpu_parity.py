@@ -1069,6 +1069,43 @@ def test_workgroup_levels_span_of_sub_batches_whoever_stays(pkg):
     assert int(pkg.lib().hipdeflate_stall_count()) == s0
 
 
+def test_workgroup_levels_two_processes_on_one_card(pkg):
+    """Two processes on ONE device, both with launches that keep emit wavefronts resident beside their parse: the rule that decides who
+    stays looks at the CU's LDS (the three lowest blocks), which the two share, so a CU never holds more than three residents whoever
+    they belong to, and a process that finds the places taken runs its launches in the old order.  Both write the twin's bytes, neither
+    gives a block up, neither takes minutes."""
+    import subprocess
+    import sys
+    prog = r'''
+import sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hdtest
+pkg = hdtest.pkg()
+who = int(sys.argv[1])
+fq = bytes(hdtest.synth().fastq_like(6 << 20, seed=50 + who))
+n, bs = 1500, 65280
+offs = [((i * 4099) %% (len(fq) - bs)) & ~15 for i in range(n)]
+slot = int(pkg.lib().hipdeflate_bound(bs, 6))
+pkg.lib().hipdeflate_test_beside(3, 400)                   # (several sub-batches per launch: the gates too)
+t0 = time.time()
+for rep in range(6):
+    members, crc, st = pkg.batch_deflate(fq, offs, [bs] * n, 6, pkg.FRAME_RAW, slot=slot)
+    assert all(int(x) == 0 for x in st)
+    for i in (0, 1, 399, 400, 401, 799, 1199, 1499):
+        rc, tw = hdtest.codec_twin(fq[offs[i]:offs[i] + bs], 6, cap=slot)
+        assert rc == 0 and members[i] == tw, (rep, i)
+back = pkg.batch_inflate(members, [bs] * n)[0]
+assert all(back[i] == fq[offs[i]:offs[i] + bs] for i in range(n))
+assert pkg.lib().hipdeflate_stall_count() == 0
+print("ok %%.2f" %% (time.time() - t0))
+''' % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    ps = [subprocess.Popen([sys.executable, "-c", prog, str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    outs = [p.communicate(timeout=400) for p in ps]
+    for p, (out, err) in zip(ps, outs):
+        assert p.returncode == 0 and out.startswith("ok"), (out[-300:], err[-800:])
+        assert float(out.split()[1]) < 60.0, out
+
+
 def test_workgroup_levels_where_kernels_run_one_at_a_time(pkg):
     """The emit kernel beside the parse needs both kernels on the device at once.  A process whose kernels run one at a time
     (HIP_LAUNCH_BLOCKING=1; rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION) must get the old order -- the same bytes, no
