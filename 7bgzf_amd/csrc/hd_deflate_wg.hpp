@@ -624,22 +624,24 @@ __global__ __launch_bounds__(64) void k_gate(uint32_t *arrived, uint32_t want, u
 
 void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hpp
 
-// BESIDE (round 5, its last hours).  The parse holds a CU with ONE workgroup (131 KB of its 160 KB of LDS, sixteen wavefronts of 80
-// registers); the emit-only kernel is one wavefront per member with 9.6 KB of LDS and 121 registers.  One behind the other, the emit
-// kernel was a quarter of these levels' time on its own.  Now the emit kernel of a sub-batch is launched FIRST, on a second stream, with
-// 768 wavefronts that stay (three to a CU -- what a parse workgroup leaves of a CU's LDS and of a SIMD's registers holds:
-// tools/coresidency_probe.hip, tools/coresidency_real.hip); a one-wavefront gate on the caller's stream waits until they are resident;
-// the parse follows.  Every parse workgroup writes its records THROUGH its XCD's L2 (sc1 stores: the reader sits behind another
-// XCD's L2; a release fence instead writes the whole L2 back, a million times per sub-batch of BGZF blocks) and raises the block's flag
-// (an RMW, a flag per 128-byte line) once its stores are acknowledged; emit wavefronts take blocks from a counter, wait for the block's
-// flag with sparse RMW polls (never a cached copy), forget their XCD's clean L2 lines (an acquire at agent scope) and write the
-// member.  Behind the parse the same kernel runs once more at full occupancy for whatever has not been taken.  The bytes do not depend
-// on any of this.  What it needed, found the hard way (profiles/r05_wg_beside.txt): the parse's LDS passed at LAUNCH -- declared
-// statically, the compiler pads the kernel's registers so that nothing else fits the SIMD.
-// Gain: BGZF-sized blocks at level 6 +6.5 % (the parse runs 25 % slower beside the emit wavefronts, the emit kernel's own time is
-// gone); 1 MiB members gain nothing -- one wavefront needs 5 ms for a member, so the last members' emit sticks out behind the parse
-// by as much as the overlap saved -- and take the old order.
-constexpr size_t WG_LDS_DYNAMIC = sizeof(WgLds) + (HD_WG_LDS_AT_ZERO ? HD_WG_LDS_AT_ZERO_BASE : 0);     // what a BESIDE parse is launched with
+// BESIDE (round 5, its last hours; DESIGN.md 4.2c, profiles/r05_wg_beside.txt).  The parse holds a CU with ONE workgroup (131 KB of its
+// 160 KB of LDS, sixteen wavefronts of 96 registers); the emit-only kernel is one wavefront per member with 9.6 KB of LDS and <= 128
+// registers.  One behind the other, the emit kernel was a quarter of these levels' time on its own.  Now the emit kernel is launched
+// FIRST, on a second stream of the low priority class, ONCE per launch: 1536 candidate wavefronts of which every CU keeps the ones in its
+// three lowest LDS blocks, one per SIMD (what a parse workgroup leaves of a CU's LDS and of a SIMD's registers holds:
+// tools/coresidency_probe.hip, coresidency_real.hip, beside_filter_probe.hip); a one-wavefront gate on the caller's stream waits until
+// the candidates have decided; the parses follow, sub-batch by sub-batch.  Every parse workgroup writes its records THROUGH its XCD's
+// L2 (sc1 stores: the reader sits behind another XCD's L2; a release fence instead writes the whole L2 back, a million times per
+// sub-batch of BGZF blocks) and raises the block's flag (an RMW, a flag per 128-byte line) once its stores are acknowledged; emit
+// wavefronts take blocks from a counter per sub-batch, wait for the block's flag with sparse RMW polls (never a cached copy), read the
+// records with loads that are coherent at the device's level themselves (sc1) and write the member.  SPAN: the records of the
+// sub-batches alternate between two buffers; the parse of sub-batch k + 2 follows a launch of the emit kernel for what is left of
+// sub-batch k and a gate on its members.  Behind the last parse the same kernel runs once more at full occupancy for whatever has not
+// been taken.  The bytes do not depend on any of this.  What it needed, found the hard way: the parse's LDS passed at LAUNCH --
+// declared statically, the compiler pads the kernel's registers so that nothing else fits the SIMD -- and then at a CONSTANT offset
+// of that allocation (HD_WG_LDS_AT_ZERO_BASE), or every LDS address costs an add.
+// Gain: config 5 (1 MiB members, level 6) 117.6 -> 131.8 GB/s, BGZF-sized blocks at level 6 115.6 -> 125.1, level 3 155 -> 175; the parse
+// runs a fifth slower beside the emit wavefronts, the emit kernel's own time is gone.
 struct WgBeside {
 	hipStream_t side = nullptr;
 	hipEvent_t ready = nullptr, done = nullptr;
@@ -677,9 +679,9 @@ struct WgBeside {
 #define HD_BESIDE_PARSE_PRIO 0                   // experiment switches of tools/r05_prio.sh (issue priority of the two kernels' wavefronts, emit wavefronts kept per CU)
 #endif
 constexpr uint32_t WG_BESIDE_WAVES = 768;        // three per CU ...
-constexpr uint32_t WG_BESIDE_CANDIDATES = 1536;  // ... kept from this many that are launched (k_deflate_dynamic<..., BESIDE>: every CU keeps its first three)
+constexpr uint32_t WG_BESIDE_CANDIDATES = 1536;  // ... kept from this many that are launched (k_deflate_dynamic<..., BESIDE>: a CU keeps those in its three lowest LDS blocks)
 constexpr uint32_t WG_BESIDE_MIN = 512;          // blocks in a sub-batch below which the emit kernel simply follows the parse
-constexpr uint32_t WG_BESIDE_MAX_BLOCK = 2097152; // ... and the longest block it is worth it for (see above)
+constexpr uint32_t WG_BESIDE_MAX_BLOCK = 2097152; // ... and the longest block it is used for (one wavefront writes a member: 5 ms per MiB is the launch's tail)
 
 // blocks [first, first + count) of a sub-batch: the workgroup parse, then the emit-only kernel over its records
 inline void launch_wg(const DeflateArgs &a, int level, hipStream_t st)
