@@ -642,6 +642,7 @@ void launch_emit_wg(const DeflateArgs &s, hipStream_t st);      // hd_emit_wg.hp
 // of that allocation (HD_WG_LDS_AT_ZERO_BASE), or every LDS address costs an add.
 // Gain: config 5 (1 MiB members, level 6) 117.6 -> 131.8 GB/s, BGZF-sized blocks at level 6 115.6 -> 125.1, level 3 155 -> 175; the parse
 // runs a fifth slower beside the emit wavefronts, the emit kernel's own time is gone.
+constexpr size_t WG_LDS_DYNAMIC = sizeof(WgLds) + (HD_WG_LDS_AT_ZERO ? HD_WG_LDS_AT_ZERO_BASE : 0);     // what a BESIDE parse is launched with
 struct WgBeside {
 	hipStream_t side = nullptr;
 	hipEvent_t ready = nullptr, done = nullptr;
