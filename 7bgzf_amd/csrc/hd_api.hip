@@ -644,7 +644,11 @@ static int batch_deflate_dev_impl(const void *in, const void *in_off, const void
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
 		if (level >= HD_WG_LEVEL && !a.lat && beside_allowed() && g.beside.init() == 0) {
 			a.beside = &g.beside;
-			a.beside_keep = g_test_beside_keep;
+			// (emit wavefronts a CU keeps: three -- but two beside the four-way parse of BGZF-sized blocks, where the third costs the parse
+			// more than it takes off the launch's end: encode_l6 123.8 -> 125.8 GB/s, 1 MiB members the other way, 131.1 -> 128.5;
+			// tools/r05_keep_ab.sh)
+			const uint32_t keep = (HD_WG_WAYS(level) == 4 && a.split_max <= 65536) ? 2u : 3u;
+			a.beside_keep = g_test_beside_keep < keep ? g_test_beside_keep : keep;
 		}
 		r = launch_deflate(a, level, (hipStream_t)stream);
 		if (!r) {
