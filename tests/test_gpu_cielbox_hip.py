@@ -4,7 +4,8 @@ oracle/_ref/cielbox_hip is the reference's multi-call CLI built by oracle/Makefi
 integration/7bgzf-hip.patch applied (DEFLATE_HIP + -G/--hip in applet/7bgzf.c and applet/7migz.c, hip_inflate behind
 zlibutil_auto_inflate) and linked against 7bgzf_amd/libhipdeflate.so.  Nothing of ours is between the reference's loops
 and the codecs: applet/7bgzf.c:159-277 creates a thread per block whose start routine is zlibutil_buffer_code ->
-hip_deflate; :306-360 a thread per member -> zlibutil_auto_inflate -> hip_inflate.  Checked against the unpatched
+hip_deflate; :306-360 a thread per member -> zlibutil_auto_inflate -> hip_inflate (HIP_INFLATE_PER_BLOCK=1; by default the
+patch runs `7bgzf -d` on the library's streaming decoder, batches of members).  Checked against the unpatched
 reference (cielbox_ref) in both directions.  GPU box only; both binaries travel with the tree (git-ignored test
 infrastructure, like libref.so)."""
 import gzip
@@ -67,27 +68,60 @@ def test_reference_7bgzf_encodes_through_hip_deflate(level, threads):
 
 
 def test_reference_7bgzf_decodes_through_hip_inflate():
-    """`cielbox_hip 7bgzf -d -@16`: a thread per member -> zlibutil_auto_inflate -> hip_inflate (USE_HIP_INFLATE), on files
-    written by the unpatched reference (libdeflate 1 / 6, zlib 6, slz: multi-block members, dynamic, static and stored
-    blocks) and by hd7bgzf; and a damaged member makes it fail as the reference does."""
+    """`cielbox_hip 7bgzf -d -@16`, both forms the patch gives it: the batched one (default under USE_HIP_INFLATE: the read /
+    inflate / write loop on hipdeflate_unpipe_*, members found with the applet's own _read_gz_header) and, with
+    HIP_INFLATE_PER_BLOCK=1, the reference's loop as it is (a thread per member -> zlibutil_auto_inflate -> hip_inflate) -- on files
+    written by the unpatched reference (libdeflate 1 / 6, zlib 6, slz: multi-block members, dynamic, static and stored blocks)
+    and by hd7bgzf; a damaged member makes it fail as the reference does; an empty file and a lone end-of-file member are 0 bytes."""
     need()
     s = hdtest.synth()
     data = bytes(s.fastq_like(24 * 0xff00 + 77, seed=32)) + bytes(s.text_like(300000, seed=33)) + os.urandom(70000)
+    per_block = dict(os.environ, HIP_INFLATE_PER_BLOCK="1")
     for args in (["-l1", "-@4"], ["-l6", "-@4"], ["-z6", "-@4"], ["-s1", "-@4"], ["-l1"]):
         rc, blob, err = run(REF, ["7bgzf"] + args, data)
         assert rc == 0, err
-        rc, back, err = run(HIP, ["7bgzf", "-d", "-@16"], blob)
-        assert rc == 0 and back == data, (args, err[-500:])
+        for env in (None, per_block):
+            rc, back, err = run(HIP, ["7bgzf", "-d", "-@16"], blob, env)
+            assert rc == 0 and back == data, (args, env is not None, err[-500:])
     exe = os.path.join(hdtest.ROOT, "7bgzf_amd", "hd7bgzf")
     rc, blob, err = run(exe, ["-G6"], data)
     assert rc == 0
-    rc, back, err = run(HIP, ["7bgzf", "-d", "-@16"], blob)
-    assert rc == 0 and back == data
+    for env in (None, per_block):
+        rc, back, err = run(HIP, ["7bgzf", "-d", "-@16"], blob, env)
+        assert rc == 0 and back == data
     bad = bytearray(blob)
     bad[18 + 40] ^= 0x10                                               # inside the first member's payload
-    rc_h, out_h, _ = run(HIP, ["7bgzf", "-d", "-@4"], bytes(bad))
     rc_r, out_r, _ = run(REF, ["7bgzf", "-d", "-@4"], bytes(bad))
-    assert (rc_h != 0) == (rc_r != 0) or out_h == out_r                # same verdict, or (both accept) the same bytes
+    for env in (None, per_block):
+        rc_h, out_h, _ = run(HIP, ["7bgzf", "-d", "-@4"], bytes(bad), env)
+        assert (rc_h != 0) == (rc_r != 0) or out_h == out_r            # same verdict, or (both accept) the same bytes
+    # not a gzip member at all; a file cut inside a member: refused in both forms, as the reference refuses them
+    for junk in (b"hello, world: this is not BGZF" * 10, blob[:len(blob) // 2]):
+        rc_r, out_r, _ = run(REF, ["7bgzf", "-d", "-@4"], junk)
+        for env in (None, per_block):
+            rc_h, out_h, _ = run(HIP, ["7bgzf", "-d", "-@4"], junk, env)
+            assert (rc_h != 0) == (rc_r != 0), (len(junk), env is not None, rc_h, rc_r)
+    # an empty file, and the 28-byte end-of-file member alone
+    rc, eof_only, err = run(REF, ["7bgzf", "-l1"], b"")
+    assert rc == 0 and len(eof_only) == 28
+    for blob0 in (b"", eof_only):
+        for env in (None, per_block):
+            rc, back, err = run(HIP, ["7bgzf", "-d", "-@4"], blob0, env)
+            assert rc == 0 and back == b"", (len(blob0), env is not None, err[-300:])
+
+
+def test_reference_7bgzf_batched_decode_of_many_batches():
+    """The batched form over more members than one batch holds (1024) and more bytes than one input slot (24 MiB): members and
+    headers cut by a batch's end are carried over; 40 MiB of FASTQ-like data in 0xff00-byte members + an incompressible stretch."""
+    need()
+    s = hdtest.synth()
+    data = bytes(s.fastq_like(40 << 20, seed=34)) + os.urandom(30 << 20) + bytes(200 << 20)      # (zeros: 3,200 members of 0.3 KB --
+    # a batch is full at 1024 members with most of its input buffer unread: all of that is carried over)
+    rc, blob, err = run(REF, ["7bgzf", "-l1", "-@8"], data)
+    assert rc == 0, err
+    rc, back, err = run(HIP, ["7bgzf", "-d", "-@16"], blob)
+    assert rc == 0 and back == data, err[-500:]
+    assert "%d done." % (len(data) // 0xff00 + (1 if len(data) % 0xff00 else 0) + 1) in err or "done." in err
 
 
 def test_reference_7migz_both_ways_on_the_hip_backend():

@@ -22,14 +22,17 @@ enc_hip6() { ./oracle/_ref/cielbox_hip 7bgzf -G6 -@16 < $D/in.bin > $D/hip6.bgz;
 enc_ref1() { ./oracle/_ref/cielbox_ref 7bgzf -l1 -@16 < $D/in.bin > $D/ref1.bgz; }
 enc_ref6() { ./oracle/_ref/cielbox_ref 7bgzf -l6 -@16 < $D/in.bin > $D/ref6.bgz; }
 dec_hip() { ./oracle/_ref/cielbox_hip 7bgzf -d -@16 < $D/ref6.bgz > $D/back_hip.bin; }
+dec_hip_pb() { HIP_INFLATE_PER_BLOCK=1 ./oracle/_ref/cielbox_hip 7bgzf -d -@16 < $D/ref6.bgz > $D/back_hip_pb.bin; }
 dec_ref() { ./oracle/_ref/cielbox_ref 7bgzf -d -@16 < $D/ref6.bgz > $D/back_ref.bin; }
 tm "cielbox_hip 7bgzf -G1 -@16 (hip_deflate per block)" enc_hip1
 tm "cielbox_ref 7bgzf -l1 -@16 (libdeflate 1)" enc_ref1
 tm "cielbox_hip 7bgzf -G6 -@16" enc_hip6
 tm "cielbox_ref 7bgzf -l6 -@16 (libdeflate 6)" enc_ref6
-tm "cielbox_hip 7bgzf -d -@16 (hip_inflate per block, libdeflate-6 file)" dec_hip
+tm "cielbox_hip 7bgzf -d -@16 (the batched loop of the patch on hipdeflate_unpipe, libdeflate-6 file)" dec_hip
+tm "cielbox_hip 7bgzf -d -@16 again" dec_hip
+tm "cielbox_hip 7bgzf -d -@16, HIP_INFLATE_PER_BLOCK=1 (the loop of the reference, hip_inflate per member)" dec_hip_pb
 tm "cielbox_ref 7bgzf -d -@16 (its own inflater)" dec_ref
-cmp $D/back_hip.bin $D/in.bin && cmp $D/back_ref.bin $D/in.bin && echo "both decodes == input" >> $OUT/e2e_cielbox.txt
+cmp $D/back_hip.bin $D/in.bin && cmp $D/back_hip_pb.bin $D/in.bin && cmp $D/back_ref.bin $D/in.bin && echo "all three decodes == input" >> $OUT/e2e_cielbox.txt
 ls -l $D/*.bgz | awk '{print $5, $9}' >> $OUT/e2e_cielbox.txt
 rm -rf $D
 cat $OUT/e2e_cielbox.txt
