@@ -35,13 +35,13 @@ def run(exe, args, data, env=None):
 
 @pytest.mark.parametrize("level,threads", [(1, 16), (6, 16), (2, 1)])
 def test_reference_7bgzf_encodes_through_hip_deflate(level, threads):
-    """`cielbox_hip 7bgzf -G<level> -@16`: the reference's thread-per-block loop on hip_deflate.  Its file is BGZF that
-    gzip, the unpatched reference and hd7bgzf all read; every member's payload is what the per-block codec gives for
-    that block (the latency form's twin), i.e. the reference framed our bytes untouched."""
+    """`cielbox_hip 7bgzf -G<level> -@16` with HIP_DEFLATE_PER_BLOCK=1: the reference's thread-per-block loop on hip_deflate.
+    Its file is BGZF that gzip, the unpatched reference and hd7bgzf all read; every member's payload is what the per-block
+    codec gives for that block (the latency form's twin), i.e. the reference framed our bytes untouched."""
     need()
     pkg = hdtest.pkg()
     data = bytes(hdtest.synth().fastq_like(40 * 0xff00 + 1234, seed=31))
-    rc, blob, err = run(HIP, ["7bgzf", "-G%d" % level, "-@%d" % threads], data)
+    rc, blob, err = run(HIP, ["7bgzf", "-G%d" % level, "-@%d" % threads], data, dict(os.environ, HIP_DEFLATE_PER_BLOCK="1"))
     assert rc == 0, err
     assert "compression level = %d (hip)" % level in err
     assert blob.endswith(pkg.BGZF_EOF)
@@ -65,6 +65,32 @@ def test_reference_7bgzf_encodes_through_hip_deflate(level, threads):
         rc, ref1, err = run(REF, ["7bgzf", "-l1", "-@%d" % threads], data)
         assert rc == 0, err
         assert len(blob) <= 1.04 * len(ref6) and len(blob) < len(ref1), (len(blob), len(ref6), len(ref1))
+
+
+@pytest.mark.parametrize("level", [1, 2, 6])
+def test_reference_7bgzf_encodes_through_the_batch_pipeline(level):
+    """`cielbox_hip 7bgzf -G<level>` as the patch runs it by default: `_compress` on the library's streaming encoder
+    (_compress_hip: 0xff00-byte blocks read into hipdeflate_pipe's pinned buffer, batches of 1024, the members back as one run).
+    The file is BGZF that gzip, the unpatched reference and hd7bgzf read; from level 3 on it is byte for byte the file of the
+    thread-per-block loop (one codec per level); more blocks than a batch holds, a ragged last block, an empty input."""
+    need()
+    pkg = hdtest.pkg()
+    data = bytes(hdtest.synth().fastq_like(2500 * 0xff00 + 4321, seed=35))          # three batches, the last block short
+    rc, blob, err = run(HIP, ["7bgzf", "-G%d" % level, "-@16"], data)
+    assert rc == 0, err[-500:]
+    assert "compression level = %d (hip)" % level in err and "2501 done." in err
+    assert blob.endswith(pkg.BGZF_EOF)
+    rc, back, err = run(REF, ["7bgzf", "-d", "-@8"], blob)
+    assert rc == 0 and back == data, err[-300:]
+    assert pkg.bgzf_decompress_bytes(blob) == data
+    members = pkg.bgzf_scan(blob)
+    assert len(members) == 2502 and all(isz == 0xff00 for (_, _, isz) in members[:2500]) and members[2500][2] == 4321
+    if level >= 3:
+        rc, blob_pb, err = run(HIP, ["7bgzf", "-G%d" % level, "-@16"], data[:300 * 0xff00], dict(os.environ, HIP_DEFLATE_PER_BLOCK="1"))
+        rc2, blob_b, err2 = run(HIP, ["7bgzf", "-G%d" % level, "-@16"], data[:300 * 0xff00])
+        assert rc == 0 and rc2 == 0 and blob_pb == blob_b
+    rc, blob0, err = run(HIP, ["7bgzf", "-G%d" % level], b"")
+    assert rc == 0 and blob0 == pkg.BGZF_EOF, (len(blob0), err[-200:])
 
 
 def test_reference_7bgzf_decodes_through_hip_inflate():
