@@ -151,22 +151,44 @@ def test_reference_7bgzf_batched_decode_of_many_batches():
 
 
 def test_reference_7migz_both_ways_on_the_hip_backend():
-    """`cielbox_hip 7migz -G6 -b1024` (config 5's container through the reference's own loop) and `7migz -d` on it and on
-    the unpatched reference's file."""
+    """`cielbox_hip 7migz -G6 -b1024` (config 5's container) and `7migz -d` on it and on the unpatched reference's file, in both
+    forms the patch gives the applet: on the library's streaming encoder / decoder (default: batches of blocks / members), and
+    with HIP_DEFLATE_PER_BLOCK=1 / HIP_INFLATE_PER_BLOCK=1 the reference's own thread-per-block loops on hip_deflate / hip_inflate.
+    The two encoders write the same file (one codec per level); a -b64 file of more members than a batch holds; an empty input."""
     need()
-    data = bytes(hdtest.synth().text_like(3 * (1 << 20) + 4242, seed=34))
-    rc, blob, err = run(HIP, ["7migz", "-G6", "-b1024", "-@3"], data)
-    assert rc == 0, err
-    assert blob[:16] == bytes.fromhex("1f8b08040000000000ff08004d5a0400")
-    assert gzip.decompress(blob) == data
-    rc, back, err = run(REF, ["7migz", "-d"], blob)
-    assert rc == 0 and back == data, err
-    rc, back, err = run(HIP, ["7migz", "-d", "-@3"], blob)
-    assert rc == 0 and back == data, err
+    data = bytes(hdtest.synth().text_like(5 * (1 << 20) + 4242, seed=34))
+    per_block = dict(os.environ, HIP_DEFLATE_PER_BLOCK="1", HIP_INFLATE_PER_BLOCK="1")
+    blobs = []
+    for env in (None, per_block):
+        rc, blob, err = run(HIP, ["7migz", "-G6", "-b1024", "-@3"], data, env)
+        assert rc == 0, err
+        assert blob[:16] == bytes.fromhex("1f8b08040000000000ff08004d5a0400")
+        assert gzip.decompress(blob) == data
+        rc, back, err = run(REF, ["7migz", "-d"], blob)
+        assert rc == 0 and back == data, err
+        blobs.append(blob)
+    assert blobs[0] == blobs[1]
     rc, blob_ref, err = run(REF, ["7migz", "-l6", "-b1024"], data)
     assert rc == 0
-    rc, back, err = run(HIP, ["7migz", "-d", "-@3"], blob_ref)
-    assert rc == 0 and back == data, err
+    for env in (None, per_block):
+        for b in (blobs[0], blob_ref):
+            rc, back, err = run(HIP, ["7migz", "-d", "-@3"], b, env)
+            assert rc == 0 and back == data, (env is not None, err[-300:])
+    # more members than a batch of the decoder holds (1024), blocks of 64 KiB: 80 MiB + a ragged end
+    big = bytes(hdtest.synth().fastq_like(80 << 20, seed=36)) + b"tail"
+    rc, blob, err = run(HIP, ["7migz", "-G3", "-b64", "-@8"], big)
+    assert rc == 0 and "1281 done." in err, err[-300:]
+    rc, back, err = run(REF, ["7migz", "-d", "-@8"], blob)
+    assert rc == 0 and back == big
+    rc, back, err = run(HIP, ["7migz", "-d", "-@8"], blob)
+    assert rc == 0 and back == big, err[-300:]
+    rc, blob0, err = run(HIP, ["7migz", "-G6", "-b1024"], b"")
+    assert rc == 0 and blob0 == b""
+    rc, back, err = run(HIP, ["7migz", "-d"], b"")
+    assert rc == 0 and back == b""
+    rc_r, _, _ = run(REF, ["7migz", "-d"], b"this is not MiGz" * 20)
+    rc_h, _, _ = run(HIP, ["7migz", "-d"], b"this is not MiGz" * 20)
+    assert (rc_r != 0) == (rc_h != 0)
 
 
 def test_reference_on_two_device_contexts():
