@@ -83,9 +83,15 @@ struct Buf {
 		if (n <= cap)
 			return 0;
 		void *old = p;
+		const size_t old_cap = cap;
 		p = nullptr;
 		cap = 0;
 		const int r = reserve(n);
+		if (r) {                                   // (nothing changed: the caller may settle for less -- batch_deflate_dev_impl)
+			p = old;
+			cap = old_cap;
+			return r;
+		}
 		if (old)
 			retired.push_back(old);
 		return r;
@@ -634,15 +640,22 @@ static int batch_deflate_dev_impl(const void *in, const void *in_off, const void
 		// token slabs of the dynamic levels, segment slots of large blocks: library-owned, grow-only
 		std::lock_guard<std::mutex> lk(g.mu_dev);
 		// (a re-allocation must not pull the rug from under launches in flight: the old scratch stays alive)
-		if (g.d_tok.grow_keep_old(need))
-			return HD_E_NOMEM;
+		bool beside_fits = true;
+		if (g.d_tok.grow_keep_old(need)) {
+			// (what the emit kernel BESIDE the parse adds -- a second buffer of records, the flag lines -- is an option, not a need:
+			// without it the launch runs in the old order)
+			const uint64_t extra = (level >= HD_WG_LEVEL && !a.lat) ? hd::wg_beside_bytes(nblocks, a.split_max) : 0;
+			if (!extra || extra >= need || g.d_tok.grow_keep_old(need - extra))
+				return HD_E_NOMEM;
+			beside_fits = false;
+		}
 		a.scratch = (uint8_t *)g.d_tok.p;
 		// the slabs are shared by every launch: launches on different streams take turns
 		if (!g.ev_tok)
 			HD_CHECK(hipEventCreateWithFlags(&g.ev_tok, hipEventDisableTiming));
 		if (g.tok_used && g.st_tok != (hipStream_t)stream)          // same stream: already in order
 			HD_CHECK(hipStreamWaitEvent((hipStream_t)stream, g.ev_tok, 0));
-		if (level >= HD_WG_LEVEL && !a.lat && beside_allowed() && g.beside.init() == 0) {
+		if (level >= HD_WG_LEVEL && !a.lat && beside_fits && beside_allowed() && g.beside.init() == 0) {
 			a.beside = &g.beside;
 			// (emit wavefronts a CU keeps: three -- but two beside the four-way parse of BGZF-sized blocks, where the third costs the parse
 			// more than it takes off the launch's end: encode_l6 123.8 -> 125.8 GB/s, 1 MiB members the other way, 131.1 -> 128.5;
