@@ -127,6 +127,12 @@ def test_reference_7bgzf_decodes_through_hip_inflate():
         for env in (None, per_block):
             rc_h, out_h, _ = run(HIP, ["7bgzf", "-d", "-@4"], junk, env)
             assert (rc_h != 0) == (rc_r != 0), (len(junk), env is not None, rc_h, rc_r)
+    # a member whose ISIZE says 3 GiB (no BGZF member does): refused at once in the batched form, whatever the per-member loop makes of it
+    liar = bytearray(blob)
+    first_len = int.from_bytes(blob[16:18], "little") + 1
+    liar[first_len - 4:first_len] = (3 << 30).to_bytes(4, "little")
+    rc_h, out_h, err_h = run(HIP, ["7bgzf", "-d", "-@4"], bytes(liar))
+    assert rc_h != 0 and "corrupted" in err_h, (rc_h, err_h[-200:])
     # an empty file, and the 28-byte end-of-file member alone
     rc, eof_only, err = run(REF, ["7bgzf", "-l1"], b"")
     assert rc == 0 and len(eof_only) == 28
