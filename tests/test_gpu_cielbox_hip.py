@@ -156,6 +156,39 @@ def test_reference_7bgzf_batched_decode_of_many_batches():
     assert "%d done." % (len(data) // 0xff00 + (1 if len(data) % 0xff00 else 0) + 1) in err or "done." in err
 
 
+def test_reference_7bgzf_batch_edges():
+    """The batched loops at their edges: inputs of 1 byte, a block minus / exactly / plus one byte, exactly the 1024 blocks of a
+    batch and one byte more; a stored (incompressible) file whose members fill the decoder's 24 MiB input slot to within a few
+    bytes of its end -- the member the slot cuts is carried into the next batch whole."""
+    need()
+    rng_bytes = os.urandom(1 << 20)
+    s = hdtest.synth()
+    fq = bytes(s.fastq_like(1024 * 0xff00 + 1, seed=37))
+    for n in (1, 0xff00 - 1, 0xff00, 0xff00 + 1, 3 * 0xff00, 1024 * 0xff00 - 1, 1024 * 0xff00, 1024 * 0xff00 + 1):
+        data = fq[:n]
+        rc, blob, err = run(HIP, ["7bgzf", "-G1", "-@4"], data)
+        assert rc == 0, (n, err[-300:])
+        assert gzip.decompress(blob) == data, n
+        if n % 0xff00 == 0 or n % 0xff00 >= 64:      # (the reference's reader takes 64 bytes per header: a tiny last member -- its own
+            # encoder writes the same one -- is "too big" a header interval for it: applet/7bgzf.c:321-324)
+            rc, back, err = run(REF, ["7bgzf", "-d", "-@4"], blob)
+            assert rc == 0 and back == data, n
+        rc, back, err = run(HIP, ["7bgzf", "-d", "-@4"], blob)
+        assert rc == 0 and back == data, (n, err[-300:])
+    # incompressible members: 0xff00 input bytes -> 65,311-byte members (18 + 5 + 65280 + 8); 385 of them are 25,144,735 bytes,
+    # the slot holds 25,165,824: every prefix length around the slot's end cuts the 386th member somewhere else
+    for extra in (0, 1, 17, 18, 19, 30000, 65310, 65311, 65312):
+        data = (rng_bytes * 26)[:385 * 0xff00 + 0xff00 + 40000]
+        rc, blob, err = run(REF, ["7bgzf", "-l1", "-@4"], data)
+        assert rc == 0
+        # (a junk-free way to move the cut: drop `extra` bytes worth of leading members is not possible -- so vary the data length instead)
+        data2 = data[:len(data) - extra]
+        rc, blob2, err = run(REF, ["7bgzf", "-l1", "-@4"], data2)
+        assert rc == 0
+        rc, back, err = run(HIP, ["7bgzf", "-d", "-@4"], blob2)
+        assert rc == 0 and back == data2, (extra, err[-300:])
+
+
 def test_reference_7migz_both_ways_on_the_hip_backend():
     """`cielbox_hip 7migz -G6 -b1024` (config 5's container) and `7migz -d` on it and on the unpatched reference's file, in both
     forms the patch gives the applet: on the library's streaming encoder / decoder (default: batches of blocks / members), and
