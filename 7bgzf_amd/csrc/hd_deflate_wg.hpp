@@ -33,6 +33,9 @@
 
 namespace hd {
 
+#ifndef HD_WG_UNIFORM_EDGES
+#define HD_WG_UNIFORM_EDGES 1
+#endif
 #ifndef HD_WG_UNALIGNED_LDS
 #define HD_WG_UNALIGNED_LDS 0                    /* own and candidate bytes by ONE ds_read_b128 at a byte address (gfx950 reads LDS unaligned) instead of five dwords + four v_alignbyte */
 #endif
@@ -412,9 +415,26 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				const uint32_t o0 = __builtin_amdgcn_alignbyte(d1, d0, sh), o1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
 					       o2 = __builtin_amdgcn_alignbyte(d3, d2, sh), o3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
 #endif
+#if HD_WG_UNIFORM_EDGES
+				// (two per-lane values that are the same in every lane but at a block's edges -- its last positions, a piece's last
+				// step: decided by the scalar unit, the vector instructions only where they differ)
+				// (the empty asm statements: left to itself the compiler computes both sides and selects)
+				uint64_t keyed = ~0ull;
+				if (S + 63 + HD_LAZY_KEY_BYTES > n) {
+					keyed = __ballot(p + HD_LAZY_KEY_BYTES <= n);
+					asm volatile("" : "+s"(keyed));
+				}
+				uint32_t room8 = (uint32_t)HD_WG_VCAP << 3;                      // in bits (keyed lanes: p < pend)
+				if (S + 63 + HD_WG_VCAP > pend) {
+					room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;
+					asm volatile("" : "+v"(room8));
+				}
+				const uint32_t lim = min(p, (uint32_t)HD_WG_WINDOW);              // (one instruction either way: no branch for it)
+#else
 				const uint64_t keyed = __ballot(p + HD_LAZY_KEY_BYTES <= n);
 				const uint32_t room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;  // in bits (keyed lanes: p < pend)
 				const uint32_t lim = min(p, (uint32_t)HD_WG_WINDOW);
+#endif
 				// the byte before (runs; only inside the step): as long as the own bytes repeat it
 				uint32_t best, dm1 = 0;                         // the best candidate's length, its distance - 1
 				{
