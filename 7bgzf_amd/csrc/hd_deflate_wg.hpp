@@ -438,7 +438,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				// the byte before (runs; only inside the step): as long as the own bytes repeat it
 				uint32_t best, dm1 = 0;                         // the best candidate's length, its distance - 1
 				{
-					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+					// (bound_ctrl: the lane without a neighbour reads 0 -- said with an old value of 0 instead, every step pays a v_mov for it)
+					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 					const uint32_t sp = __builtin_amdgcn_perm(prev, prev, 0u);      // its first byte, four times
 					const uint32_t m = wg_common_bits(o0 ^ sp, o1 ^ sp, o2 ^ sp, o3 ^ sp, room8, k96) >> 3;
 					best = sel(keyed & ~1ull, m, 0u);
@@ -487,8 +488,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				// ---- the lazy rule on the lane to the right (deflate_compress.c:2723-2726, lengths capped at 16) ------
 				uint64_t defer = 0;
 				if (LAZY) {
-					const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-					const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)dist, 0x130, 0xf, 0xf, false);
+					const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+					const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dist, 0x130, 0xf, 0xf, true);   // (lane 63: 0, and `| 1` below)
 					const int gain = 4 * ((int)clen_r - (int)clen) + ((int)__clz(dist_r | 1) - (int)__clz(dist | 1));
 					defer = __ballot(clen_r >= clen) & __ballot(gain > 2) & candm & (lanem >> 1);
 				}
