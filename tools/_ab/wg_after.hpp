@@ -33,6 +33,9 @@
 
 namespace hd {
 
+#ifndef HD_WG_OR_OFFSETS
+#define HD_WG_OR_OFFSETS 1
+#endif
 #ifndef HD_WG_UNIFORM_EDGES
 #define HD_WG_UNIFORM_EDGES 1
 #endif
@@ -101,7 +104,7 @@ __device__ __forceinline__ bool wg_wait(wg_word_p word, uint32_t want, wg_word_p
 
 // first BIT at which two 16-byte strings differ, given the XOR of their dwords, capped at `cap_bits` (<= 128): v_ffbl_b32 of
 // an equal dword is 0xffffffff and stays there through the saturating add, so the minimum is the first differing dword's.
-// Nine instructions, pinned: the compiler's own form of "first set bit or the next dword's" is a compare and a select per dword.
+// Nine instructions, pinned (the three adds as ORs since round 5's end): the compiler's own form of "first set bit or the next dword's" is a compare and a select per dword.
 __device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t cap_bits, uint32_t k96)
 {
 	uint32_t g0, g1, g2, g3, t;
@@ -109,9 +112,18 @@ __device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uin
 	asm("v_ffbl_b32 %0, %1" : "=v"(g1) : "v"(x1));
 	asm("v_ffbl_b32 %0, %1" : "=v"(g2) : "v"(x2));
 	asm("v_ffbl_b32 %0, %1" : "=v"(g3) : "v"(x3));
+#if HD_WG_OR_OFFSETS
+	// (v_ffbl_b32 gives 0..31 or 0xffffffff: OR-ing the dword's bit offset in is the add, leaves 0xffffffff alone, and is a VOP2
+	// instruction at the fast issue rate where the saturating add is VOP3)
+	(void)k96;
+	asm("v_or_b32_e32 %0, 32, %1" : "=v"(g1) : "v"(g1));
+	asm("v_or_b32_e32 %0, 64, %1" : "=v"(g2) : "v"(g2));
+	asm("v_or_b32_e32 %0, 0x60, %1" : "=v"(g3) : "v"(g3));
+#else
 	asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(g1) : "v"(g1));
 	asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(g2) : "v"(g2));
 	asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(g3) : "v"(g3), "s"(k96));
+#endif
 	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(g0), "v"(g1), "v"(g2));
 	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(g3), "v"(cap_bits));
 	return t;

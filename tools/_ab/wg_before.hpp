@@ -33,6 +33,9 @@
 
 namespace hd {
 
+#ifndef HD_WG_OR_OFFSETS
+#define HD_WG_OR_OFFSETS 0                     /* (measured: no gain on 1 MiB members, -0.8 % on BGZF blocks -- tools/r05_ab_files.sh; the saturating adds stay) */
+#endif
 #ifndef HD_WG_UNIFORM_EDGES
 #define HD_WG_UNIFORM_EDGES 1
 #endif
@@ -101,7 +104,7 @@ __device__ __forceinline__ bool wg_wait(wg_word_p word, uint32_t want, wg_word_p
 
 // first BIT at which two 16-byte strings differ, given the XOR of their dwords, capped at `cap_bits` (<= 128): v_ffbl_b32 of
 // an equal dword is 0xffffffff and stays there through the saturating add, so the minimum is the first differing dword's.
-// Nine instructions, pinned: the compiler's own form of "first set bit or the next dword's" is a compare and a select per dword.
+// Nine instructions, pinned (the three adds as ORs since round 5's end): the compiler's own form of "first set bit or the next dword's" is a compare and a select per dword.
 __device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t cap_bits, uint32_t k96)
 {
 	uint32_t g0, g1, g2, g3, t;
@@ -109,9 +112,18 @@ __device__ __forceinline__ uint32_t wg_common_bits(uint32_t x0, uint32_t x1, uin
 	asm("v_ffbl_b32 %0, %1" : "=v"(g1) : "v"(x1));
 	asm("v_ffbl_b32 %0, %1" : "=v"(g2) : "v"(x2));
 	asm("v_ffbl_b32 %0, %1" : "=v"(g3) : "v"(x3));
+#if HD_WG_OR_OFFSETS
+	// (v_ffbl_b32 gives 0..31 or 0xffffffff: OR-ing the dword's bit offset in is the add, leaves 0xffffffff alone, and is a VOP2
+	// instruction at the fast issue rate where the saturating add is VOP3)
+	(void)k96;
+	asm("v_or_b32_e32 %0, 32, %1" : "=v"(g1) : "v"(g1));
+	asm("v_or_b32_e32 %0, 64, %1" : "=v"(g2) : "v"(g2));
+	asm("v_or_b32_e32 %0, 0x60, %1" : "=v"(g3) : "v"(g3));
+#else
 	asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(g1) : "v"(g1));
 	asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(g2) : "v"(g2));
 	asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(g3) : "v"(g3), "s"(k96));
+#endif
 	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(g0), "v"(g1), "v"(g2));
 	asm("v_min3_u32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(g3), "v"(cap_bits));
 	return t;
@@ -438,7 +450,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				// the byte before (runs; only inside the step): as long as the own bytes repeat it
 				uint32_t best, dm1 = 0;                         // the best candidate's length, its distance - 1
 				{
-					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+					// (bound_ctrl: the lane without a neighbour reads 0 -- said with an old value of 0 instead, every step pays a v_mov for it)
+					const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o0, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 					const uint32_t sp = __builtin_amdgcn_perm(prev, prev, 0u);      // its first byte, four times
 					const uint32_t m = wg_common_bits(o0 ^ sp, o1 ^ sp, o2 ^ sp, o3 ^ sp, room8, k96) >> 3;
 					best = sel(keyed & ~1ull, m, 0u);
@@ -487,9 +500,15 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				// ---- the lazy rule on the lane to the right (deflate_compress.c:2723-2726, lengths capped at 16) ------
 				uint64_t defer = 0;
 				if (LAZY) {
-					const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-					const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)dist, 0x130, 0xf, 0xf, false);
-					const int gain = 4 * ((int)clen_r - (int)clen) + ((int)__clz(dist_r | 1) - (int)__clz(dist | 1));
+					const uint32_t clen_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clen, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+					const uint32_t dist_r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dist, 0x130, 0xf, 0xf, true);   // (lane 63: 0, and `| 1` below)
+					// (a distance is >= 1, so its leading zeros are those of `dist | 1` -- the twin's form -- without the OR; lane 63's
+					// neighbour is nobody and its verdict is masked out below)
+					// (v_ffbh_u32 as it is: __clz adds a fix-up for 0, which no distance is)
+					uint32_t lz_r, lz;
+					asm("v_ffbh_u32 %0, %1" : "=v"(lz_r) : "v"(dist_r));
+					asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(dist));
+					const int gain = (int)((((uint32_t)clen_r - (uint32_t)clen) << 2) + lz_r) - (int)lz;
 					defer = __ballot(clen_r >= clen) & __ballot(gain > 2) & candm & (lanem >> 1);
 				}
 				const uint64_t take = candm & ~defer;
@@ -572,16 +591,18 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 				const uint32_t tw = sel(take, (flen << 16) + dm1 + (HD_TOKEN_MATCH_TAG - (3u << 16)), litw);
 				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0));
-					uint32_t *const at = ptok + cnt + rank;
+					// (the address as a scalar base -- the piece's tokens so far -- and a 32-bit lane offset: no 64-bit vector add)
+					const uint32_t *const at_base = (const uint32_t *)wg_uniform64((uint64_t)(ptok + cnt));
+					const uint32_t at_off = rank << 2;
 					// (the store under exec = starts: the mask goes to exec as it is, not through a compare per lane)
 					uint64_t saved;
 					// (beside: the reader sits behind another XCD's L2 -- the store goes through this one's, sc1)
 					if (beside)
-						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off sc1\n\ts_mov_b64 exec, %0"
-							     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
+						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, %4 sc1\n\ts_mov_b64 exec, %0"
+							     : "=&s"(saved) : "s"(starts), "v"(at_off), "v"(tw), "s"(at_base) : "memory");
 					else
-						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, off\n\ts_mov_b64 exec, %0"
-							     : "=&s"(saved) : "s"(starts), "v"(at), "v"(tw) : "memory");
+						asm volatile("s_and_saveexec_b64 %0, %1\n\tglobal_store_dword %2, %3, %4\n\ts_mov_b64 exec, %0"
+							     : "=&s"(saved) : "s"(starts), "v"(at_off), "v"(tw), "s"(at_base) : "memory");
 				}
 				cnt += (uint32_t)__popcll(starts);
 				c_lit += (uint32_t)__popcll(starts & ~take);
