@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t nb0 = e0 >> 16;
 		const uint32_t code = sel(vmask, sel(mmask, (e0 & 0xffff) | (dpart << nb0), e0 & 0xffff), 0u);
 		const uint32_t nbits = sel(vmask, sel(mmask, nb0 + 5 + deb, nb0), 0u);
-		const uint32_t incl = wave_incl_scan(nbits);
+		const uint32_t incl = wave_incl_scan<true>(nbits);
 		const uint32_t total = readlane(incl, 63);
 		if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit)
 			return use_static = false;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			tcode = lane ? 0xffffu : 0u;
 			nb = 16;
 		}
-		const uint32_t incl = wave_incl_scan(nb);
+		const uint32_t incl = wave_incl_scan<true>(nb);
 		put(tcode, nb, incl, 32);
 	}
 	bitpos = (bitpos + 7) & ~7u;
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 			tcode = frame_trl_field(a.frame, lane, crcv, n_own);
 			nb = 16;
 		}
-		const uint32_t incl = wave_incl_scan(nb);
+		const uint32_t incl = wave_incl_scan<true>(nb);
 		put(tcode, nb, incl, 8 * trl);
 	}
 	// final flush: everything left, including the last partial dword (< 256 dwords)

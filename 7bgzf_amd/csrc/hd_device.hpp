@@ -76,24 +76,28 @@ struct ClockStamp {
 #endif
 enum { HD_CLK_STATIC = 0, HD_CLK_DYNAMIC = 1, HD_CLK_INFLATE = 2, HD_CLK_PARSE = 3 };
 
-template <int CTRL, int ROW_MASK, int BANK_MASK>
+// BC: bound_ctrl -- "a lane without a source reads 0" said by the instruction instead of by an old value of 0.  The same values; with it
+// the v_mov that seeds the old value is not emitted where no mask is set (two per wave_incl_scan).  Taken where it measured as a gain
+// (the level-1 kernel: +0.3 %), left where it did not (k_inflate: -1 %, the emit kernels: nothing) -- tools/r05_ab_dev.sh
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BC = false>
 __device__ __forceinline__ uint32_t dpp0(uint32_t v)
 {
 	// lanes whose DPP source is masked off or out of the row read 0
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, BC);
 }
 
 // inclusive prefix sum over the 64 lanes: 7 DPP adds, no LDS
+template <bool BC = false>
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x)
 {
 	uint32_t v = x;
-	v += dpp0<0x111, 0xf, 0xf>(x);   // row_shr:1
-	v += dpp0<0x112, 0xf, 0xf>(x);   // row_shr:2
-	v += dpp0<0x113, 0xf, 0xf>(x);   // row_shr:3
-	v += dpp0<0x114, 0xf, 0xe>(v);   // row_shr:4, banks 1-3
-	v += dpp0<0x118, 0xf, 0xc>(v);   // row_shr:8, banks 2-3
-	v += dpp0<0x142, 0xa, 0xf>(v);   // row_bcast:15 -> rows 1,3
-	v += dpp0<0x143, 0xc, 0xf>(v);   // row_bcast:31 -> rows 2,3
+	v += dpp0<0x111, 0xf, 0xf, BC>(x);   // row_shr:1
+	v += dpp0<0x112, 0xf, 0xf, BC>(x);   // row_shr:2
+	v += dpp0<0x113, 0xf, 0xf, BC>(x);   // row_shr:3
+	v += dpp0<0x114, 0xf, 0xe, BC>(v);   // row_shr:4, banks 1-3
+	v += dpp0<0x118, 0xf, 0xc, BC>(v);   // row_shr:8, banks 2-3
+	v += dpp0<0x142, 0xa, 0xf, BC>(v);   // row_bcast:15 -> rows 1,3
+	v += dpp0<0x143, 0xc, 0xf, BC>(v);   // row_bcast:31 -> rows 2,3
 	return v;
 }
 
