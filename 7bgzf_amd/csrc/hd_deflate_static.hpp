@@ -382,6 +382,7 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 	bool use_static = TOK || (a.level >= 1 && cap >= hdr + trl + sfx + 2);   // level 0: stored only
 	if (!TOK && use_static && cap - hdr - trl - sfx < limit)
 		limit = cap - hdr - trl - sfx;
+	const uint32_t limit_bits = limit > 0x1fffffe0u ? 0xffffff00u : 8u * limit;    // (the per-step test in 32 bits; a stream of 2^32 bits is out of the kernel's reach anyway)
 
 	// ---- init LDS -------------------------------------------------------
 	for (uint32_t i = lane; i < HS / 8; i += 64)
@@ -631,7 +632,9 @@ __global__ __launch_bounds__(64) void k_deflate_static(DeflateArgs a)
 		const uint32_t nbits = sel(vmask, sel(mmask, nb0 + 5 + deb, nb0), 0u);
 		const uint32_t incl = wave_incl_scan<true>(nbits);
 		const uint32_t total = readlane(incl, 63);
-		if ((uint64_t)(bitpos - paybase) + total + 7 > 8ull * limit)
+		// (in 32 bits: a 64-bit compare of two uniform values is a VECTOR compare on this machine -- v_mov_b64 + v_cmp_gt_u64 per step.
+		// limit_bits <= 0xffffff00 and what has passed this test is <= limit_bits, so the sum cannot wrap)
+		if ((bitpos - paybase) + total + 7 > limit_bits)
 			return use_static = false;
 		put(code, nbits, incl, total);
 		flush_ready();
