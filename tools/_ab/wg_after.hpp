@@ -412,14 +412,6 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 			uint32_t E = P0;                           // first position no token covers yet
 			uint32_t cnt = 0, c_lit = 0, c_long = 0;
 			uint32_t *const ptok = tok + P0;           // the piece's tokens
-#if HD_WG_UNIFORM_EDGES
-			// (the room to the piece's end, carried through the steps: 16 bytes until the piece's last step -- once a step is that near the
-			// end, so are the ones behind it; set here, touched in the loop only there: a v_mov per step otherwise.  The empty asm statement
-			// pins the value to a register the compiler cannot fold back into a constant.  The window's reach the same way -- 32 KiB for
-			// every piece beyond the block's first 32 KiB -- was measured and lost: a branch per step for the pieces before)
-			uint32_t room8 = (uint32_t)HD_WG_VCAP << 3;
-			asm volatile("" : "+v"(room8));
-#endif
 			for (uint32_t t = 0; t < nst; t++) {
 				const uint32_t S = P0 + 64 * t, p = S + lane;
 				const uint32_t lanes = pend - S < 64 ? pend - S : 64;
@@ -444,7 +436,8 @@ __global__ __launch_bounds__(64 * HD_WG_WAVES) __attribute__((amdgpu_waves_per_e
 					keyed = __ballot(p + HD_LAZY_KEY_BYTES <= n);
 					asm volatile("" : "+s"(keyed));
 				}
-				if (S + 63 + HD_WG_VCAP > pend) {                                // in bits (keyed lanes: p < pend)
+				uint32_t room8 = (uint32_t)HD_WG_VCAP << 3;                      // in bits (keyed lanes: p < pend)
+				if (S + 63 + HD_WG_VCAP > pend) {
 					room8 = min(pend - p, (uint32_t)HD_WG_VCAP) << 3;
 					asm volatile("" : "+v"(room8));
 				}
